@@ -1,0 +1,214 @@
+/*
+ * mm_hausdorff.h -- C ABI of the MI355X Hausdorff pose-search engine.
+ *
+ * Drop-in boundary for the three `search_range(cost = hausdorff_distance o rotate)` call
+ * sites of yungselm/multimoda-rs (paths relative to the reference checkout):
+ *   src/intravascular/processing/align_within.rs:97-119    (within-pullback chain)
+ *   src/intravascular/processing/align_between.rs:46-47    (between-pullback search)
+ *   src/intravascular/centerline_align/align_algorithms.rs:369-441 (refine, angle x index)
+ * and for the metric itself, src/intravascular/processing/process_utils.rs:33-121.
+ *
+ * Plain pointers and sizes only; every pointer is caller-owned host memory unless the
+ * name says `dev`.  All coordinates are f64 SoA (x[], y[]); z never enters the metric
+ * (process_utils.rs:105-107).  Functions return 0 on success or a negative mm_status;
+ * mm_last_error() returns a thread-local message (the reference surfaces anyhow errors
+ * as PyRuntimeError(format!("{e:#}")), binding/functions.rs:228).
+ *
+ * There is NO CPU fallback behind this ABI: without a HIP device every compute entry
+ * point fails with MM_ERR_NO_DEVICE.
+ */
+#ifndef MM_HAUSDORFF_H
+#define MM_HAUSDORFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MM_OK               =  0,
+    MM_ERR_NO_DEVICE    = -1,  /* no HIP device / HIP runtime error            */
+    MM_ERR_INVALID      = -2,  /* bad argument                                 */
+    MM_ERR_TOO_LARGE    = -3,  /* a point set exceeds the kernel's LDS budget  */
+    MM_ERR_NO_FRAMES    = -4,  /* "Geometry contains no frames"      (align_within.rs:32-34) */
+    MM_ERR_NO_POINTS    = -5,  /* "Lumen contours have no points"    (align_within.rs:35-37) */
+    MM_ERR_SAMPLE_SIZE  = -6,  /* "sample_size must be > 0"          (align_within.rs:38-40) */
+    MM_ERR_HIP          = -7,
+    MM_ERR_REF_INDEX    = -8   /* reference-frame index out of range (Rust would panic)      */
+} mm_status;
+
+/* precision of the candidate scoring */
+enum {
+    MM_PRECISION_F64 = 0, /* every candidate scored in f64 with the reference's exact
+                             operation order (bit-identical costs)                        */
+    MM_PRECISION_F32 = 1  /* f32 screening of every candidate + f64 exact re-score of all
+                             candidates within 2*delta of the f32 minimum; the winner and
+                             its cost are bit-identical to MM_PRECISION_F64              */
+};
+
+/* flags of one search */
+enum {
+    MM_SEARCH_SKIP_ZERO = 1 /* apply ContourPoint::rotate's `angle == 0.0 -> unchanged`
+                               shortcut (contour_point.rs:39-41); set for the within
+                               closure, clear for the between closure (align_between.rs:194-209) */
+};
+
+typedef struct mm_engine mm_engine; /* one HIP device + stream + grow-only workspaces */
+
+/* ---- runtime ---------------------------------------------------------------------- */
+int         mm_device_count(void);
+const char* mm_last_error(void);
+const char* mm_version(void);
+
+/* device < 0 -> current device.  stream == NULL -> the engine creates its own stream;
+ * otherwise `stream` is a hipStream_t the caller owns (e.g. torch's current stream), and
+ * every kernel of this engine is launched on it. */
+int  mm_engine_create(int device, void* stream, mm_engine** out);
+void mm_engine_destroy(mm_engine* e);
+int  mm_engine_synchronize(mm_engine* e);
+void* mm_engine_stream(mm_engine* e);
+
+/* ---- the metric: hausdorff_distance (process_utils.rs:78-82) ------------------------ */
+/* f64-exact on the device; empty set on either side -> 0.0 (process_utils.rs:86-88). */
+int mm_hausdorff_2d(mm_engine* e,
+                    const double* ax, const double* ay, int na,
+                    const double* bx, const double* by, int nb,
+                    double* out);
+
+/* ---- candidate enumeration of search_range (process_utils.rs:43-67) ---------------- */
+/* Host-side, exact: writes up to `cap` wrapped angles, returns their count. When the
+ * reference returns early (step <= 0, or stop <= start) *degenerate = 1 and
+ * *early_value is the value it returns. has_center = 0 <=> center_angle = None. */
+int64_t mm_search_angles(double step_deg, double range_deg, int has_center, double center,
+                         double limes_deg, double* out, int64_t cap,
+                         int* degenerate, double* early_value);
+
+/* ---- one search: search_range(|a| hausdorff(ref, rotate(tgt, a, centre))) ----------- */
+/* `angles` is the host-generated candidate list (radians, already wrapped). Returns the
+ * FIRST index of minimal cost (process_utils.rs:72 ordered reduce). all_costs (nullable,
+ * n_angles) receives sqrt'ed costs: exact for re-scored candidates, f32-derived for the
+ * rest when precision == MM_PRECISION_F32. */
+int mm_best_rotation(mm_engine* e,
+                     const double* rx, const double* ry, int nr,
+                     const double* tx, const double* ty, int nt,
+                     double cx, double cy,
+                     const double* angles, int n_angles, int flags, int precision,
+                     double* best_angle, double* best_cost, int* best_idx,
+                     double* all_costs);
+
+/* ---- batched searches (one launch sequence for all pairs) ---------------------------- */
+/* Pair p uses reference points  ref_[xy][ref_off[p] .. ref_off[p+1]),
+ *             target points     tgt_[xy][tgt_off[p] .. tgt_off[p+1]),
+ *             candidates        angles[ang_off[p] .. ang_off[p+1]),
+ *             rotation centre   (cx[p], cy[p]),  flags[p] (nullable -> 0).
+ * Outputs (n_pairs each): best_idx (index into the pair's own candidate list),
+ * best_angle, best_cost; n_rescored (nullable) = f64 re-scores done for the pair;
+ * all_costs (nullable, ang_off[n_pairs] entries). */
+int mm_best_rotation_batch(mm_engine* e, int n_pairs,
+                           const int64_t* ref_off, const double* ref_x, const double* ref_y,
+                           const int64_t* tgt_off, const double* tgt_x, const double* tgt_y,
+                           const int64_t* ang_off, const double* angles,
+                           const double* cx, const double* cy, const int32_t* flags,
+                           int precision,
+                           int32_t* best_idx, double* best_angle, double* best_cost,
+                           int32_t* n_rescored, double* all_costs);
+
+/* ---- device-resident plan: upload once, run many times ------------------------------ */
+/* Same arguments as mm_best_rotation_batch; the batch is staged into HBM at creation.
+ * angle_begin/angle_end restrict every pair's candidate list to the slice
+ * [angle_begin, min(angle_end, n_angles_p)) -- the shard one rank owns when the candidate
+ * axis is split across GPUs; pass 0 / INT32_MAX for everything. */
+typedef struct mm_plan mm_plan;
+int  mm_plan_create(mm_engine* e, int n_pairs,
+                    const int64_t* ref_off, const double* ref_x, const double* ref_y,
+                    const int64_t* tgt_off, const double* tgt_x, const double* tgt_y,
+                    const int64_t* ang_off, const double* angles,
+                    const double* cx, const double* cy, const int32_t* flags,
+                    int precision, int32_t angle_begin, int32_t angle_end,
+                    mm_plan** out);
+void mm_plan_destroy(mm_plan* p);
+/* Enqueue the whole search (screen -> shortlist -> exact re-score -> argmin) on the
+ * engine's stream; asynchronous. */
+int  mm_plan_run(mm_plan* p);
+/* Enqueue only the dominant screening kernel (for roofline timing with HIP events). */
+int  mm_plan_run_screen_only(mm_plan* p);
+/* Wait for the stream and copy results to the host (same meaning as the batch call;
+ * best_idx is relative to the pair's FULL candidate list, -1 if the slice was empty). */
+int  mm_plan_fetch(mm_plan* p, int32_t* best_idx, double* best_angle, double* best_cost,
+                   int32_t* n_rescored, double* all_costs);
+/* Device pointers of the per-pair results (n_pairs entries each) for collectives issued
+ * by the caller (torch.distributed / RCCL): best cost (f64) and best index (i32). */
+int  mm_plan_result_dev(mm_plan* p, void** best_cost_dev, void** best_idx_dev);
+/* Average device time (ms) of `iters` back-to-back runs, measured with hipEvents on the
+ * engine's stream; screen_only selects mm_plan_run_screen_only. */
+int  mm_plan_time(mm_plan* p, int iters, int screen_only, float* ms_avg);
+/* Work accounting of one run: candidates screened, pair-distance evaluations the
+ * reference algorithm performs for them (2*Na*Nb each), bytes staged in HBM. */
+int  mm_plan_stats(mm_plan* p, int64_t* n_candidates, double* pair_evals, int64_t* hbm_bytes);
+
+/* ---- host orchestration mirroring the reference's L2 drivers -------------------------- */
+/* Flat (CSR) mirror of Geometry/Frame (types/native/geometry.rs:9-12, frame.rs:8-15);
+ * all arrays caller-owned and updated in place.  Points are AoS xyz triples. */
+typedef struct {
+    int32_t   n_frames;
+    uint32_t* id;          /* [F]   Frame.id                           */
+    uint32_t* lumen_id;    /* [F]   Frame.lumen.id                     */
+    uint32_t* orig_frame;  /* [F]   Frame.lumen.original_frame         */
+    double*   centroid;    /* [F*3] Frame.centroid                     */
+    int64_t*  lumen_off;   /* [F+1]                                    */
+    double*   lumen;       /* xyz triples                              */
+    int32_t   has_catheter;/* frames[0].extras contains Catheter       */
+    int64_t*  cath_off;    /* [F+1] or NULL                            */
+    double*   cath;
+    int64_t*  extra_off;   /* [F+1] or NULL: all other extras contours */
+    double*   extra;
+    uint8_t*  has_ref;     /* [F]   Frame.reference_point.is_some()    */
+    double*   ref;         /* [F*3]                                    */
+} mm_geometry;
+
+/* AlignLog (align_within.rs:14-22), returned to Python as 7-tuples (functions.rs:26-40) */
+typedef struct {
+    uint32_t contour_id;
+    uint32_t matched_to;
+    double   rot_deg;
+    double   tx, ty;
+    double   cx, cy;
+} mm_alignlog;
+
+/* align_frames_in_geometry, lines 24-134 (align_within.rs): the sequential chain for
+ * n_geoms pullbacks advanced in lockstep (the reference runs them in 4 crossbeam threads,
+ * entry.rs:140-203); every step is one batched device search.  logs[g] must hold
+ * geoms[g]->n_frames - 1 entries.  mode: 0 = faithful chain (every step's candidates are
+ * scored on the chain state), 1 = decoupled screening of all frame pairs in one launch
+ * followed by the exact chain pass (same results). */
+int mm_align_within(mm_engine* e, int n_geoms, mm_geometry** geoms,
+                    double step_deg, double range_deg, int bruteforce, int64_t sample_size,
+                    int precision, int mode, mm_alignlog** logs, int64_t* pose_evals);
+
+/* align_between_geometries (align_between.rs:11-68) for n_pairs independent (a,b) pairs
+ * (entry.rs:206-277 runs two at a time); b is moved onto a.  best_rotation[p] receives
+ * the searched angle (radians). */
+int mm_align_between(mm_engine* e, int n_pairs, mm_geometry** a, mm_geometry** b,
+                     double rot_deg, double step_rot_deg, int64_t sample_size,
+                     int precision, double* best_rotation, int64_t* pose_evals);
+
+/* Sets exactly as the chain builds them for frame i (align_within.rs:45-59,173-191):
+ * downsample(lumen, S) ++ downsample(catheter, ceil(n_cath*S/len_lumen0)).  Writes up to
+ * cap points to out_x/out_y, returns the count. */
+int64_t mm_catheter_lumen_vec(const mm_geometry* g, int32_t frame, int64_t sample_size,
+                              double* out_x, double* out_y, int64_t cap);
+
+/* extract_geometry_points_with_frame_info (align_between.rs:154-178) */
+int64_t mm_extract_between_points(const mm_geometry* g, int64_t sample_size,
+                                  double* out_x, double* out_y, int64_t cap);
+
+/* Frame::translate / Frame::rotate (frame.rs:17-64) on frame i of a flat geometry. */
+void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double dz);
+void mm_frame_rotate(mm_geometry* g, int32_t i, double angle, double cx, double cy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,26 @@
+"""multimoda-rs_amd -- MI355X-native Hausdorff pose-search engine.
+
+One hot path of yungselm/multimoda-rs (the brute-force / coarse-to-fine Hausdorff rotation
+search of ``src/intravascular``) rebuilt for gfx950: hand-written HIP kernels behind a
+C ABI (``include/mm_hausdorff.h``), host orchestration in C++, and this thin Python layer
+that mirrors the reference's ``mm.from_array_*`` / ``mm.from_file_*`` entry points for
+that path.  Import as ``import multimoda_rs_amd as mm`` (root-level shim), since the
+package directory name contains a hyphen.
+"""
+from __future__ import annotations
+
+from . import _native
+from ._native import (MM_PRECISION_F32, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine, Plan,
+                      device_count, search_angles)
+from .geometry import (FlatGeometry, align_between, align_within, between_points, catheter_points,
+                       contour_centroid, search_set)
+from .synth import synthetic_case, synthetic_pullback
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "Engine", "Batch", "Plan", "FlatGeometry", "device_count", "search_angles",
+    "align_within", "align_between", "search_set", "between_points",
+    "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
+    "MM_PRECISION_F32", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
+]

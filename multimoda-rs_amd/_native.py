@@ -1,0 +1,358 @@
+"""ctypes binding of ``libmm_hausdorff.so`` (the C ABI declared in ``include/mm_hausdorff.h``).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is visible
+when an :class:`Engine` is created, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmm_hausdorff.so")
+
+MM_PRECISION_F64 = 0
+MM_PRECISION_F32 = 1
+MM_SEARCH_SKIP_ZERO = 1
+
+EXPORTS = [
+    "mm_device_count", "mm_last_error", "mm_version",
+    "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream",
+    "mm_hausdorff_2d", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
+    "mm_plan_create", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
+    "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
+    "mm_align_within", "mm_align_between", "mm_catheter_lumen_vec", "mm_extract_between_points",
+    "mm_frame_translate", "mm_frame_rotate",
+]
+
+
+class MMGeometry(C.Structure):
+    """``mm_geometry`` (include/mm_hausdorff.h)."""
+    _fields_ = [
+        ("n_frames", C.c_int32),
+        ("id", C.c_void_p),
+        ("lumen_id", C.c_void_p),
+        ("orig_frame", C.c_void_p),
+        ("centroid", C.c_void_p),
+        ("lumen_off", C.c_void_p),
+        ("lumen", C.c_void_p),
+        ("has_catheter", C.c_int32),
+        ("cath_off", C.c_void_p),
+        ("cath", C.c_void_p),
+        ("extra_off", C.c_void_p),
+        ("extra", C.c_void_p),
+        ("has_ref", C.c_void_p),
+        ("ref", C.c_void_p),
+    ]
+
+
+class MMAlignLog(C.Structure):
+    _fields_ = [
+        ("contour_id", C.c_uint32),
+        ("matched_to", C.c_uint32),
+        ("rot_deg", C.c_double),
+        ("tx", C.c_double),
+        ("ty", C.c_double),
+        ("cx", C.c_double),
+        ("cy", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension; fail loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    P, I, D = C.c_void_p, C.c_int, C.c_double
+    I64, I32 = C.c_int64, C.c_int32
+    L.mm_device_count.restype = I
+    L.mm_last_error.restype = C.c_char_p
+    L.mm_version.restype = C.c_char_p
+    L.mm_engine_create.restype = I
+    L.mm_engine_create.argtypes = [I, P, C.POINTER(P)]
+    L.mm_engine_destroy.restype = None
+    L.mm_engine_destroy.argtypes = [P]
+    L.mm_engine_synchronize.restype = I
+    L.mm_engine_synchronize.argtypes = [P]
+    L.mm_engine_stream.restype = P
+    L.mm_engine_stream.argtypes = [P]
+    L.mm_hausdorff_2d.restype = I
+    L.mm_hausdorff_2d.argtypes = [P, P, P, I, P, P, I, C.POINTER(D)]
+    L.mm_search_angles.restype = I64
+    L.mm_search_angles.argtypes = [D, D, I, D, D, P, I64, C.POINTER(I), C.POINTER(D)]
+    L.mm_best_rotation.restype = I
+    L.mm_best_rotation.argtypes = [P, P, P, I, P, P, I, D, D, P, I, I, I, C.POINTER(D), C.POINTER(D),
+                                   C.POINTER(I), P]
+    batch_args = [P, I, P, P, P, P, P, P, P, P, P, P, P, I]
+    L.mm_best_rotation_batch.restype = I
+    L.mm_best_rotation_batch.argtypes = batch_args + [P, P, P, P, P]
+    L.mm_plan_create.restype = I
+    L.mm_plan_create.argtypes = batch_args + [I32, I32, C.POINTER(P)]
+    L.mm_plan_destroy.restype = None
+    L.mm_plan_destroy.argtypes = [P]
+    L.mm_plan_run.restype = I
+    L.mm_plan_run.argtypes = [P]
+    L.mm_plan_run_screen_only.restype = I
+    L.mm_plan_run_screen_only.argtypes = [P]
+    L.mm_plan_fetch.restype = I
+    L.mm_plan_fetch.argtypes = [P, P, P, P, P, P]
+    L.mm_plan_result_dev.restype = I
+    L.mm_plan_result_dev.argtypes = [P, C.POINTER(P), C.POINTER(P)]
+    L.mm_plan_time.restype = I
+    L.mm_plan_time.argtypes = [P, I, I, C.POINTER(C.c_float)]
+    L.mm_plan_stats.restype = I
+    L.mm_plan_stats.argtypes = [P, C.POINTER(I64), C.POINTER(D), C.POINTER(I64)]
+    L.mm_align_within.restype = I
+    L.mm_align_within.argtypes = [P, I, P, D, D, I, I64, I, I, P, C.POINTER(I64)]
+    L.mm_align_between.restype = I
+    L.mm_align_between.argtypes = [P, I, P, P, D, D, I64, I, P, C.POINTER(I64)]
+    L.mm_catheter_lumen_vec.restype = I64
+    L.mm_catheter_lumen_vec.argtypes = [C.POINTER(MMGeometry), I32, I64, P, P, I64]
+    L.mm_extract_between_points.restype = I64
+    L.mm_extract_between_points.argtypes = [C.POINTER(MMGeometry), I64, P, P, I64]
+    L.mm_frame_translate.restype = None
+    L.mm_frame_translate.argtypes = [C.POINTER(MMGeometry), I32, D, D, D]
+    L.mm_frame_rotate.restype = None
+    L.mm_frame_rotate.argtypes = [C.POINTER(MMGeometry), I32, D, D, D]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().mm_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = ""):
+    """Map a negative status to RuntimeError, like the reference maps anyhow errors to
+    PyRuntimeError (binding/functions.rs:228)."""
+    if rc != 0:
+        raise RuntimeError(f"{what + ': ' if what else ''}{last_error()} (mm_status {rc})")
+
+
+def device_count() -> int:
+    return int(lib().mm_device_count())
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _xy(a) -> np.ndarray:
+    """array-like of points -> (n, >=2) f64 array ((0, 2) when empty)."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.size == 0:
+        return np.zeros((0, 2), dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] < 2:
+        raise ValueError("point sets must be (n, 2) or (n, 3) arrays")
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def search_angles(step_deg: float, range_deg: float, center: Optional[float] = None,
+                  limes_deg: Optional[float] = None):
+    """Candidate list of ``search_range`` (process_utils.rs:43-67), host-exact.
+    Returns (angles, degenerate, early_value)."""
+    if limes_deg is None:
+        limes_deg = range_deg
+    deg, early = C.c_int(0), C.c_double(0.0)
+    hc, c = (0, 0.0) if center is None else (1, float(center))
+    n = lib().mm_search_angles(step_deg, range_deg, hc, c, limes_deg, None, 0, C.byref(deg), C.byref(early))
+    out = np.empty(int(n), dtype=np.float64)
+    if n:
+        lib().mm_search_angles(step_deg, range_deg, hc, c, limes_deg, _ptr(out), n, C.byref(deg), C.byref(early))
+    return out, bool(deg.value), early.value
+
+
+class Batch:
+    """Host-side description of a batch of searches (SoA f64 + CSR offsets)."""
+
+    def __init__(self, refs: Sequence[np.ndarray], tgts: Sequence[np.ndarray], angle_lists: Sequence[np.ndarray],
+                 centres: Sequence[Sequence[float]], flags: Optional[Sequence[int]] = None):
+        n = len(refs)
+        assert len(tgts) == n and len(angle_lists) == n and len(centres) == n
+        self.n_pairs = n
+
+        def pack(sets):
+            arrs = [_xy(s) for s in sets]
+            off = np.zeros(n + 1, dtype=np.int64)
+            off[1:] = np.cumsum([a.shape[0] for a in arrs])
+            xs = np.empty(int(off[-1]), dtype=np.float64)
+            ys = np.empty(int(off[-1]), dtype=np.float64)
+            for i, a in enumerate(arrs):
+                xs[off[i]:off[i + 1]] = a[:, 0]
+                ys[off[i]:off[i + 1]] = a[:, 1]
+            return off, xs, ys
+
+        self.ref_off, self.ref_x, self.ref_y = pack(refs)
+        self.tgt_off, self.tgt_x, self.tgt_y = pack(tgts)
+        self.ang_off = np.zeros(n + 1, dtype=np.int64)
+        self.ang_off[1:] = np.cumsum([len(a) for a in angle_lists])
+        self.angles = (np.concatenate([_f64(a) for a in angle_lists]) if n and self.ang_off[-1] > 0
+                       else np.zeros(0, dtype=np.float64))
+        c = np.asarray(centres, dtype=np.float64).reshape(n, 2) if n else np.zeros((0, 2))
+        self.cx = np.ascontiguousarray(c[:, 0])
+        self.cy = np.ascontiguousarray(c[:, 1])
+        self.flags = np.ascontiguousarray(np.zeros(n, dtype=np.int32) if flags is None
+                                          else np.asarray(flags, dtype=np.int32))
+
+    def _args(self):
+        return [self.n_pairs, _ptr(self.ref_off), _ptr(self.ref_x), _ptr(self.ref_y),
+                _ptr(self.tgt_off), _ptr(self.tgt_x), _ptr(self.tgt_y),
+                _ptr(self.ang_off), _ptr(self.angles), _ptr(self.cx), _ptr(self.cy), _ptr(self.flags)]
+
+
+class Engine:
+    """One HIP device + stream (``mm_engine``)."""
+
+    def __init__(self, device: int = -1, stream: Optional[int] = None):
+        self._h = C.c_void_p()
+        check(lib().mm_engine_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)),
+              "mm_engine_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mm_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self) -> int:
+        return int(lib().mm_engine_stream(self._h) or 0)
+
+    def synchronize(self):
+        check(lib().mm_engine_synchronize(self._h), "mm_engine_synchronize")
+
+    # -- metric ----------------------------------------------------------------------
+    def hausdorff(self, a, b) -> float:
+        """``hausdorff_distance`` (process_utils.rs:78-82), f64-exact on the device."""
+        a, b = _xy(a), _xy(b)
+        ax, ay = _f64(a[:, 0]), _f64(a[:, 1])
+        bx, by = _f64(b[:, 0]), _f64(b[:, 1])
+        out = C.c_double(0.0)
+        check(lib().mm_hausdorff_2d(self._h, _ptr(ax), _ptr(ay), len(ax), _ptr(bx), _ptr(by), len(bx), C.byref(out)),
+              "mm_hausdorff_2d")
+        return out.value
+
+    # -- one search ------------------------------------------------------------------
+    def best_rotation(self, ref, tgt, angles, centre, skip_zero=True, precision=MM_PRECISION_F32,
+                      return_costs=False):
+        ref, tgt = _xy(ref), _xy(tgt)
+        rx, ry = _f64(ref[:, 0]), _f64(ref[:, 1])
+        tx, ty = _f64(tgt[:, 0]), _f64(tgt[:, 1])
+        ang = _f64(angles)
+        costs = np.empty(len(ang), dtype=np.float64) if return_costs else None
+        ba, bc, bi = C.c_double(0.0), C.c_double(0.0), C.c_int(-1)
+        check(lib().mm_best_rotation(self._h, _ptr(rx), _ptr(ry), len(rx), _ptr(tx), _ptr(ty), len(tx),
+                                     float(centre[0]), float(centre[1]), _ptr(ang), len(ang),
+                                     MM_SEARCH_SKIP_ZERO if skip_zero else 0, precision,
+                                     C.byref(ba), C.byref(bc), C.byref(bi), _ptr(costs)), "mm_best_rotation")
+        if return_costs:
+            return bi.value, ba.value, bc.value, costs
+        return bi.value, ba.value, bc.value
+
+    # -- batch -----------------------------------------------------------------------
+    def best_rotation_batch(self, batch: Batch, precision=MM_PRECISION_F32, return_costs=False):
+        n = batch.n_pairs
+        bidx = np.full(n, -1, dtype=np.int32)
+        bang = np.zeros(n, dtype=np.float64)
+        bcost = np.zeros(n, dtype=np.float64)
+        nres = np.zeros(n, dtype=np.int32)
+        costs = np.zeros(int(batch.ang_off[-1]), dtype=np.float64) if return_costs else None
+        check(lib().mm_best_rotation_batch(self._h, *batch._args(), precision, _ptr(bidx), _ptr(bang), _ptr(bcost),
+                                           _ptr(nres), _ptr(costs)), "mm_best_rotation_batch")
+        out = {"best_idx": bidx, "best_angle": bang, "best_cost": bcost, "n_rescored": nres}
+        if return_costs:
+            out["costs"] = costs
+        return out
+
+    def plan(self, batch: Batch, precision=MM_PRECISION_F32, angle_begin=0, angle_end=2**31 - 1) -> "Plan":
+        return Plan(self, batch, precision, angle_begin, angle_end)
+
+
+class Plan:
+    """Device-resident batch (``mm_plan``): upload once, run many times."""
+
+    def __init__(self, engine: Engine, batch: Batch, precision, angle_begin, angle_end):
+        self.engine = engine
+        self.batch = batch
+        self._h = C.c_void_p()
+        check(lib().mm_plan_create(engine.handle, *batch._args(), precision, int(angle_begin), int(angle_end),
+                                   C.byref(self._h)), "mm_plan_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mm_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, screen_only=False):
+        f = lib().mm_plan_run_screen_only if screen_only else lib().mm_plan_run
+        check(f(self._h), "mm_plan_run")
+
+    def fetch(self, return_costs=False):
+        n = self.batch.n_pairs
+        bidx = np.full(n, -1, dtype=np.int32)
+        bang = np.zeros(n, dtype=np.float64)
+        bcost = np.zeros(n, dtype=np.float64)
+        nres = np.zeros(n, dtype=np.int32)
+        costs = np.full(int(self.batch.ang_off[-1]), np.nan, dtype=np.float64) if return_costs else None
+        check(lib().mm_plan_fetch(self._h, _ptr(bidx), _ptr(bang), _ptr(bcost), _ptr(nres), _ptr(costs)),
+              "mm_plan_fetch")
+        out = {"best_idx": bidx, "best_angle": bang, "best_cost": bcost, "n_rescored": nres}
+        if return_costs:
+            out["costs"] = costs
+        return out
+
+    def result_dev_ptrs(self):
+        c, i = C.c_void_p(), C.c_void_p()
+        check(lib().mm_plan_result_dev(self._h, C.byref(c), C.byref(i)), "mm_plan_result_dev")
+        return int(c.value or 0), int(i.value or 0)
+
+    def time(self, iters=10, screen_only=False) -> float:
+        ms = C.c_float(0.0)
+        check(lib().mm_plan_time(self._h, iters, int(screen_only), C.byref(ms)), "mm_plan_time")
+        return float(ms.value)
+
+    def stats(self):
+        n, pe, hb = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        check(lib().mm_plan_stats(self._h, C.byref(n), C.byref(pe), C.byref(hb)), "mm_plan_stats")
+        return {"candidates": int(n.value), "pair_evals": float(pe.value), "hbm_bytes": int(hb.value)}

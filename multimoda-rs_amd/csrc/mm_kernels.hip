@@ -1,0 +1,497 @@
+// mm_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the Hausdorff pose search.
+//
+// What one candidate ("pose-eval") is, in the reference (yungselm/multimoda-rs):
+//   process_utils.rs:78-121  hausdorff_distance = max(directed(A,B), directed(B,A)),
+//                            directed = sqrt(max_a min_b ((ax-bx)^2 + (ay-by)^2))
+//   contour_point.rs:38-52   B = rotate(target, angle, centre)
+// The reference evaluates the Na x Nb squared-distance matrix twice (once per direction).
+// (ax-bx)^2 and (bx-ax)^2 are the same bits, so one pass over the matrix with a running
+// row-min (per reference point) and column-min (per target point) yields both directed
+// distances exactly.
+//
+// Mapping to the hardware (no MFMA: this is min/max over a point-set metric):
+//   * one workgroup = (pair, slice of its candidate angles); threads form a 16-wide
+//     lane grid: lj = tid & 15 picks columns (target points), li = tid >> 4 picks rows
+//     (reference points).  A DPP row (16 lanes) shares li, so row-min reduction is
+//     in-row cross-lane; the column-min reduction goes through LDS ds_min atomics.
+//   * reference points live in VGPRs for the whole angle slice (R rows per lane);
+//     the rotated target is staged in LDS once per angle (float2/double2, 16 distinct
+//     consecutive addresses per wave-instruction -> conflict-free broadcast reads).
+//   * f32 screening uses 2x2 micro-tiles: packed v_pk_add/mul/fma_f32 for the distance
+//     and three-operand integer min (v_min3_u32 on the bit patterns, valid because
+//     squared distances are >= +0) for the row/column minima.
+//   * the f64 kernel reproduces the reference's operation order with contraction off,
+//     so its squared distances are bit-identical to the Rust code's.
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "mm_device.h"
+#include "../../include/mm_hausdorff.h"
+
+namespace mm {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Tr;
+template <> struct Tr<float> {
+    using U = unsigned int;
+    using T2 = float2;
+    static __device__ __forceinline__ U bits(float v) { return __float_as_uint(v); }
+    static __device__ __forceinline__ float from(U u) { return __uint_as_float(u); }
+    static __device__ __forceinline__ float big() { return 1.0e18f; }
+    static __device__ __forceinline__ float inf() { return __uint_as_float(0x7f800000u); }
+    static constexpr U INF_BITS = 0x7f800000u;
+};
+template <> struct Tr<double> {
+    using U = unsigned long long;
+    using T2 = double2;
+    static __device__ __forceinline__ U bits(double v) { return (U)__double_as_longlong(v); }
+    static __device__ __forceinline__ double from(U u) { return __longlong_as_double((long long)u); }
+    static __device__ __forceinline__ double big() { return 1.0e150; }
+    static __device__ __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000ll); }
+    static constexpr U INF_BITS = 0x7ff0000000000000ull;
+};
+
+// min of non-negative floats through their bit patterns (v_min_u32 / v_min3_u32).
+static __device__ __forceinline__ float umin3f(float a, float b, float c)
+{
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b), uc = __float_as_uint(c);
+    unsigned m = ua < ub ? ua : ub;
+    m = m < uc ? m : uc;
+    return __uint_as_float(m);
+}
+static __device__ __forceinline__ float umin2f(float a, float b)
+{
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    return __uint_as_float(ua < ub ? ua : ub);
+}
+static __device__ __forceinline__ double dmin2(double a, double b) { return a < b ? a : b; }
+
+// All-reduce min over the 16 lanes of a DPP row (lanes sharing li).  DPP keeps this on
+// the VALU (v_min_u32_dpp) instead of a ds_bpermute round trip through the LDS crossbar:
+// quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror.
+static __device__ __forceinline__ float lane_min16(float f)
+{
+    unsigned v = __float_as_uint(f), o;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = o < v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = o < v ? o : v;
+    return __uint_as_float(v);
+}
+static __device__ __forceinline__ double dpp_f64(double d, const int ctrl_sel)
+{
+    const long long b = __double_as_longlong(d);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break;
+    }
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+static __device__ __forceinline__ double lane_min16(double v)
+{
+    double o;
+    o = dpp_f64(v, 0); v = o < v ? o : v;
+    o = dpp_f64(v, 1); v = o < v ? o : v;
+    o = dpp_f64(v, 2); v = o < v ? o : v;
+    o = dpp_f64(v, 3); v = o < v ? o : v;
+    return v;
+}
+
+template <typename T>
+static __device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        T o = __shfl_xor(v, m, 64);
+        v = (o > v) ? o : v;
+    }
+    return v;
+}
+
+// -------------------------------------------------------------------------------------
+// The search kernel.
+//   T      float (screening) or double (exact)
+//   R      reference points (rows) per lane held in registers
+//   NLI    row lanes per workgroup (threads = 16 * NLI)
+//   EXACT  reference operation order, absolute coordinates, angle==0 shortcut
+// Work items come either from a host-built table (n_work_dev == nullptr) or from the
+// device shortlist queue (count read from *n_work_dev); workgroups stride over them, so
+// every wave terminates whatever the queue length is.
+// -------------------------------------------------------------------------------------
+template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB>
+__global__ void __launch_bounds__(NLI * 16)
+k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
+         int n_work_host, const int* __restrict__ n_work_dev,
+         const T* __restrict__ refx, const T* __restrict__ refy,
+         const T* __restrict__ tgtx, const T* __restrict__ tgty,
+         const T* __restrict__ cosv, const T* __restrict__ sinv,
+         T* __restrict__ out_sq)
+{
+    using TT = Tr<T>;
+    using U = typename TT::U;
+    using T2 = typename TT::T2;
+    constexpr int NT = NLI * 16;
+    constexpr int RP = R / 2;          // row pairs
+    constexpr bool ODD = (R & 1) != 0; // one extra single row
+    constexpr int ROWS_PER_BLOCK = NLI * R;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lj = tid & 15;
+    const int li = tid >> 4;
+    const int n_work = n_work_dev ? *n_work_dev : n_work_host;
+
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const WorkItem w = work[wi];
+        const PairDesc pd = pairs[w.pair];
+        const int na = pd.n_ref, nb = pd.n_tgt;
+        const int nbp = (nb + 15) & ~15;
+        const int ncg = nbp >> 4;  // 16-column groups
+        const int nrb = MULTI_RB ? (na + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK : 1;
+
+        T2* s_tgt = reinterpret_cast<T2*>(smem);
+        T2* s_b = s_tgt + nbp;
+        U* s_colmin = reinterpret_cast<U*>(s_b + nbp);
+        U* s_red = s_colmin + nbp;
+
+        __syncthreads();  // previous work item is done with LDS
+        for (int j = tid; j < nbp; j += NT) {
+            T2 t;
+            if (j < nb) { t.x = tgtx[pd.tgt_off + j]; t.y = tgty[pd.tgt_off + j]; }
+            else        { t.x = -TT::big();           t.y = -TT::big(); }
+            s_tgt[j] = t;
+        }
+
+        // reference rows -> registers (row = rb*ROWS_PER_BLOCK + r*NLI + li); branch-free:
+        // out-of-range rows read a clamped address and are replaced by a far-away point.
+        T ax[R], ay[R];
+        auto load_rows = [&](int rb) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = rb * ROWS_PER_BLOCK + r * NLI + li;
+                const int rc = row < na ? row : na - 1;
+                const T vx = refx[pd.ref_off + rc], vy = refy[pd.ref_off + rc];
+                ax[r] = row < na ? vx : TT::big();
+                ay[r] = row < na ? vy : TT::big();
+            }
+        };
+        if constexpr (!MULTI_RB) load_rows(0);
+
+        const T cx = (T)pd.cx, cy = (T)pd.cy;
+        const bool skip_zero = (pd.flags & MM_SEARCH_SKIP_ZERO) != 0;
+
+        for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
+            const T c = cosv[pd.ang_off + a];
+            const T s = sinv[pd.ang_off + a];
+
+            __syncthreads();  // S0: readers of s_b / s_colmin / s_red from the previous angle are done
+            for (int j = tid; j < nbp; j += NT) {
+                const T2 t = s_tgt[j];
+                T2 b;
+                if (j < nb) {
+                    if constexpr (EXACT) {
+                        // contour_point.rs:39-52 / align_between.rs:194-206
+                        if (skip_zero && s == (T)0) {  // angle == 0.0  <=>  sin(angle) == 0 for f64
+                            b = t;
+                        } else {
+                            const T x = t.x - cx;
+                            const T y = t.y - cy;
+                            b.x = (x * c - y * s) + cx;
+                            b.y = (x * s + y * c) + cy;
+                        }
+                    } else {
+                        b.x = __builtin_fmaf(t.x, c, -(t.y * s));
+                        b.y = __builtin_fmaf(t.x, s, t.y * c);
+                    }
+                } else {
+                    b = t;  // padding stays far away
+                }
+                s_b[j] = b;
+                s_colmin[j] = TT::INF_BITS;
+            }
+            if (tid == 0) s_red[0] = 0;
+            __syncthreads();  // S1
+
+            T rowmax = (T)0;
+            for (int rb = 0; rb < nrb; ++rb) {
+                if constexpr (MULTI_RB) load_rows(rb);
+                T rmin[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) rmin[r] = TT::inf();
+
+                int k = 0;
+                for (; k + 1 < ncg; k += 2) {
+                    const T2 b0 = s_b[k * 16 + lj];
+                    const T2 b1 = s_b[(k + 1) * 16 + lj];
+                    T cm0 = TT::inf(), cm1 = TT::inf();
+                    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+                        for (int q = 0; q < RP; ++q) {
+                            const v2f axp = {ax[2 * q], ax[2 * q + 1]};
+                            const v2f ayp = {ay[2 * q], ay[2 * q + 1]};
+                            const v2f dx0 = axp - (v2f)(b0.x);
+                            const v2f dy0 = ayp - (v2f)(b0.y);
+                            const v2f dx1 = axp - (v2f)(b1.x);
+                            const v2f dy1 = ayp - (v2f)(b1.y);
+                            const v2f d0 = __builtin_elementwise_fma(dy0, dy0, dx0 * dx0);
+                            const v2f d1 = __builtin_elementwise_fma(dy1, dy1, dx1 * dx1);
+                            rmin[2 * q]     = umin3f(rmin[2 * q], d0.x, d1.x);
+                            rmin[2 * q + 1] = umin3f(rmin[2 * q + 1], d0.y, d1.y);
+                            cm0 = umin3f(cm0, d0.x, d0.y);
+                            cm1 = umin3f(cm1, d1.x, d1.y);
+                        }
+                        if constexpr (ODD) {
+                            const float dx0 = ax[R - 1] - b0.x, dy0 = ay[R - 1] - b0.y;
+                            const float dx1 = ax[R - 1] - b1.x, dy1 = ay[R - 1] - b1.y;
+                            const float d0 = __builtin_fmaf(dy0, dy0, dx0 * dx0);
+                            const float d1 = __builtin_fmaf(dy1, dy1, dx1 * dx1);
+                            rmin[R - 1] = umin3f(rmin[R - 1], d0, d1);
+                            cm0 = umin2f(cm0, d0);
+                            cm1 = umin2f(cm1, d1);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            // process_utils.rs:105-110 (no fma: -ffp-contract=off)
+                            const T dx0 = ax[r] - b0.x, dy0 = ay[r] - b0.y;
+                            const T dx1 = ax[r] - b1.x, dy1 = ay[r] - b1.y;
+                            const T d0 = dx0 * dx0 + dy0 * dy0;
+                            const T d1 = dx1 * dx1 + dy1 * dy1;
+                            rmin[r] = dmin2(dmin2(rmin[r], d0), d1);
+                            cm0 = dmin2(cm0, d0);
+                            cm1 = dmin2(cm1, d1);
+                        }
+                    }
+                    atomicMin(&s_colmin[k * 16 + lj], TT::bits(cm0));
+                    atomicMin(&s_colmin[(k + 1) * 16 + lj], TT::bits(cm1));
+                }
+                if (k < ncg) {  // odd tail: one column group
+                    const T2 b0 = s_b[k * 16 + lj];
+                    T cm0 = TT::inf();
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const T dx0 = ax[r] - b0.x, dy0 = ay[r] - b0.y;
+                        T d0;
+                        if constexpr (std::is_same<T, float>::value) {
+                            d0 = __builtin_fmaf(dy0, dy0, dx0 * dx0);
+                            rmin[r] = umin2f(rmin[r], d0);
+                            cm0 = umin2f(cm0, d0);
+                        } else {
+                            d0 = dx0 * dx0 + dy0 * dy0;
+                            rmin[r] = dmin2(rmin[r], d0);
+                            cm0 = dmin2(cm0, d0);
+                        }
+                    }
+                    atomicMin(&s_colmin[k * 16 + lj], TT::bits(cm0));
+                }
+
+                // directed(A,B): min over all columns (16 lanes of the row), max over valid rows
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T v = lane_min16(rmin[r]);
+                    const int row = rb * ROWS_PER_BLOCK + r * NLI + li;
+                    if (row < na && v > rowmax) rowmax = v;
+                }
+            }
+            __syncthreads();  // S2: all column minima are in LDS
+
+            // directed(B,A): max over valid columns of the column minima
+            T m = rowmax;
+            for (int j = tid; j < nb; j += NT) {
+                const T v = TT::from(s_colmin[j]);
+                m = (v > m) ? v : m;
+            }
+            m = wave_max(m);
+            if ((tid & 63) == 0) atomicMax(&s_red[0], TT::bits(m));
+            __syncthreads();  // S3
+            if (tid == 0) out_sq[pd.ang_off + a] = TT::from(s_red[0]);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Shortlist: per pair, minimum screened cost and every candidate within 2*delta of it.
+// One 256-thread workgroup per pair.
+// -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_shortlist(const PairDesc* __restrict__ pairs, const float* __restrict__ sq32,
+            uint8_t* __restrict__ flag, WorkItem* __restrict__ items, int* __restrict__ n_items)
+{
+    __shared__ unsigned int s_min;
+    const int p = blockIdx.x;
+    const PairDesc pd = pairs[p];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_min = 0x7f800000u;
+    __syncthreads();
+    unsigned int m = 0x7f800000u;
+    for (int a = tid; a < pd.n_ang; a += 256) {
+        const unsigned int u = __float_as_uint(sq32[pd.ang_off + a]);
+        m = u < m ? u : m;
+    }
+    atomicMin(&s_min, m);
+    __syncthreads();
+    const double hmin = sqrt((double)__uint_as_float(s_min));
+    const double thr = hmin + 2.0 * pd.delta;
+    for (int a = tid; a < pd.n_ang; a += 256) {
+        const double h = sqrt((double)sq32[pd.ang_off + a]);
+        const bool keep = h <= thr;
+        flag[pd.ang_off + a] = keep ? 1 : 0;
+        if (keep) {
+            const int slot = atomicAdd(n_items, 1);
+            WorkItem w; w.pair = p; w.a0 = a; w.cnt = 1; w.pad = 0;
+            items[slot] = w;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Finalize: first index of minimal sqrt'ed exact cost among the re-scored candidates
+// (process_utils.rs:72: reduce_with(|a, b| if b.1 < a.1 { b } else { a }), ordered).
+// -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_finalize(const PairDesc* __restrict__ pairs, const double* __restrict__ sq64,
+           const float* __restrict__ sq32, const uint8_t* __restrict__ flag,
+           double* __restrict__ best_cost, int* __restrict__ best_idx,
+           int* __restrict__ n_rescored, double* __restrict__ all_costs)
+{
+    __shared__ double s_cost[256];
+    __shared__ int s_idx[256];
+    __shared__ int s_cnt[256];
+    const int p = blockIdx.x;
+    const PairDesc pd = pairs[p];
+    const int tid = threadIdx.x;
+    double bc = __longlong_as_double(0x7ff0000000000000ll);
+    int bi = 0x7fffffff, cnt = 0;
+    for (int a = tid; a < pd.n_ang; a += 256) {
+        const bool f = flag ? (flag[pd.ang_off + a] != 0) : true;
+        double h;
+        if (f) {
+            h = sqrt(sq64[pd.ang_off + a]);  // process_utils.rs:120 (max before sqrt == sqrt before max)
+            ++cnt;
+            if (h < bc) { bc = h; bi = a; }  // a increases per thread: first minimum kept
+        } else {
+            h = sqrt((double)sq32[pd.ang_off + a]);
+        }
+        if (all_costs) all_costs[pd.ang_off + a] = h;
+    }
+    s_cost[tid] = bc; s_idx[tid] = bi; s_cnt[tid] = cnt;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            const double oc = s_cost[tid + st];
+            const int oi = s_idx[tid + st];
+            if (oc < s_cost[tid] || (oc == s_cost[tid] && oi < s_idx[tid])) { s_cost[tid] = oc; s_idx[tid] = oi; }
+            s_cnt[tid] += s_cnt[tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool any = s_idx[0] != 0x7fffffff;
+        best_cost[p] = any ? s_cost[0] : __longlong_as_double(0x7ff0000000000000ll);
+        best_idx[p] = any ? (s_idx[0] + pd.ang_begin) : -1;
+        if (n_rescored) n_rescored[p] = s_cnt[0];
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// launch helpers
+// -------------------------------------------------------------------------------------
+static constexpr int LDS_CAP = 160 * 1024 - 256;
+
+size_t lds_bytes_f32(int nbp) { return (size_t)nbp * (8 + 8 + 4) + 16; }
+size_t lds_bytes_f64(int nbp) { return (size_t)nbp * (16 + 16 + 8) + 16; }
+int max_target_points_f32() { return ((LDS_CAP - 16) / 20) & ~15; }
+int max_target_points_f64() { return ((LDS_CAP - 16) / 40) & ~15; }
+const char* screen_kernel_name() { return "k_search<float"; }
+
+template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB>
+static hipError_t launch_one(const BatchDev& b, const WorkItem* work, int n_work, const int* n_work_dev,
+                             int grid, size_t lds, const T* rx, const T* ry, const T* tx, const T* ty,
+                             const T* cv, const T* sv, T* out, hipStream_t s)
+{
+    auto kern = k_search<T, R, NLI, EXACT, MULTI_RB>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NLI * 16), lds, s, b.pairs, work, n_work, n_work_dev,
+                       rx, ry, tx, ty, cv, sv, out);
+    return hipGetLastError();
+}
+
+// Rows-per-lane variants: the smallest R whose single row block covers the largest
+// reference set wins (padding waste is (16*R - na)/na); larger sets loop over row blocks
+// of the widest variant.
+hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
+{
+    if (b.n_work <= 0) return hipSuccess;
+    const size_t lds = lds_bytes_f32(max_nbp);
+    const int grid = b.n_work;
+#define MM_F32(Rv, MRB) launch_one<float, Rv, 16, false, MRB>(b, b.work, b.n_work, nullptr, grid, lds, b.ref32x, b.ref32y, \
+                                                         b.tgt32x, b.tgt32y, b.cos32, b.sin32, b.sq32, s)
+    if (max_na <= 16 * 2) return MM_F32(2, false);
+    if (max_na <= 16 * 8) return MM_F32(8, false);
+    if (max_na <= 16 * 14) return MM_F32(14, false);
+    if (max_na <= 16 * 20) return MM_F32(20, false);
+    if (max_na <= 16 * 26) return MM_F32(26, false);
+    if (max_na <= 16 * 33) return MM_F32(33, false);
+    return MM_F32(32, true);
+#undef MM_F32
+}
+
+template <bool FROM_QUEUE>
+static hipError_t launch_f64(const BatchDev& b, int max_na, int max_nbp, int grid, hipStream_t s)
+{
+    const size_t lds = lds_bytes_f64(max_nbp);
+    const WorkItem* work = FROM_QUEUE ? b.items : b.work;
+    const int* nd = FROM_QUEUE ? b.n_items : nullptr;
+    const int nw = FROM_QUEUE ? 0 : b.n_work;
+#define MM_F64(Rv, NLIv, MRB) launch_one<double, Rv, NLIv, true, MRB>(b, work, nw, nd, grid, lds, b.ref64x, b.ref64y, \
+                                                                 b.tgt64x, b.tgt64y, b.cos64, b.sin64, b.sq64, s)
+    if (max_na <= 16 * 4) return MM_F64(4, 16, false);
+    if (max_na <= 16 * 14) return MM_F64(14, 16, false);
+    if (max_na <= 32 * 9) return MM_F64(9, 32, false);
+    if (max_na <= 32 * 17) return MM_F64(17, 32, false);
+    return MM_F64(16, 32, true);
+#undef MM_F64
+}
+
+hipError_t launch_exact_all(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
+{
+    if (b.n_work <= 0) return hipSuccess;
+    return launch_f64<false>(b, max_na, max_nbp, b.n_work, s);
+}
+
+hipError_t launch_rescore(const BatchDev& b, int max_na, int max_nbp, int total_candidates, hipStream_t s)
+{
+    if (total_candidates <= 0) return hipSuccess;
+    // workgroups stride over the device-side queue; bound the grid, every block exits
+    int grid = total_candidates < 2048 ? total_candidates : 2048;
+    return launch_f64<true>(b, max_na, max_nbp, grid, s);
+}
+
+hipError_t launch_shortlist(const BatchDev& b, hipStream_t s)
+{
+    if (b.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_shortlist, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.sq32, b.flag, b.items, b.n_items);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const BatchDev& b, int use_flags, hipStream_t s)
+{
+    if (b.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.sq64, b.sq32,
+                       use_flags ? b.flag : nullptr, b.best_cost, b.best_idx, b.n_rescored, b.all_costs);
+    return hipGetLastError();
+}
+
+}  // namespace mm

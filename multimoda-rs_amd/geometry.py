@@ -1,0 +1,220 @@
+"""Flat (CSR) geometry container: the host-side mirror of the reference's
+``Geometry { frames: Vec<Frame> }`` (types/native/geometry.rs:9-12, frame.rs:8-15) in the
+layout the C ABI consumes (``mm_geometry``, include/mm_hausdorff.h).
+
+Points are (N, 3) f64 arrays (x, y, z); frames are CSR slices.  ``cath`` is the synthetic
+catheter contour (frame.rs:163-204); ``extra`` carries every other extras contour (eem,
+calcification, sidebranch, wall) concatenated per frame, with ``extra_kind`` telling which
+is which, so that frame transforms move them like the reference does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+def _pts3(a) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    if a.size == 0:
+        return np.zeros((0, 3), dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] not in (2, 3):
+        raise ValueError("points must be (n, 2) or (n, 3)")
+    if a.shape[1] == 2:
+        a = np.concatenate([a, np.zeros((a.shape[0], 1))], axis=1)
+    return np.ascontiguousarray(a)
+
+
+def contour_centroid(points: np.ndarray):
+    """``Contour::compute_centroid`` (contour.rs:213-224): sequential sums / n."""
+    sx = sy = sz = 0.0
+    for p in points:
+        sx += float(p[0]); sy += float(p[1]); sz += float(p[2])
+    n = float(len(points))
+    return (sx / n, sy / n, sz / n)
+
+
+def catheter_points(z: float, image_center=(4.5, 4.5), radius=0.5, n_points=20) -> np.ndarray:
+    """``Frame::create_catheter_points`` for one frame (frame.rs:189-202)."""
+    out = np.empty((n_points, 3), dtype=np.float64)
+    for i in range(n_points):
+        angle = 2.0 * math.pi * float(i) / float(n_points)
+        out[i, 0] = image_center[0] + radius * math.cos(angle)
+        out[i, 1] = image_center[1] + radius * math.sin(angle)
+        out[i, 2] = z
+    return out
+
+
+@dataclass
+class FlatGeometry:
+    ids: np.ndarray                      # (F,) u32  Frame.id
+    lumen_ids: np.ndarray                # (F,) u32  Frame.lumen.id
+    orig_frames: np.ndarray              # (F,) u32  Frame.lumen.original_frame
+    centroids: np.ndarray                # (F,3) f64 Frame.centroid
+    lumen_off: np.ndarray                # (F+1,) i64
+    lumen: np.ndarray                    # (N,3) f64
+    cath_off: Optional[np.ndarray] = None
+    cath: Optional[np.ndarray] = None
+    extra_off: Optional[np.ndarray] = None
+    extra: Optional[np.ndarray] = None
+    has_ref: Optional[np.ndarray] = None  # (F,) u8
+    ref: Optional[np.ndarray] = None      # (F,3) f64
+    label: str = ""
+
+    # ------------------------------------------------------------------------------
+    @property
+    def n_frames(self) -> int:
+        return int(self.ids.shape[0])
+
+    @staticmethod
+    def from_frames(lumens: Sequence[np.ndarray], catheters: Optional[Sequence[np.ndarray]] = None,
+                    centroids=None, ids=None, orig_frames=None, ref_points: Optional[Dict[int, Sequence[float]]] = None,
+                    label: str = "") -> "FlatGeometry":
+        F = len(lumens)
+        lum = [_pts3(l) for l in lumens]
+        off = np.zeros(F + 1, dtype=np.int64)
+        if F:
+            off[1:] = np.cumsum([l.shape[0] for l in lum])
+        if centroids is None:
+            cen = np.array([contour_centroid(l) for l in lum], dtype=np.float64).reshape(F, 3)
+        else:
+            cen = np.array(centroids, dtype=np.float64).reshape(F, 3).copy()
+        idv = np.arange(F, dtype=np.uint32) if ids is None else np.asarray(ids, dtype=np.uint32).copy()
+        g = FlatGeometry(
+            ids=idv,
+            lumen_ids=idv.copy(),
+            orig_frames=(np.arange(F, dtype=np.uint32) if orig_frames is None
+                         else np.asarray(orig_frames, dtype=np.uint32).copy()),
+            centroids=np.ascontiguousarray(cen),
+            lumen_off=off,
+            lumen=np.ascontiguousarray(np.concatenate(lum, axis=0)) if F else np.zeros((0, 3)),
+            label=label,
+        )
+        if catheters is not None:
+            cat = [_pts3(c) for c in catheters]
+            coff = np.zeros(F + 1, dtype=np.int64)
+            coff[1:] = np.cumsum([c.shape[0] for c in cat])
+            g.cath_off = coff
+            g.cath = np.ascontiguousarray(np.concatenate(cat, axis=0))
+        g.has_ref = np.zeros(F, dtype=np.uint8)
+        g.ref = np.zeros((F, 3), dtype=np.float64)
+        if ref_points:
+            for i, p in ref_points.items():
+                g.has_ref[i] = 1
+                g.ref[i] = np.asarray(p, dtype=np.float64)
+        return g
+
+    def copy(self) -> "FlatGeometry":
+        cp = lambda a: None if a is None else a.copy()
+        return FlatGeometry(cp(self.ids), cp(self.lumen_ids), cp(self.orig_frames), cp(self.centroids),
+                            cp(self.lumen_off), cp(self.lumen), cp(self.cath_off), cp(self.cath),
+                            cp(self.extra_off), cp(self.extra), cp(self.has_ref), cp(self.ref), self.label)
+
+    def frame_lumen(self, i: int) -> np.ndarray:
+        return self.lumen[self.lumen_off[i]:self.lumen_off[i + 1]]
+
+    def frame_cath(self, i: int) -> np.ndarray:
+        return self.cath[self.cath_off[i]:self.cath_off[i + 1]]
+
+    # ------------------------------------------------------------------------------
+    def _validate(self):
+        F = self.n_frames
+        for name, dt, shape in (("ids", np.uint32, (F,)), ("lumen_ids", np.uint32, (F,)),
+                                ("orig_frames", np.uint32, (F,)), ("centroids", np.float64, (F, 3)),
+                                ("lumen_off", np.int64, (F + 1,))):
+            a = getattr(self, name)
+            if a.dtype != dt or a.shape != shape or not a.flags.c_contiguous:
+                raise ValueError(f"FlatGeometry.{name}: expected C-contiguous {dt.__name__}{shape}")
+        if self.lumen.dtype != np.float64 or self.lumen.ndim != 2 or self.lumen.shape[1] != 3 \
+                or not self.lumen.flags.c_contiguous or self.lumen.shape[0] != int(self.lumen_off[-1] if F else 0):
+            raise ValueError("FlatGeometry.lumen: expected C-contiguous float64 (N,3) matching lumen_off")
+        for off, arr, nm in ((self.cath_off, self.cath, "cath"), (self.extra_off, self.extra, "extra")):
+            if off is not None:
+                if off.dtype != np.int64 or off.shape != (F + 1,) or arr is None or arr.dtype != np.float64 \
+                        or not arr.flags.c_contiguous or arr.shape != (int(off[-1]), 3):
+                    raise ValueError(f"FlatGeometry.{nm}: inconsistent CSR arrays")
+        if self.has_ref is not None:
+            if self.has_ref.dtype != np.uint8 or self.has_ref.shape != (F,) or self.ref is None \
+                    or self.ref.shape != (F, 3) or self.ref.dtype != np.float64:
+                raise ValueError("FlatGeometry.has_ref/ref: inconsistent arrays")
+
+    def c_struct(self) -> N.MMGeometry:
+        """Borrowed view for the C ABI (arrays stay owned by this object)."""
+        self._validate()
+        g = N.MMGeometry()
+        p = N._ptr
+        g.n_frames = self.n_frames
+        g.id = p(self.ids); g.lumen_id = p(self.lumen_ids); g.orig_frame = p(self.orig_frames)
+        g.centroid = p(self.centroids)
+        g.lumen_off = p(self.lumen_off); g.lumen = p(self.lumen)
+        g.has_catheter = 1 if self.cath_off is not None else 0
+        g.cath_off = p(self.cath_off); g.cath = p(self.cath)
+        g.extra_off = p(self.extra_off); g.extra = p(self.extra)
+        g.has_ref = p(self.has_ref); g.ref = p(self.ref)
+        return g
+
+
+# --------------------------------------------------------------------------------------
+# drivers (host orchestration lives in C++: csrc/mm_host.cpp)
+# --------------------------------------------------------------------------------------
+def align_within(engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: float, range_deg: float,
+                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32, mode: int = 0):
+    """``align_frames_in_geometry`` lines 24-134 (align_within.rs) for several pullbacks in
+    lockstep; geometries are updated in place.  Returns (logs per geometry as 7-tuples
+    ``(id, matched_to, rot_deg, tx, ty, cx, cy)`` -- binding/functions.rs:26-40, pose_evals)."""
+    G = len(geoms)
+    structs = [g.c_struct() for g in geoms]
+    gptrs = (C.POINTER(N.MMGeometry) * G)(*[C.pointer(s) for s in structs])
+    log_bufs = [(N.MMAlignLog * max(g.n_frames - 1, 1))() for g in geoms]
+    lptrs = (C.c_void_p * G)(*[C.cast(b, C.c_void_p) for b in log_bufs])
+    pe = C.c_int64(0)
+    N.check(N.lib().mm_align_within(engine.handle, G, C.cast(gptrs, C.c_void_p), float(step_deg), float(range_deg),
+                                    int(bool(bruteforce)), int(sample_size), int(precision), int(mode),
+                                    C.cast(lptrs, C.c_void_p), C.byref(pe)), "mm_align_within")
+    logs = [[(l.contour_id, l.matched_to, l.rot_deg, l.tx, l.ty, l.cx, l.cy) for l in b[: g.n_frames - 1]]
+            for b, g in zip(log_bufs, geoms)]
+    return logs, int(pe.value)
+
+
+def align_between(engine: N.Engine, pairs: Sequence[Sequence[FlatGeometry]], rot_deg: float, step_rot_deg: float,
+                  sample_size: int, precision: int = N.MM_PRECISION_F32):
+    """``align_between_geometries`` (align_between.rs:11-68) for independent (a, b) pairs; every
+    b is moved onto its a in place.  Returns (best rotations in radians, pose_evals)."""
+    P = len(pairs)
+    sa = [a.c_struct() for a, _ in pairs]
+    sb = [b.c_struct() for _, b in pairs]
+    pa = (C.POINTER(N.MMGeometry) * P)(*[C.pointer(s) for s in sa])
+    pb = (C.POINTER(N.MMGeometry) * P)(*[C.pointer(s) for s in sb])
+    best = np.zeros(P, dtype=np.float64)
+    pe = C.c_int64(0)
+    N.check(N.lib().mm_align_between(engine.handle, P, C.cast(pa, C.c_void_p), C.cast(pb, C.c_void_p), float(rot_deg),
+                                     float(step_rot_deg), int(sample_size), int(precision), N._ptr(best),
+                                     C.byref(pe)), "mm_align_between")
+    return best, int(pe.value)
+
+
+def search_set(geom: FlatGeometry, frame: int, sample_size: int) -> np.ndarray:
+    """The point set the chain builds for one frame (align_within.rs:45-59,173-191), (n,2)."""
+    s = geom.c_struct()
+    cap = int(geom.lumen_off[frame + 1] - geom.lumen_off[frame])
+    if geom.cath_off is not None:
+        cap += int(geom.cath_off[frame + 1] - geom.cath_off[frame])
+    x = np.empty(cap + 1, dtype=np.float64)
+    y = np.empty(cap + 1, dtype=np.float64)
+    n = N.lib().mm_catheter_lumen_vec(C.byref(s), frame, int(sample_size), N._ptr(x), N._ptr(y), cap + 1)
+    return np.stack([x[:n], y[:n]], axis=1)
+
+
+def between_points(geom: FlatGeometry, sample_size: int) -> np.ndarray:
+    """``extract_geometry_points_with_frame_info`` (align_between.rs:154-178), (n,2)."""
+    s = geom.c_struct()
+    n = N.lib().mm_extract_between_points(C.byref(s), int(sample_size), None, None, 0)
+    x = np.empty(int(n), dtype=np.float64)
+    y = np.empty(int(n), dtype=np.float64)
+    N.lib().mm_extract_between_points(C.byref(s), int(sample_size), N._ptr(x), N._ptr(y), int(n))
+    return np.stack([x, y], axis=1)

@@ -1,0 +1,69 @@
+"""Synthetic pullbacks for the benchmark configs (generator is ours).
+
+Four pullbacks (rest-dia, rest-sys, stress-dia, stress-sys), each F frames x M points:
+frame k lumen = ellipse a = 2.5 + 0.3 sin(k/9), b = 1.8 + 0.2 cos(k/7) mm, plus three
+low-order radial harmonics (orders 2..4) whose amplitudes are N(0, 0.05^2) per pullback
+with a small per-frame jitter, sampled at M equal parameter steps, centred at
+(4.5, 4.5) + N(0, 0.1^2), rotated by a random-walk torsion theta_k = theta_{k-1} + N(0, 3 deg),
+z = 0.5 k mm.  Reference point on frame 0; catheter circle n_points = 20, r = 0.5 around
+the image centre.  PCG64 seed = 1234 + pullback id.  Coordinates land in ~2..7 mm like
+examples/data/ivus_rest of the reference.
+
+The geometry is emitted in the state ``build_geometry_from_inputdata`` leaves it in
+(io/build.rs:176-197): every contour starts at its highest-y point and runs
+counter-clockwise, frame 0 is the proximal end, ids are 0..F-1.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import numpy as np
+
+from .geometry import FlatGeometry, catheter_points, contour_centroid
+
+PULLBACK_LABELS = ("rest_dia", "rest_sys", "stress_dia", "stress_sys")
+
+
+def _start_at_highest_y(pts: np.ndarray) -> np.ndarray:
+    return np.roll(pts, -int(np.argmax(pts[:, 1])), axis=0)
+
+
+def synthetic_pullback(n_frames: int, n_points: int = 501, pullback_id: int = 0, seed: int = 1234,
+                       image_center=(4.5, 4.5), radius: float = 0.5, n_catheter: int = 20,
+                       torsion_sigma_deg: float = 3.0) -> FlatGeometry:
+    rng = np.random.Generator(np.random.PCG64(seed + pullback_id))
+    t = np.arange(n_points, dtype=np.float64) * (2.0 * math.pi / n_points)
+    base_amp = rng.normal(0.0, 0.05, size=(3, 2))
+    theta = 0.0
+    lumens, caths, cents = [], [], []
+    for k in range(n_frames):
+        a = 2.5 + 0.3 * math.sin(k / 9.0)
+        b = 1.8 + 0.2 * math.cos(k / 7.0)
+        amp = base_amp + 0.2 * rng.normal(0.0, 0.05, size=(3, 2))
+        rad = np.ones_like(t)
+        for h in range(3):
+            rad = rad + (amp[h, 0] * np.cos((h + 2) * t) + amp[h, 1] * np.sin((h + 2) * t)) / 2.0
+        x = a * np.cos(t) * rad
+        y = b * np.sin(t) * rad
+        if k > 0:
+            theta += rng.normal(0.0, math.radians(torsion_sigma_deg))
+        c, s = math.cos(theta), math.sin(theta)
+        cx = image_center[0] + rng.normal(0.0, 0.1)
+        cy = image_center[1] + rng.normal(0.0, 0.1)
+        z = 0.5 * k
+        pts = np.stack([cx + c * x - s * y, cy + s * x + c * y, np.full_like(t, z)], axis=1)
+        pts = _start_at_highest_y(pts)
+        lumens.append(pts)
+        cents.append(contour_centroid(pts))
+        caths.append(_start_at_highest_y(catheter_points(z, image_center, radius, n_catheter)))
+    ref0 = lumens[0][np.argmax(lumens[0][:, 0])].copy()  # a point on frame 0 (rightmost)
+    g = FlatGeometry.from_frames(lumens, catheters=caths, centroids=cents,
+                                 orig_frames=np.arange(n_frames - 1, -1, -1, dtype=np.uint32),
+                                 ref_points={0: ref0}, label=PULLBACK_LABELS[pullback_id % 4])
+    return g
+
+
+def synthetic_case(n_frames: int, n_points: int = 501, seed: int = 1234) -> List[FlatGeometry]:
+    """The four pullbacks of one full (4-phase) alignment."""
+    return [synthetic_pullback(n_frames, n_points, pullback_id=i, seed=seed) for i in range(4)]
