@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Hausdorff pose search on MI355X.
+
+Metric (BASELINE.json): Hausdorff pose-evals/sec (frames x poses) for a 4-phase full
+alignment, with the best pose identical to the reference algorithm's.
+
+A "step" is one full 4-phase alignment of a synthetic case (4 pullbacks x F frames x 501
+points, N = 521 points per set): 4 within-pullback chains (bruteforce) and the AB|CD,
+AC|BD between-pullback alignments, all through the product's C ABI.  Workloads
+(SURVEY.md section 8(d)):
+  config2: F = 128, step 1 deg,  range 180 deg -> 361 candidates/search (default)
+  config3: F = 512, step 0.5 deg, range 180 deg -> 721 candidates/search
+
+Usage: python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "config2": dict(frames=128, points=501, step_deg=1.0, range_deg=180.0, sample_size=501),
+    "config3": dict(frames=512, points=501, step_deg=0.5, range_deg=180.0, sample_size=501),
+    "tiny": dict(frames=12, points=501, step_deg=2.0, range_deg=180.0, sample_size=501),
+}
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (vector)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md, HBM3E peak
+FLOPS_PER_PAIR_EVAL = 6.0         # 2 sub, 2 mul, 1 add, 1 min
+BYTES_PER_POSE_EVAL = lambda na, nb: (na + nb) * 2 * 4 + 8   # SURVEY 8(d) no-reuse model
+
+
+def full_alignment(mm, eng, geoms, cfg, mode):
+    """One 4-phase alignment (entry.rs:140-277 order); returns (logs, between angles, pose_evals)."""
+    logs, evals = mm.align_within(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                  precision=mm.MM_PRECISION_F32, mode=mode)
+    a, b, c, d = geoms
+    r1, e1 = mm.align_between(eng, [(a, b), (c, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"])
+    r2, e2 = mm.align_between(eng, [(a, c), (b, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"])
+    return logs, np.concatenate([r1, r2]), evals + e1 + e2
+
+
+def cpu_baseline(cfg, geoms, budget_s=12.0):
+    """The CPU oracle (a port of the reference algorithm) timed on this box's host cores on a
+    bounded sample of the same workload: the first frame pairs of pullback 0, all candidates,
+    candidates evaluated in parallel (OpenMP) like the reference's rayon par_iter."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    g = geoms[0]
+    ss = cfg["sample_size"]
+    import multimoda_rs_amd as mm
+    n_angles = len(mm.search_angles(cfg["step_deg"], cfg["range_deg"])[0])
+    done, t_used, pairs = 0, 0.0, 0
+    i = 1
+    while i < g.n_frames and t_used < budget_s and pairs < 64:
+        ref = np.concatenate([mm.search_set(g, i - 1, ss), np.zeros((0, 2))])
+        tgt = mm.search_set(g, i, ss)
+        t0 = time.perf_counter()
+        orc.bruteforce_rotation(ref, tgt, cfg["step_deg"], cfg["range_deg"], float(g.centroids[i, 0]),
+                                float(g.centroids[i, 1]), n_threads=cores)
+        t_used += time.perf_counter() - t0
+        done += n_angles
+        pairs += 1
+        i += 1
+    return {"value": done / t_used, "unit": "pose-evals/s", "cores": cores, "kind": "port",
+            "sample": f"oracle bruteforce search on the first {pairs} frame pairs of pullback 0 "
+                      f"({n_angles} candidates each, N={ss + 20} pts/set), {t_used:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="chain", choices=["chain", "decoupled"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle (slow)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    ge.build()
+    import multimoda_rs_amd as mm
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    cfg = WORKLOADS[args.workload]
+    mode = 0 if args.mode == "chain" else 1
+    base = mm.synthetic_case(cfg["frames"], cfg["points"])
+    eng = mm.Engine(local_rank)
+
+    # pullbacks are independent chains: with N ranks, rank r owns pullbacks r, r+N, ...
+    # (no data-path collective; the between stage needs all four and runs on rank 0)
+    def one_step():
+        geoms = [g.copy() for g in base]
+        if world == 1:
+            return full_alignment(mm, eng, geoms, cfg, mode)
+        mine = [i for i in range(4) if i % world == rank]
+        logs, evals = ([], 0)
+        if mine:
+            logs, evals = mm.align_within(eng, [geoms[i] for i in mine], cfg["step_deg"], cfg["range_deg"], True,
+                                          cfg["sample_size"], precision=mm.MM_PRECISION_F32, mode=mode)
+        return logs, None, evals
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    evals = 0
+    for _ in range(args.steps):
+        res = one_step()
+        evals += res[2]
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+
+    if world > 1:
+        t = torch.tensor([dt, float(evals)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0].item())
+        evals = int(t[1].item())
+
+    if rank == 0:
+        na = nb = cfg["sample_size"] + 20
+        kern_s = prof["ms"] * 1e-3
+        achieved_tflops = prof["pair_evals"] * FLOPS_PER_PAIR_EVAL / kern_s * 1e-12 if kern_s > 0 else 0.0
+        algo_gbs = prof["candidates"] * BYTES_PER_POSE_EVAL(na, nb) / kern_s * 1e-9 if kern_s > 0 else 0.0
+        out = {
+            "metric": "Hausdorff pose-evals/sec (frames x poses) for 4-phase full align; best-pose match",
+            "value": evals / dt,
+            "unit": "pose-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 screen + f64 exact re-score",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: full 4-phase alignment, 4 pullbacks x {cfg['frames']} frames x "
+                                   f"{cfg['points']} pts (N={na} pts/set), {cfg['step_deg']} deg x +-{cfg['range_deg']} deg "
+                                   f"bruteforce grid", "mode": args.mode, "pose_evals_per_step": evals // max(args.steps, 1),
+                       "parallelism": f"{'pullback' if world > 1 else 'single'}-sharded x{world}"},
+            "roofline": {
+                "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "kernel": "mm::k_search<float,33,16,false,false>", "launches": prof["launches"],
+                "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
+                "note": "point-set min/max metric: bounded by fp32 VALU issue (SURVEY 8(d)), not HBM/MFMA; "
+                        "achieved = pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every launch)",
+                "hbm": {"bound": "hbm", "achieved": algo_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_gbs / HBM_PEAK_GBS,
+                        "note": "algorithmic no-reuse bytes ((Na+Nb)*8+8 per pose-eval) / kernel time"},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, base)
+        if args.check:
+            from oracle import oracle as orc
+            from tests.helpers import to_oracle  # type: ignore
+            og = to_oracle(orc, base[0])
+            ol = orc.align_within_chain(og, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                        n_threads=os.cpu_count() or 1)
+            out["check"] = {"pullback0_logs_identical": bool(res[0][0] == ol)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,14 @@ void mm_engine_destroy(mm_engine* e);
 int  mm_engine_synchronize(mm_engine* e);
 void* mm_engine_stream(mm_engine* e);
 
+/* Per-launch timing of the dominant (candidate-scoring) kernel with hipEvents recorded on
+ * the engine's stream around every launch.  mm_engine_profile_read synchronizes, returns
+ * the number of launches, their summed device time (ms), the pair-distance evaluations
+ * (2*Na*Nb per candidate) and candidates they covered, and resets the accumulators. */
+int  mm_engine_profile(mm_engine* e, int enable);
+int  mm_engine_profile_read(mm_engine* e, int64_t* n_launches, double* ms_total,
+                            double* pair_evals, int64_t* candidates);
+
 /* ---- the metric: hausdorff_distance (process_utils.rs:78-82) ------------------------ */
 /* f64-exact on the device; empty set on either side -> 0.0 (process_utils.rs:86-88). */
 int mm_hausdorff_2d(mm_engine* e,

@@ -21,6 +21,7 @@ MM_SEARCH_SKIP_ZERO = 1
 EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
     "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream",
+    "mm_engine_profile", "mm_engine_profile_read",
     "mm_hausdorff_2d", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
@@ -88,6 +89,10 @@ def lib():
     L.mm_engine_synchronize.argtypes = [P]
     L.mm_engine_stream.restype = P
     L.mm_engine_stream.argtypes = [P]
+    L.mm_engine_profile.restype = I
+    L.mm_engine_profile.argtypes = [P, I]
+    L.mm_engine_profile_read.restype = I
+    L.mm_engine_profile_read.argtypes = [P, C.POINTER(I64), C.POINTER(D), C.POINTER(D), C.POINTER(I64)]
     L.mm_hausdorff_2d.restype = I
     L.mm_hausdorff_2d.argtypes = [P, P, P, I, P, P, I, C.POINTER(D)]
     L.mm_search_angles.restype = I64
@@ -255,6 +260,17 @@ class Engine:
 
     def synchronize(self):
         check(lib().mm_engine_synchronize(self._h), "mm_engine_synchronize")
+
+    def profile(self, enable: bool = True):
+        """hipEvent timing around every launch of the scoring kernel (mm_engine_profile)."""
+        check(lib().mm_engine_profile(self._h, int(enable)), "mm_engine_profile")
+
+    def profile_read(self):
+        n, ms, pe, ca = C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
+        check(lib().mm_engine_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(pe), C.byref(ca)),
+              "mm_engine_profile_read")
+        return {"launches": int(n.value), "ms": float(ms.value), "pair_evals": float(pe.value),
+                "candidates": int(ca.value)}
 
     # -- metric ----------------------------------------------------------------------
     def hausdorff(self, a, b) -> float:

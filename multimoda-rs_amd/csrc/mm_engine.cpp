@@ -73,6 +73,28 @@ int Engine::ensure_dev(size_t bytes)
     return MM_OK;
 }
 
+int Engine::profile_begin()
+{
+    if (!profile) return MM_OK;
+    while (events.size() < 2 * (launches + 1)) {
+        hipEvent_t ev;
+        MM_HIP(hipEventCreate(&ev));
+        events.push_back(ev);
+    }
+    MM_HIP(hipEventRecord(events[2 * launches], stream));
+    return MM_OK;
+}
+
+int Engine::profile_end(double pair_evals, int64_t candidates)
+{
+    if (!profile) return MM_OK;
+    MM_HIP(hipEventRecord(events[2 * launches + 1], stream));
+    ++launches;
+    prof_pair_evals += pair_evals;
+    prof_candidates += candidates;
+    return MM_OK;
+}
+
 // -------------------------------------------------------------------------------------
 // plan construction
 // -------------------------------------------------------------------------------------
@@ -269,9 +291,12 @@ int Plan::run(bool screen_only)
         return MM_OK;
     }
     hipError_t e;
+    int prc;
     if (precision == MM_PRECISION_F32) {
+        if ((prc = eng->profile_begin())) return prc;
         e = launch_screen_f32(dev, max_na, max_nbp, s);
         if (e != hipSuccess) return hip_error(e, "screen kernel launch");
+        if ((prc = eng->profile_end(pair_evals, A))) return prc;
         if (screen_only) return MM_OK;
         MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
         e = launch_shortlist(dev, s);
@@ -281,8 +306,10 @@ int Plan::run(bool screen_only)
         e = launch_finalize(dev, 1, s);
         if (e != hipSuccess) return hip_error(e, "finalize kernel launch");
     } else {
+        if ((prc = eng->profile_begin())) return prc;
         e = launch_exact_all(dev, max_na, max_nbp, s);
         if (e != hipSuccess) return hip_error(e, "exact kernel launch");
+        if ((prc = eng->profile_end(pair_evals, A))) return prc;
         if (screen_only) return MM_OK;
         e = launch_finalize(dev, 0, s);
         if (e != hipSuccess) return hip_error(e, "finalize kernel launch");
@@ -397,6 +424,7 @@ void mm_engine_destroy(mm_engine* h)
     (void)hipStreamSynchronize(e->stream);
     if (e->host_buf) (void)hipHostFree(e->host_buf);
     if (e->dev_buf) (void)hipFree(e->dev_buf);
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -406,6 +434,36 @@ int mm_engine_synchronize(mm_engine* h)
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     MM_HIP(hipStreamSynchronize(e->stream));
+    return MM_OK;
+}
+
+int mm_engine_profile(mm_engine* h, int enable)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    MM_HIP(hipStreamSynchronize(e->stream));
+    e->profile = enable != 0;
+    e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0;
+    return MM_OK;
+}
+
+int mm_engine_profile_read(mm_engine* h, int64_t* n_launches, double* ms_total, double* pair_evals,
+                           int64_t* candidates)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    MM_HIP(hipStreamSynchronize(e->stream));
+    double ms = 0.0;
+    for (size_t k = 0; k < e->launches; ++k) {
+        float t = 0.f;
+        MM_HIP(hipEventElapsedTime(&t, e->events[2 * k], e->events[2 * k + 1]));
+        ms += (double)t;
+    }
+    if (n_launches) *n_launches = (int64_t)e->launches;
+    if (ms_total) *ms_total = ms;
+    if (pair_evals) *pair_evals = e->prof_pair_evals;
+    if (candidates) *candidates = e->prof_candidates;
+    e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0;
     return MM_OK;
 }
 

@@ -25,6 +25,14 @@ struct Engine {
     bool own_stream = false;
     void* host_buf = nullptr; size_t host_cap = 0;
     void* dev_buf = nullptr;  size_t dev_cap = 0;
+    // profiling of the scoring kernel (mm_engine_profile*)
+    bool profile = false;
+    std::vector<hipEvent_t> events;   // pairs: [2k] before, [2k+1] after launch k
+    size_t launches = 0;
+    double prof_pair_evals = 0.0;
+    int64_t prof_candidates = 0;
+    int profile_begin();
+    int profile_end(double pair_evals, int64_t candidates);
     int ensure_host(size_t bytes);
     int ensure_dev(size_t bytes);
 };

@@ -68,18 +68,27 @@ static __device__ __forceinline__ float umin2f(float a, float b)
     unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
     return __uint_as_float(ua < ub ? ua : ub);
 }
-static __device__ __forceinline__ double dmin2(double a, double b) { return a < b ? a : b; }
+// squared distances are never NaN (finite inputs), so IEEE minNum == the reference's
+// `if d2 < min_sq { min_sq = d2 }` (process_utils.rs:108-110); one v_min_f64.
+static __device__ __forceinline__ double dmin2(double a, double b) { return __builtin_fmin(a, b); }
 
 // All-reduce min over the 16 lanes of a DPP row (lanes sharing li).  DPP keeps this on
 // the VALU (v_min_u32_dpp) instead of a ds_bpermute round trip through the LDS crossbar:
 // quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror.
+template <int CTRL>
+static __device__ __forceinline__ unsigned dpp_min_u32(unsigned v)
+{
+    // old = UINT_MAX is the identity of min, all rows/banks enabled -> v_min_u32_dpp
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, CTRL, 0xF, 0xF, false);
+    return o < v ? o : v;
+}
 static __device__ __forceinline__ float lane_min16(float f)
 {
-    unsigned v = __float_as_uint(f), o;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  v = o < v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  v = o < v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = o < v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = o < v ? o : v;
+    unsigned v = __float_as_uint(f);
+    v = dpp_min_u32<0xB1>(v);
+    v = dpp_min_u32<0x4E>(v);
+    v = dpp_min_u32<0x141>(v);
+    v = dpp_min_u32<0x140>(v);
     return __uint_as_float(v);
 }
 static __device__ __forceinline__ double dpp_f64(double d, const int ctrl_sel)

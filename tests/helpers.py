@@ -1,0 +1,31 @@
+"""Shared test helpers."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def to_oracle(orc, g):
+    """FlatGeometry -> OracleGeometry (deep copy; same CSR layout)."""
+    cp = lambda a: None if a is None else a.copy()
+    return orc.OracleGeometry(cp(g.ids), cp(g.lumen_ids), cp(g.orig_frames), cp(g.centroids), cp(g.lumen_off),
+                              cp(g.lumen), cp(g.cath_off), cp(g.cath), cp(g.extra_off), cp(g.extra),
+                              cp(g.has_ref), cp(g.ref), g.label)
+
+
+def geoms_equal(g, og) -> bool:
+    """Bit-for-bit equality of everything the chain mutates."""
+    ok = np.array_equal(g.lumen, og.lumen) and np.array_equal(g.centroids, og.centroids)
+    if g.cath is not None:
+        ok = ok and np.array_equal(g.cath, og.cath)
+    if g.extra is not None:
+        ok = ok and np.array_equal(g.extra, og.extra)
+    if g.ref is not None:
+        ok = ok and np.array_equal(g.ref, og.ref)
+    return bool(ok)
+
+
+def blob(rng, n, radius=2.5, centre=(4.5, 4.5), noise=0.05):
+    """A noisy closed contour with n points (roughly IVUS-lumen sized)."""
+    t = np.sort(rng.uniform(0, 2 * np.pi, n))
+    r = radius * (1 + 0.15 * np.cos(2 * t + rng.uniform(0, 6)) + 0.07 * np.sin(3 * t)) + rng.normal(0, noise, n)
+    return np.stack([centre[0] + r * np.cos(t), centre[1] + 0.8 * r * np.sin(t)], axis=1)

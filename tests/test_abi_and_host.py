@@ -1,0 +1,90 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol the header declares;
+host logic (candidate enumeration, set construction, frame transforms) is bit-identical to
+the oracle.  No compute entry point is called (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import refgeom
+from helpers import to_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+
+
+def test_header_symbols_exported(built, mm):
+    hdr = open(os.path.join(ROOT, "include", "mm_hausdorff.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    L = mm._native.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/mm_hausdorff.h but not exported"
+    assert names == set(mm._native.EXPORTS)
+    assert b"gfx950" in L.mm_version()
+
+
+def test_no_cpu_fallback(built, mm):
+    if mm.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mm.Engine()
+
+
+@pytest.mark.parametrize("step,rng,center,limes", [
+    (1.0, 180.0, None, 180.0), (0.5, 180.0, None, 180.0), (0.5, 90.0, None, 90.0), (0.05, 90.0, None, 90.0),
+    (0.01, 6.0, None, 6.0), (0.5, 5.0, 0.3, 90.0), (0.1, 5.0, -1.55, 90.0), (0.01, 0.1, 3.1, 180.0),
+    (1.0, 180.0, None, 90.0), (0.0, 90.0, 1.0, 180.0), (-1.0, 90.0, 0.5, 180.0), (1.0, 0.0, None, 0.0),
+    (7.0, 45.0, 0.2, 30.0), (0.3, 20.0, -0.1, 20.0),
+])
+def test_search_angles_match_oracle(built, mm, oracle, step, rng, center, limes):
+    a, d, e = mm.search_angles(step, rng, center, limes)
+    oa, od, oe = oracle.search_angles(step, rng, center, limes)
+    assert d == od and e == oe
+    assert np.array_equal(a, oa)
+
+
+def test_search_set_and_between_points_match_oracle(built, mm, oracle):
+    g = mm.synthetic_pullback(9, 501, pullback_id=1)
+    og = to_oracle(oracle, g)
+    for ss in (6, 200, 500, 501, 600):
+        for i in (0, 3, 8):
+            assert np.array_equal(mm.search_set(g, i, ss), oracle.catheter_lumen_vec(og, i, ss)[:, :2])
+    for ss in (6, 500, 800):
+        assert np.array_equal(mm.between_points(g, ss), oracle.extract_between_points(og, ss)[:, :2])
+    assert mm.search_set(g, 0, 500).shape == (520, 2) and mm.search_set(g, 0, 501).shape == (521, 2)
+
+
+def test_frame_transforms_match_oracle(built, mm, oracle):
+    g = mm.synthetic_pullback(4, 64, pullback_id=2)
+    og = to_oracle(oracle, g)
+    s = g.c_struct()
+    L = mm._native.lib()
+    L.mm_frame_translate(C.byref(s), 1, 0.3, -0.2, 1.5)
+    oracle.frame_translate(og, 1, 0.3, -0.2, 1.5)
+    L.mm_frame_rotate(C.byref(s), 1, 0.37, g.centroids[1, 0], g.centroids[1, 1])
+    oracle.frame_rotate(og, 1, 0.37, og.centroids[1, 0], og.centroids[1, 1])
+    L.mm_frame_rotate(C.byref(s), 2, 0.0, 1.0, 1.0)  # angle == 0.0 -> untouched (contour_point.rs:39-41)
+    oracle.frame_rotate(og, 2, 0.0, 1.0, 1.0)
+    L.mm_frame_rotate(C.byref(s), 0, -2.1, 4.4, 4.6)  # frame 0 carries the reference point
+    oracle.frame_rotate(og, 0, -2.1, 4.4, 4.6)
+    for a, b in ((g.lumen, og.lumen), (g.cath, og.cath), (g.centroids, og.centroids), (g.ref, og.ref)):
+        assert np.array_equal(a, b)
+
+
+def test_dummy_geometry_builders():
+    f = refgeom.dummy_frames()
+    assert [fr.id for fr in f] == [0, 1, 2] and f[0].ref == [3.0, 1.0, 0.0]
+    assert f[1].centroid[0] == pytest.approx(2.0) and f[2].centroid[1] == pytest.approx(19.0 / 6.0)
+    g = refgeom.dummy_aligned_long_frames()
+    assert len(g) == 6 and g[3].ref is None and g[0].ref is not None
+    assert g[1].pts[0][0] == pytest.approx(1.0, abs=1e-6) and g[1].pts[0][1] == pytest.approx(3.0, abs=1e-6)
+    assert [fr.centroid[2] for fr in g] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]

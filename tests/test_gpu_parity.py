@@ -1,0 +1,293 @@
+"""GPU parity tests: every call goes through the C ABI (libmm_hausdorff.so) and is compared
+with the CPU oracle on the same seeded inputs.  Bar: bit-exact for costs scored in f64,
+for winners (index, angle) and for the geometry the chain produces; the f32 screening costs
+must stay within the stated bound delta = 24 * 2^-24 * (rho_ref + rho_tgt)."""
+import math
+
+import numpy as np
+import pytest
+
+import refgeom
+from helpers import blob, geoms_equal, to_oracle
+
+pytestmark = pytest.mark.gpu
+
+U24 = 2.0 ** -24
+
+
+def P(*xy):
+    return np.array(xy, dtype=np.float64).reshape(-1, 2)
+
+
+# ---------------------------------------------------------------------------------------
+# the metric (process_utils.rs:78-121) -- reference KATs through the device path
+# ---------------------------------------------------------------------------------------
+def test_hausdorff_kats(engine):
+    pts = P((0, 0), (1, 0), (0, 1))
+    assert engine.hausdorff(pts, pts) == 0.0
+    assert engine.hausdorff(P((0, 0), (1, 0)), P((2, 0), (3, 0))) == 2.0
+    assert engine.hausdorff(P((0, 0), (3, 0)), P((1, 0), (2, 0), (4, 0))) == 1.0
+    e = np.zeros((0, 2))
+    assert engine.hausdorff(e, P((1, 1))) == 0.0 and engine.hausdorff(P((1, 1)), e) == 0.0
+    assert engine.hausdorff(e, e) == 0.0
+    i = np.arange(100, dtype=np.float64)
+    assert engine.hausdorff(np.stack([i, 0 * i], 1), np.stack([i + 0.5, 0 * i], 1)) == 0.5
+    sq, di = P((0, 0), (2, 0), (2, 2), (0, 2)), P((1, 0), (2, 1), (1, 2), (0, 1))
+    assert engine.hausdorff(sq, di) == 1.0
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (1, 7), (6, 6), (17, 33), (64, 65), (100, 90), (208, 208), (224, 225),
+                                   (272, 288), (289, 300), (520, 520), (521, 521), (544, 512), (545, 521),
+                                   (600, 1000), (1100, 40), (33, 2049), (2000, 3000)])
+def test_hausdorff_random_bit_exact(engine, oracle, na, nb):
+    rng = np.random.default_rng(na * 10007 + nb)
+    a = rng.normal(4.5, 1.5, size=(na, 2))
+    b = rng.normal(4.6, 1.4, size=(nb, 2))
+    assert engine.hausdorff(a, b) == oracle.hausdorff(a, b)
+    assert engine.hausdorff(b, a) == oracle.hausdorff(b, a)
+
+
+def test_hausdorff_too_large_is_an_error(engine):
+    a = np.zeros((8, 2))
+    b = np.zeros((5000, 2))
+    with pytest.raises(RuntimeError, match="LDS budget"):
+        engine.hausdorff(a, b)
+
+
+# ---------------------------------------------------------------------------------------
+# one search: costs and winner
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,step,rng_deg,between", [(6, 1.0, 30.0, False), (120, 1.0, 180.0, False),
+                                                    (208, 0.5, 90.0, True), (521, 1.0, 180.0, False),
+                                                    (521, 5.0, 180.0, True), (505, 2.0, 90.0, True)])
+def test_search_f64_costs_bit_exact(engine, oracle, mm, n, step, rng_deg, between):
+    rng = np.random.default_rng(n + int(step * 10))
+    ref = blob(rng, n)
+    th = math.radians(7.3)
+    c = ref.mean(axis=0)
+    tgt = (ref - c) @ np.array([[math.cos(th), math.sin(th)], [-math.sin(th), math.cos(th)]]) + c
+    tgt = tgt + rng.normal(0, 0.01, tgt.shape)
+    angles, deg, _ = mm.search_angles(step, rng_deg)
+    assert not deg
+    centre = (float(c[0]), float(c[1]))
+    bi, ba, bc, costs = engine.best_rotation(ref, tgt, angles, centre, skip_zero=not between,
+                                             precision=mm.MM_PRECISION_F64, return_costs=True)
+    ocosts = oracle.costs_over_angles(ref, tgt, angles, centre[0], centre[1], between=between)
+    assert np.array_equal(costs, ocosts)
+    obi = int(np.argmin(ocosts))  # numpy argmin == first minimum
+    assert bi == obi and ba == angles[obi] and bc == ocosts[obi]
+
+
+@pytest.mark.parametrize("n,step,rng_deg", [(6, 1.0, 30.0), (200, 0.5, 180.0), (521, 0.5, 180.0), (520, 1.0, 90.0)])
+def test_search_f32_screen_winner_bit_exact_and_bound(engine, oracle, mm, n, step, rng_deg):
+    rng = np.random.default_rng(1000 + n)
+    ref = blob(rng, n)
+    tgt = blob(rng, n) + rng.normal(0, 0.02, (n, 2))
+    c = ref.mean(axis=0)
+    centre = (float(c[0]), float(c[1]))
+    angles, _, _ = mm.search_angles(step, rng_deg)
+    bi, ba, bc, costs = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True,
+                                             precision=mm.MM_PRECISION_F32, return_costs=True)
+    ocosts = oracle.costs_over_angles(ref, tgt, angles, centre[0], centre[1])
+    obi = int(np.argmin(ocosts))
+    assert bi == obi and ba == angles[obi]
+    assert bc == ocosts[obi]                      # the winner is re-scored in f64: identical bits
+    rho = np.hypot(*(ref - c).T).max() + np.hypot(*(tgt - c).T).max()
+    delta = 24 * U24 * rho
+    err = np.abs(costs - ocosts).max()
+    assert err <= delta, (err, delta)             # stated f32 tolerance on the Hausdorff values
+    assert err <= 0.5 * delta                     # and it is not a tight squeeze
+
+
+def test_duplicate_candidates_first_index_wins(engine, oracle, mm):
+    """range == limes == 180 deg: first and last candidate both wrap to -pi."""
+    rng = np.random.default_rng(5)
+    ref = blob(rng, 150)
+    c = ref.mean(axis=0)
+    tgt = (ref - c) @ np.array([[-1.0, 0.0], [0.0, -1.0]]) + c  # rotated by pi: best angle is +-pi
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    assert angles[0] == angles[-1] == -math.pi
+    for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32):
+        bi, ba, bc = engine.best_rotation(ref, tgt, angles, (float(c[0]), float(c[1])), precision=prec)
+        ocosts = oracle.costs_over_angles(ref, tgt, angles, float(c[0]), float(c[1]))
+        assert bi == int(np.argmin(ocosts)) == 0 and bc == ocosts[0]
+
+
+def test_all_candidates_tie_circle(engine, oracle, mm):
+    """A perfectly symmetric target: costs tie to within rounding; the f32 screen must hand
+    every near-tie to the exact re-score and still return the reference's first minimum."""
+    t = np.arange(360) * (2 * math.pi / 360)
+    ref = np.stack([4.5 + 2 * np.cos(t), 4.5 + 2 * np.sin(t)], 1)
+    tgt = ref.copy()
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    ocosts = oracle.costs_over_angles(ref, tgt, angles, 4.5, 4.5)
+    out = engine.best_rotation(ref, tgt, angles, (4.5, 4.5), precision=mm.MM_PRECISION_F32)
+    assert out[0] == int(np.argmin(ocosts)) and out[2] == ocosts.min()
+
+
+# ---------------------------------------------------------------------------------------
+# batches: ragged sets, empty sets, per-pair candidate lists and flags
+# ---------------------------------------------------------------------------------------
+def test_batch_ragged_and_empty(engine, oracle, mm):
+    rng = np.random.default_rng(77)
+    sizes = [(6, 6), (40, 0), (0, 12), (521, 521), (100, 333), (17, 1), (300, 299), (64, 64)]
+    refs = [blob(rng, a) if a else np.zeros((0, 2)) for a, _ in sizes]
+    tgts = [blob(rng, b) + 0.05 if b else np.zeros((0, 2)) for _, b in sizes]
+    lists = [mm.search_angles(s, r, c, lim)[0] for s, r, c, lim in
+             [(1.0, 30.0, None, 30.0), (2.0, 20.0, None, 20.0), (2.0, 20.0, None, 20.0), (1.0, 180.0, None, 180.0),
+              (0.5, 5.0, 0.3, 90.0), (3.0, 90.0, None, 90.0), (0.1, 5.0, -0.4, 45.0), (10.0, 180.0, None, 180.0)]]
+    lists[5] = np.array([0.0])  # a single candidate, angle == 0.0
+    centres = [(4.5, 4.5)] * len(sizes)
+    flags = [1, 1, 1, 1, 0, 1, 0, 1]
+    batch = mm.Batch(refs, tgts, lists, centres, flags)
+    for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32):
+        out = engine.best_rotation_batch(batch, precision=prec, return_costs=True)
+        for p, (r, t, al, fl) in enumerate(zip(refs, tgts, lists, flags)):
+            oc = oracle.costs_over_angles(r, t, al, 4.5, 4.5, between=(fl == 0))
+            obi = int(np.argmin(oc))
+            assert out["best_idx"][p] == obi, (p, prec)
+            assert out["best_angle"][p] == al[obi]
+            assert out["best_cost"][p] == oc[obi]
+            got = out["costs"][batch.ang_off[p]:batch.ang_off[p + 1]]
+            if prec == mm.MM_PRECISION_F64 or len(r) == 0 or len(t) == 0:
+                assert np.array_equal(got, oc)
+            else:
+                assert np.abs(got - oc).max() <= 24 * U24 * 12.0
+        if prec == mm.MM_PRECISION_F32:
+            assert (out["n_rescored"][[0, 3, 4, 6, 7]] >= 1).all()
+            assert out["n_rescored"][3] < len(lists[3])   # the screen prunes almost everything
+
+
+def test_plan_slices_partition_the_candidate_axis(engine, oracle, mm):
+    """Sharding the candidate axis (what each rank does at N GPUs): min over slices of
+    (cost, index) == the unsharded winner."""
+    rng = np.random.default_rng(9)
+    refs = [blob(rng, 260) for _ in range(5)]
+    tgts = [blob(rng, 260) for _ in range(5)]
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    batch = mm.Batch(refs, tgts, [angles] * 5, [(4.5, 4.5)] * 5, [1] * 5)
+    full = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32)
+    world = 4
+    per = (len(angles) + world - 1) // world
+    best_cost = np.full(5, np.inf)
+    best_idx = np.full(5, 2**31 - 1, dtype=np.int64)
+    for r in range(world):
+        plan = engine.plan(batch, mm.MM_PRECISION_F32, r * per, min((r + 1) * per, len(angles)))
+        plan.run()
+        res = plan.fetch()
+        plan.close()
+        for p in range(5):
+            c, i = res["best_cost"][p], res["best_idx"][p]
+            if i >= 0 and (c < best_cost[p] or (c == best_cost[p] and i < best_idx[p])):
+                best_cost[p], best_idx[p] = c, i
+    assert np.array_equal(best_idx, full["best_idx"]) and np.array_equal(best_cost, full["best_cost"])
+
+
+# ---------------------------------------------------------------------------------------
+# the within-pullback chain (align_within.rs:24-134)
+# ---------------------------------------------------------------------------------------
+def test_chain_dummy_geometry_reference_expectation(engine, oracle, mm):
+    """align_within.rs:791-830: rot = -15 +- 1e-6, t = (-i, -i); and identical to the oracle."""
+    g = mm.FlatGeometry.from_frames(**refgeom.to_arrays(refgeom.dummy_frames()))
+    og = to_oracle(oracle, g)
+    logs, _ = mm.align_within(engine, [g], 0.01, 30.0, False, 6)
+    ologs = oracle.align_within_chain(og, 0.01, 30.0, False, 6)
+    assert logs[0] == ologs
+    for i, (_, _, rot, tx, ty, _, _) in enumerate(logs[0]):
+        assert rot == pytest.approx(-15.0, abs=1e-6)
+        assert tx == pytest.approx(-(i + 1.0), abs=1e-6) and ty == pytest.approx(-(i + 1.0), abs=1e-6)
+    assert geoms_equal(g, og)
+
+
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss,prec", [
+    (True, 1.0, 180.0, 501, 1), (True, 2.0, 90.0, 500, 0), (False, 0.5, 90.0, 500, 1),
+    (False, 0.05, 45.0, 200, 1), (False, 0.005, 20.0, 501, 1), (True, 0.5, 180.0, 501, 1)])
+def test_chain_synthetic_bit_identical(engine, oracle, mm, bruteforce, step, rng_deg, ss, prec):
+    geoms = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((7, 5, 7, 6))]
+    ogeoms = [to_oracle(oracle, g) for g in geoms]
+    logs, evals = mm.align_within(engine, geoms, step, rng_deg, bruteforce, ss, precision=prec)
+    for g, og, lg in zip(geoms, ogeoms, logs):
+        ol = oracle.align_within_chain(og, step, rng_deg, bruteforce, ss, n_threads=8)
+        assert lg == ol
+        assert geoms_equal(g, og)
+    assert evals > 0
+
+
+def test_chain_validation_errors(engine, mm):
+    g = mm.synthetic_pullback(3, 32)
+    with pytest.raises(RuntimeError, match="sample_size must be > 0"):
+        mm.align_within(engine, [g], 1.0, 30.0, False, 0)
+
+
+# ---------------------------------------------------------------------------------------
+# between pullbacks (align_between.rs:11-68)
+# ---------------------------------------------------------------------------------------
+def test_between_dummy_reference_expectation(engine, oracle, mm):
+    """align_between.rs:280-303: B = A rotated by 15 deg; afterwards all points equal within 1e-6."""
+    fa = refgeom.dummy_aligned_long_frames()
+    fb = refgeom.dummy_aligned_long_frames()
+    refgeom.rotate_geometry(fb, math.radians(15.0))
+    ga = mm.FlatGeometry.from_frames(**refgeom.to_arrays(fa))
+    gb = mm.FlatGeometry.from_frames(**refgeom.to_arrays(fb))
+    oa, ob = to_oracle(oracle, ga), to_oracle(oracle, gb)
+    best, _ = mm.align_between(engine, [(ga, gb)], 30.0, 0.01, 6)
+    obest = oracle.align_between(oa, ob, 30.0, 0.01, 6)
+    assert best[0] == obest
+    assert geoms_equal(gb, ob) and geoms_equal(ga, oa)
+    np.testing.assert_allclose(ga.lumen, gb.lumen, atol=1e-6)
+
+
+def test_between_synthetic_bit_identical(engine, oracle, mm):
+    geoms = mm.synthetic_case(10, 501)
+    mm.align_within(engine, geoms, 1.0, 60.0, False, 500)
+    og = [to_oracle(oracle, g) for g in geoms]
+    pairs = [(geoms[0], geoms[1]), (geoms[2], geoms[3])]
+    best, evals = mm.align_between(engine, pairs, 90.0, 0.5, 500)
+    ob0 = oracle.align_between(og[0], og[1], 90.0, 0.5, 500, n_threads=8)
+    ob1 = oracle.align_between(og[2], og[3], 90.0, 0.5, 500, n_threads=8)
+    assert best[0] == ob0 and best[1] == ob1
+    for g, o in zip(geoms, og):
+        assert geoms_equal(g, o)
+    assert evals > 0
+
+
+# ---------------------------------------------------------------------------------------
+# full-size properties (BASELINE configs: N = 521 pts/set, 361 / 721 candidates)
+# ---------------------------------------------------------------------------------------
+def test_fullsize_known_rotation_recovered(engine, mm):
+    """target = reference rotated by -theta_k (theta_k on the candidate grid) about the
+    centre => the search returns exactly candidate k with a ~0 cost (size-independent property)."""
+    rng = np.random.default_rng(4)
+    angles, _, _ = mm.search_angles(0.5, 180.0)
+    assert len(angles) == 721
+    refs, tgts, want = [], [], []
+    for p in range(64):
+        ref = blob(rng, 521)
+        k = int(rng.integers(1, 720))
+        c, s = math.cos(-angles[k]), math.sin(-angles[k])
+        rel = ref - 4.5
+        tgt = np.stack([rel[:, 0] * c - rel[:, 1] * s, rel[:, 0] * s + rel[:, 1] * c], 1) + 4.5
+        refs.append(ref); tgts.append(tgt); want.append(k)
+    batch = mm.Batch(refs, tgts, [angles] * 64, [(4.5, 4.5)] * 64, [1] * 64)
+    out = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32)
+    assert list(out["best_idx"]) == want
+    assert out["best_cost"].max() < 1e-12
+
+
+def test_fullsize_f32_and_f64_paths_agree(engine, mm):
+    """Same batch through the screening path and the all-f64 path: identical winners and
+    identical winning costs (the claim behind MM_PRECISION_F32)."""
+    geoms = mm.synthetic_case(17, 501)
+    refs, tgts, cs = [], [], []
+    for g in geoms:
+        for i in range(1, g.n_frames):
+            r = mm.search_set(g, i - 1, 501) - g.centroids[i - 1, :2]
+            t = mm.search_set(g, i, 501) - g.centroids[i, :2]
+            refs.append(r); tgts.append(t); cs.append((0.0, 0.0))
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    batch = mm.Batch(refs, tgts, [angles] * len(refs), cs, [1] * len(refs))
+    a = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32)
+    b = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F64)
+    assert np.array_equal(a["best_idx"], b["best_idx"])
+    assert np.array_equal(a["best_cost"], b["best_cost"])
+    assert a["n_rescored"].sum() < 0.05 * len(refs) * len(angles)
