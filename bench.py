@@ -39,26 +39,34 @@ FLOPS_PER_PAIR_EVAL = 6.0         # 2 sub, 2 mul, 1 add, 1 min
 BYTES_PER_POSE_EVAL = lambda na, nb: (na + nb) * 2 * 4 + 8   # SURVEY 8(d) no-reuse model
 
 
-def full_alignment(mm, eng, geoms, cfg, mode):
-    """One 4-phase alignment (entry.rs:140-277 order); returns (logs, between angles, pose_evals)."""
-    logs, evals = mm.align_within(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                                  precision=mm.MM_PRECISION_F32, mode=mode)
+def between_stage(mm, eng, geoms, cfg):
+    """AB | CD then AC | BD (entry.rs:206-277)."""
     a, b, c, d = geoms
     r1, e1 = mm.align_between(eng, [(a, b), (c, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"])
     r2, e2 = mm.align_between(eng, [(a, c), (b, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"])
-    return logs, np.concatenate([r1, r2]), evals + e1 + e2
+    return np.concatenate([r1, r2]), e1 + e2
 
 
-def cpu_baseline(cfg, geoms, budget_s=12.0):
+def full_alignment(mm, eng, geoms, cfg, plan=None):
+    """One 4-phase alignment (entry.rs:140-277 order); returns (logs, between angles, pose_evals).
+    plan = a pre-staged mm.WithinPlan (decoupled mode, point sets already in HBM) or None
+    (faithful per-step chain)."""
+    if plan is None:
+        logs, evals = mm.align_within(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                      precision=mm.MM_PRECISION_F32, mode=0)
+        unresolved = 0
+    else:
+        logs, evals, unresolved = plan.run()
+    rot, e2 = between_stage(mm, eng, geoms, cfg)
+    return logs, rot, evals + e2, unresolved
+
+
+def cpu_baseline(cfg, geoms, threads, budget_s=12.0):
     """The CPU oracle (a port of the reference algorithm) timed on this box's host cores on a
     bounded sample of the same workload: the first frame pairs of pullback 0, all candidates,
     candidates evaluated in parallel (OpenMP) like the reference's rayon par_iter."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = threads
     g = geoms[0]
     ss = cfg["sample_size"]
     import multimoda_rs_amd as mm
@@ -86,8 +94,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="chain", choices=["chain", "decoupled"])
+    ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline (default: the GPU box's CPU share per GPU, 16, or fewer cores)")
     ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle (slow)")
     args = ap.parse_args()
 
@@ -118,18 +128,37 @@ def main():
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
     eng = mm.Engine(local_rank)
 
-    # pullbacks are independent chains: with N ranks, rank r owns pullbacks r, r+N, ...
-    # (no data-path collective; the between stage needs all four and runs on rank 0)
-    def one_step():
+    # Every step works on a fresh copy of the case.  In decoupled mode the copies are staged
+    # into HBM (mm.WithinPlan) before the timed region: inputs resident, as the contract asks;
+    # the staging-inclusive rate is reported separately.
+    # N > 1 (interim): pullbacks are independent chains, rank r owns pullbacks r, r+N, ...
+    n_total = args.warmup + args.steps
+    t_stage0 = time.perf_counter()
+    cases, plans = [], []
+    for _ in range(n_total):
         geoms = [g.copy() for g in base]
+        mine = geoms if world == 1 else [geoms[i] for i in range(4) if i % world == rank]
+        cases.append((geoms, mine))
+        plans.append(mm.WithinPlan(eng, mine, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"])
+                     if (mode == 1 and mine) else None)
+    eng.synchronize()
+    t_stage = (time.perf_counter() - t_stage0) / n_total
+    it = iter(range(n_total))
+
+    def one_step():
+        k = next(it)
+        geoms, mine = cases[k]
         if world == 1:
-            return full_alignment(mm, eng, geoms, cfg, mode)
-        mine = [i for i in range(4) if i % world == rank]
-        logs, evals = ([], 0)
-        if mine:
-            logs, evals = mm.align_within(eng, [geoms[i] for i in mine], cfg["step_deg"], cfg["range_deg"], True,
-                                          cfg["sample_size"], precision=mm.MM_PRECISION_F32, mode=mode)
-        return logs, None, evals
+            return full_alignment(mm, eng, geoms, cfg, plans[k])
+        if not mine:
+            return [], None, 0, 0
+        if plans[k] is not None:
+            logs, evals, unres = plans[k].run()
+        else:
+            logs, evals = mm.align_within(eng, mine, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                          precision=mm.MM_PRECISION_F32, mode=0)
+            unres = 0
+        return logs, None, evals, unres
 
     def barrier():
         if world > 1:
@@ -142,10 +171,11 @@ def main():
     barrier()
     eng.profile(True)
     t0 = time.perf_counter()
-    evals = 0
+    evals, unresolved = 0, 0
     for _ in range(args.steps):
         res = one_step()
         evals += res[2]
+        unresolved += res[3]
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
@@ -180,6 +210,8 @@ def main():
             "config": {"workload": f"{args.workload}: full 4-phase alignment, 4 pullbacks x {cfg['frames']} frames x "
                                    f"{cfg['points']} pts (N={na} pts/set), {cfg['step_deg']} deg x +-{cfg['range_deg']} deg "
                                    f"bruteforce grid", "mode": args.mode, "pose_evals_per_step": evals // max(args.steps, 1),
+                       "chain_steps_researched_on_chain_state": unresolved,
+                       "value_incl_host_staging": evals / (dt + t_stage * args.steps),
                        "parallelism": f"{'pullback' if world > 1 else 'single'}-sharded x{world}"},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -194,7 +226,11 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, base)
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except Exception:
+                avail = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(cfg, base, args.cpu_threads or min(avail, 16))
         if args.check:
             from oracle import oracle as orc
             from tests.helpers import to_oracle  # type: ignore

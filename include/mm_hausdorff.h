@@ -195,6 +195,20 @@ int mm_align_within(mm_engine* e, int n_geoms, mm_geometry** geoms,
                     double step_deg, double range_deg, int bruteforce, int64_t sample_size,
                     int precision, int mode, mm_alignlog** logs, int64_t* pose_evals);
 
+/* The decoupled mode split in two, so that the point sets are resident in HBM before the
+ * search is timed: create() validates, builds the centred search sets of the original frames
+ * and stages them; run() scores every (frame pair, candidate) in one launch sequence, then
+ * walks the chain exactly (mutating the geometries passed to create()) and writes the logs.
+ * A plan runs once (the walk consumes the original frames).  n_unresolved (nullable) = chain
+ * steps whose winner had to be re-searched on the chain state. */
+typedef struct mm_within_plan mm_within_plan;
+int  mm_within_plan_create(mm_engine* e, int n_geoms, mm_geometry** geoms,
+                           double step_deg, double range_deg, int bruteforce, int64_t sample_size,
+                           int precision, mm_within_plan** out);
+int  mm_within_plan_run(mm_within_plan* p, mm_alignlog** logs, int64_t* pose_evals,
+                        int64_t* n_unresolved);
+void mm_within_plan_destroy(mm_within_plan* p);
+
 /* align_between_geometries (align_between.rs:11-68) for n_pairs independent (a,b) pairs
  * (entry.rs:206-277 runs two at a time); b is moved onto a.  best_rotation[p] receives
  * the searched angle (radians). */

@@ -12,7 +12,7 @@ from __future__ import annotations
 from . import _native
 from ._native import (MM_PRECISION_F32, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine, Plan,
                       device_count, search_angles)
-from .geometry import (FlatGeometry, align_between, align_within, between_points, catheter_points,
+from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
                        contour_centroid, search_set)
 from .synth import synthetic_case, synthetic_pullback
 
@@ -20,7 +20,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "Engine", "Batch", "Plan", "FlatGeometry", "device_count", "search_angles",
-    "align_within", "align_between", "search_set", "between_points",
+    "align_within", "align_between", "WithinPlan", "search_set", "between_points",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

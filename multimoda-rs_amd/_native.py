@@ -25,7 +25,7 @@ EXPORTS = [
     "mm_hausdorff_2d", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
-    "mm_align_within", "mm_align_between", "mm_catheter_lumen_vec", "mm_extract_between_points",
+    "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy", "mm_catheter_lumen_vec", "mm_extract_between_points",
     "mm_frame_translate", "mm_frame_rotate",
 ]
 
@@ -121,6 +121,12 @@ def lib():
     L.mm_plan_stats.argtypes = [P, C.POINTER(I64), C.POINTER(D), C.POINTER(I64)]
     L.mm_align_within.restype = I
     L.mm_align_within.argtypes = [P, I, P, D, D, I, I64, I, I, P, C.POINTER(I64)]
+    L.mm_within_plan_create.restype = I
+    L.mm_within_plan_create.argtypes = [P, I, P, D, D, I, I64, I, C.POINTER(P)]
+    L.mm_within_plan_run.restype = I
+    L.mm_within_plan_run.argtypes = [P, P, C.POINTER(I64), C.POINTER(I64)]
+    L.mm_within_plan_destroy.restype = None
+    L.mm_within_plan_destroy.argtypes = [P]
     L.mm_align_between.restype = I
     L.mm_align_between.argtypes = [P, I, P, P, D, D, I64, I, P, C.POINTER(I64)]
     L.mm_catheter_lumen_vec.restype = I64

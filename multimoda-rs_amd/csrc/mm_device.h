@@ -7,17 +7,21 @@
 
 namespace mm {
 
-// One (reference set, target set, candidate list) search.
+// One (reference set, target set, candidate list) search.  Point sets live in one pool
+// (several pairs may share a set: frame i is the target of pair i and the reference of
+// pair i+1); cos/sin tables are shared between pairs with identical candidate lists.
 struct PairDesc {
-    int32_t ref_off, n_ref;   // into the ref SoA arrays
-    int32_t tgt_off, n_tgt;   // into the tgt SoA arrays
-    int32_t ang_off, n_ang;   // into cos/sin tables and the per-candidate outputs
+    int32_t ref_off, n_ref;   // into the point pool
+    int32_t tgt_off, n_tgt;
+    int32_t tab_off;          // into the cos/sin tables
+    int32_t out_off;          // into the per-candidate outputs
+    int32_t n_ang;            // candidates of this pair in this plan (slice)
     int32_t flags;            // MM_SEARCH_SKIP_ZERO
     int32_t ang_full;         // length of the pair's full candidate list (>= n_ang)
     int32_t ang_begin;        // first candidate of the slice this plan owns
-    int32_t pad;
     double  cx, cy;           // rotation centre (exact kernel)
     double  delta;            // f32 screening error bound (same unit as the costs)
+    double  tol2;             // candidates within tol2 of the exact minimum are reported as near-ties
 };
 
 // One workgroup's share: `cnt` consecutive candidates of one pair.
@@ -25,14 +29,18 @@ struct WorkItem {
     int32_t pair, a0, cnt, pad;
 };
 
+static constexpr int kMaxNear = 8;  // near-tie slots per pair (MM_MAX_NEAR)
+
 struct BatchDev {
     const PairDesc* pairs;
     const WorkItem* work;
     int32_t n_pairs, n_work;
-    // f32 screening inputs (coordinates relative to the rotation centre)
-    const float *ref32x, *ref32y, *tgt32x, *tgt32y, *cos32, *sin32;
-    // f64 exact inputs (absolute coordinates)
-    const double *ref64x, *ref64y, *tgt64x, *tgt64y, *cos64, *sin64;
+    // point pool: f32 copy relative to the set's centre, f64 copy as given
+    const float *p32x, *p32y;
+    const double *p64x, *p64y;
+    // candidate tables
+    const float *cos32, *sin32;
+    const double *cos64, *sin64;
     // per-candidate outputs
     float*    sq32;       // squared Hausdorff from the screening kernel
     double*   sq64;       // exact squared Hausdorff (valid where flag != 0 or in exact mode)
@@ -44,6 +52,8 @@ struct BatchDev {
     double*   best_cost;
     int32_t*  best_idx;
     int32_t*  n_rescored;
+    int32_t*  near_cnt;   // exact-scored candidates with cost <= best + tol2 (may exceed kMaxNear)
+    int32_t*  near_idx;   // [n_pairs * kMaxNear] ascending candidate indices (full-list numbering)
     double*   all_costs;  // optional per-candidate sqrt'ed costs
 };
 

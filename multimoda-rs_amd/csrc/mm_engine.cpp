@@ -1,16 +1,16 @@
 // mm_engine.cpp -- host side of the C ABI (include/mm_hausdorff.h): engine, batch staging,
 // device-resident plans.  Compiled with hipcc -ffp-contract=off.
 //
-// Data layout in HBM (one contiguous blob per plan, 256-B aligned sections):
-//   [PairDesc x P][WorkItem x W]
-//   [cos32 | sin32 | cos64 | sin64]                    per candidate (angle tables are
-//                                                      computed on the host with glibc
-//                                                      sin/cos = what Rust's f64::sin/cos
-//                                                      call on linux-gnu)
-//   [ref32x | ref32y | tgt32x | tgt32y]                f32 SoA, relative to the centre
-//   [ref64x | ref64y | tgt64x | tgt64y]                f64 SoA, absolute
-//   ---- outputs ----
-//   [sq32 | sq64 | flag | items | n_items | best_cost | best_idx | n_rescored | all_costs]
+// Data layout in HBM.  Point pool (staged once per plan; a set may serve several pairs):
+//   [p32x | p32y]   f32 SoA, coordinates relative to the set's centre (screening kernel)
+//   [p64x | p64y]   f64 SoA, coordinates as given                     (exact kernel)
+// Level blob (re-stageable: a coarse->fine search re-uses the resident points):
+//   [PairDesc x P][WorkItem x W][cos32 | sin32 | cos64 | sin64]   <- one H2D copy
+//   [sq32 | sq64 | flag | items | n_items]                         per-candidate scratch
+//   [best_cost | best_idx | n_rescored | near_cnt | near_idx]      <- one D2H copy
+//   [all_costs]                                                    optional
+// cos/sin tables are computed on the host with glibc sin/cos (what Rust's f64::sin/cos
+// call on linux-gnu) and shared by pairs with identical candidate lists.
 #include "mm_engine.h"
 
 #include <algorithm>
@@ -47,29 +47,19 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // -------------------------------------------------------------------------------------
 // engine
 // -------------------------------------------------------------------------------------
-int Engine::ensure_host(size_t bytes)
+int Engine::ensure(Buf& b, size_t bytes, bool host)
 {
-    if (bytes <= host_cap) return MM_OK;
-    if (host_buf) (void)hipHostFree(host_buf);
-    host_buf = nullptr;
-    host_cap = 0;
-    size_t cap = std::max(bytes, (size_t)1 << 20);
+    if (bytes <= b.cap) return MM_OK;
+    if (b.p) {
+        MM_HIP(hipStreamSynchronize(stream));  // a copy may still read the old buffer
+        if (host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
+    }
+    b.p = nullptr; b.cap = 0;
+    size_t cap = std::max(bytes, host ? (size_t)1 << 20 : (size_t)4 << 20);
     cap = align_up(cap + cap / 2, 4096);
-    MM_HIP(hipHostMalloc(&host_buf, cap, hipHostMallocDefault));
-    host_cap = cap;
-    return MM_OK;
-}
-
-int Engine::ensure_dev(size_t bytes)
-{
-    if (bytes <= dev_cap) return MM_OK;
-    if (dev_buf) (void)hipFree(dev_buf);
-    dev_buf = nullptr;
-    dev_cap = 0;
-    size_t cap = std::max(bytes, (size_t)4 << 20);
-    cap = align_up(cap + cap / 2, 4096);
-    MM_HIP(hipMalloc(&dev_buf, cap));
-    dev_cap = cap;
+    if (host) MM_HIP(hipHostMalloc(&b.p, cap, hipHostMallocDefault));
+    else MM_HIP(hipMalloc(&b.p, cap));
+    b.cap = cap;
     return MM_OK;
 }
 
@@ -96,190 +86,200 @@ int Engine::profile_end(double pair_evals, int64_t candidates)
 }
 
 // -------------------------------------------------------------------------------------
-// plan construction
+// plan: point pool
 // -------------------------------------------------------------------------------------
-struct Layout {
-    size_t pairs, work, cos32, sin32, cos64, sin64;
-    size_t r32x, r32y, t32x, t32y, r64x, r64y, t64x, t64y;
-    size_t in_bytes;  // everything above (one H2D copy)
-    size_t sq32, sq64, flag, items, n_items, best_cost, best_idx, n_rescored, all_costs;
-    size_t total;
-};
-
-static Layout make_layout(int P, int W, int64_t A, int64_t NR, int64_t NT, bool want_costs)
-{
-    Layout L{};
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + std::max<size_t>(bytes, 16)); return at; };
-    L.pairs = take((size_t)P * sizeof(PairDesc));
-    L.work = take((size_t)W * sizeof(WorkItem));
-    L.cos32 = take((size_t)A * 4); L.sin32 = take((size_t)A * 4);
-    L.cos64 = take((size_t)A * 8); L.sin64 = take((size_t)A * 8);
-    L.r32x = take((size_t)NR * 4); L.r32y = take((size_t)NR * 4);
-    L.t32x = take((size_t)NT * 4); L.t32y = take((size_t)NT * 4);
-    L.r64x = take((size_t)NR * 8); L.r64y = take((size_t)NR * 8);
-    L.t64x = take((size_t)NT * 8); L.t64y = take((size_t)NT * 8);
-    L.in_bytes = o;
-    L.sq32 = take((size_t)A * 4); L.sq64 = take((size_t)A * 8); L.flag = take((size_t)A);
-    L.items = take((size_t)A * sizeof(WorkItem)); L.n_items = take(16);
-    L.best_cost = take((size_t)P * 8); L.best_idx = take((size_t)P * 4); L.n_rescored = take((size_t)P * 4);
-    L.all_costs = want_costs ? take((size_t)A * 8) : 0;
-    L.total = o;
-    return L;
-}
-
-// f32 screening error bound for one pair (see DESIGN.md "screen-then-exact"): with
-// u = 2^-24, rho_r / rho_t the largest distance of a reference / target point from the
-// rotation centre, |H_f32 - H_f64| <= u * (3.9 rho_r + 10 rho_t); we use 24 u (rho_r+rho_t).
-static double screen_delta(const double* rx, const double* ry, int64_t nr, const double* tx,
-                           const double* ty, int64_t nt, double cx, double cy)
-{
-    double rr = 0.0, rt = 0.0;
-    for (int64_t i = 0; i < nr; ++i) rr = std::max(rr, std::hypot(rx[i] - cx, ry[i] - cy));
-    for (int64_t i = 0; i < nt; ++i) rt = std::max(rt, std::hypot(tx[i] - cx, ty[i] - cy));
-    const double u = 5.9604644775390625e-08;  // 2^-24
-    return 24.0 * u * (rr + rt) + 1e-300;
-}
-
-int Plan::build(Engine* e, int n_pairs, const int64_t* ref_off, const double* ref_x, const double* ref_y,
-                const int64_t* tgt_off, const double* tgt_x, const double* tgt_y,
-                const int64_t* ang_off, const double* angles, const double* cx, const double* cy,
-                const int32_t* flags, int precision_, int32_t angle_begin, int32_t angle_end,
-                bool want_costs, bool transient_)
+int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_)
 {
     eng = e;
-    P = n_pairs;
-    precision = precision_;
     transient = transient_;
-    if (n_pairs < 0) return set_error(MM_ERR_INVALID, "n_pairs < 0");
+    const size_t S = sets.size();
+    set_off.assign(S, 0); set_len.assign(S, 0);
+    set_rho.assign(S, 0.0);
+    n_points = 0;
+    for (size_t s = 0; s < S; ++s) {
+        if (sets[s].n < 0) return set_error(MM_ERR_INVALID, "negative set size");
+        set_off[s] = (int32_t)n_points; set_len[s] = sets[s].n;
+        n_points += sets[s].n;
+        if (n_points > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
+    }
+    const size_t n = (size_t)n_points;
+    const size_t o32x = 0, o32y = align_up(o32x + n * 4), o64x = align_up(o32y + n * 4), o64y = align_up(o64x + n * 8);
+    pts_bytes = align_up(o64y + n * 8);
+    int rc = e->ensure(e->host_pts, pts_bytes, true);
+    if (rc) return rc;
+    unsigned char* h = (unsigned char*)e->host_pts.p;
+    float *x32 = (float*)(h + o32x), *y32 = (float*)(h + o32y);
+    double *x64 = (double*)(h + o64x), *y64 = (double*)(h + o64y);
+    for (size_t s = 0; s < S; ++s) {
+        const SetRef& r = sets[s];
+        const int32_t o = set_off[s];
+        double rho2 = 0.0;
+        for (int32_t i = 0; i < r.n; ++i) {
+            const double dx = r.x[i] - r.cx, dy = r.y[i] - r.cy;
+            x64[o + i] = r.x[i]; y64[o + i] = r.y[i];
+            x32[o + i] = (float)dx; y32[o + i] = (float)dy;
+            rho2 = std::max(rho2, dx * dx + dy * dy);
+        }
+        set_rho[s] = std::sqrt(rho2) * (1.0 + 1e-12);
+    }
+    if (transient) {
+        rc = e->ensure(e->dev_pts, pts_bytes, false);
+        if (rc) return rc;
+        pts_blob = (unsigned char*)e->dev_pts.p; own_pts = false;
+    } else {
+        MM_HIP(hipMalloc((void**)&pts_blob, std::max<size_t>(pts_bytes, 256)));
+        own_pts = true;
+    }
+    if (pts_bytes) MM_HIP(hipMemcpyAsync(pts_blob, h, pts_bytes, hipMemcpyHostToDevice, e->stream));
+    if (!transient) MM_HIP(hipStreamSynchronize(e->stream));
+    dev.p32x = (const float*)(pts_blob + o32x); dev.p32y = (const float*)(pts_blob + o32y);
+    dev.p64x = (const double*)(pts_blob + o64x); dev.p64y = (const double*)(pts_blob + o64y);
+    return MM_OK;
+}
+
+// -------------------------------------------------------------------------------------
+// plan: level (descriptors, candidate tables, outputs)
+// -------------------------------------------------------------------------------------
+// f32 screening error bound (DESIGN.md "screen-then-exact"): with u = 2^-24 and rho_r, rho_t
+// the largest distance of a reference / target point from the rotation centre,
+// |H_f32 - H_f64| <= u (3.9 rho_r + 10 rho_t); we use 24 u (rho_r + rho_t).
+static inline double screen_delta(double rho_r, double rho_t)
+{
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    return 24.0 * u * (rho_r + rho_t) + 1e-300;
+}
+
+int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_t angle_begin, int32_t angle_end,
+                      bool want_costs_)
+{
+    Engine* e = eng;
+    precision = precision_;
+    want_costs = want_costs_;
+    slice_end = angle_end;
+    P = (int)pairs.size();
     if (precision != MM_PRECISION_F64 && precision != MM_PRECISION_F32)
         return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64 or MM_PRECISION_F32");
     if (angle_begin < 0) angle_begin = 0;
-    slice_end = angle_end;
 
-    // ---- sizes -----------------------------------------------------------------------
     host_pairs.assign(P, PairDesc{});
     trivial.assign(P, 0);
-    first_angle.assign(P, NAN);
-    user_ang_off.assign(ang_off, ang_off + P + 1);
-    A = 0;
-    int64_t NR = 0, NT = 0;
+    host_tables.clear();
+    A = 0; T = 0;
     max_na = 1; max_nbp = 16;
     pair_evals = 0.0;
+    // table sharing: same list as the previous distinct table (pointer or content) and same slice
+    const double* last_ptr = nullptr; int32_t last_n = -1, last_b = -1, last_tab = 0, last_len = -1;
     for (int p = 0; p < P; ++p) {
-        const int64_t nr = ref_off[p + 1] - ref_off[p], nt = tgt_off[p + 1] - tgt_off[p];
-        const int64_t na_full = ang_off[p + 1] - ang_off[p];
-        if (nr < 0 || nt < 0 || na_full < 0) return set_error(MM_ERR_INVALID, "negative extent in batch offsets");
-        const int64_t b = std::min<int64_t>(angle_begin, na_full), en = std::min<int64_t>(angle_end, na_full);
-        const int64_t na = std::max<int64_t>(en - b, 0);
+        const PairSpec& sp = pairs[p];
+        if (sp.ref_set < 0 || sp.tgt_set < 0 || (size_t)sp.ref_set >= set_len.size() || (size_t)sp.tgt_set >= set_len.size())
+            return set_error(MM_ERR_INVALID, "pair references a set that was not staged");
+        if (sp.n_angles < 0) return set_error(MM_ERR_INVALID, "negative candidate count");
+        const int32_t nr = set_len[sp.ref_set], nt = set_len[sp.tgt_set];
+        const int32_t b = std::min(angle_begin, sp.n_angles), en = std::min(angle_end, sp.n_angles);
+        const int32_t na = std::max(en - b, 0);
         PairDesc& d = host_pairs[p];
-        d.ref_off = (int32_t)NR; d.n_ref = (int32_t)nr;
-        d.tgt_off = (int32_t)NT; d.n_tgt = (int32_t)nt;
-        d.ang_off = (int32_t)A;  d.n_ang = (int32_t)na;
-        d.ang_full = (int32_t)na_full; d.ang_begin = (int32_t)b;
-        d.flags = flags ? flags[p] : 0;
-        d.cx = cx[p]; d.cy = cy[p];
-        if (na > 0) first_angle[p] = angles[ang_off[p] + b];
+        d.ref_off = set_off[sp.ref_set]; d.n_ref = nr;
+        d.tgt_off = set_off[sp.tgt_set]; d.n_tgt = nt;
+        d.out_off = (int32_t)A; d.n_ang = na;
+        d.ang_full = sp.n_angles; d.ang_begin = b;
+        d.flags = sp.flags;
+        d.cx = sp.cx; d.cy = sp.cy;
+        d.tol2 = sp.tie_tol;
+        d.delta = (precision == MM_PRECISION_F32)
+                      ? screen_delta(set_rho[sp.ref_set], set_rho[sp.tgt_set]) + sp.delta_extra : 0.0;
         if (nr == 0 || nt == 0) {
-            // process_utils.rs:86-88: an empty set makes every cost 0.0 -> first candidate wins;
-            // nothing to launch for this pair.
+            // process_utils.rs:86-88: an empty set makes every cost 0.0 -> the first candidate wins;
+            // nothing to launch for this pair (one table entry keeps its first angle).
             trivial[p] = 1;
             d.n_ang = 0;
+            d.tab_off = (int32_t)host_tables.size();
+            if (na > 0) host_tables.push_back(sp.angles[b]);
+            last_ptr = nullptr; last_len = -1;
             continue;
         }
-        NR += nr; NT += nt; A += na;
-        max_na = std::max<int>(max_na, (int)nr);
-        max_nbp = std::max<int>(max_nbp, (int)((nt + 15) & ~(int64_t)15));
+        const bool share = (na == last_len && b == last_b && sp.n_angles == last_n) &&
+                           (sp.angles == last_ptr ||
+                            (na > 0 && std::memcmp(sp.angles + b, host_tables.data() + last_tab, (size_t)na * 8) == 0));
+        if (!share) {
+            last_tab = (int32_t)host_tables.size();
+            host_tables.insert(host_tables.end(), sp.angles + b, sp.angles + b + na);
+            last_len = na; last_b = b; last_n = sp.n_angles;
+        }
+        last_ptr = sp.angles;
+        d.tab_off = last_tab;
+        A += na;
+        max_na = std::max<int>(max_na, nr);
+        max_nbp = std::max<int>(max_nbp, (nt + 15) & ~15);
         pair_evals += 2.0 * (double)nr * (double)nt * (double)na;
+        if (A > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 candidates");
     }
-    if (A > (int64_t)1 << 30 || NR > (int64_t)1 << 30 || NT > (int64_t)1 << 30)
-        return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 candidates or points");
+    T = (int64_t)host_tables.size();
     if (max_nbp > max_target_points_f64() || (precision == MM_PRECISION_F32 && max_nbp > max_target_points_f32()))
         return set_error(MM_ERR_TOO_LARGE, "target set does not fit the kernel's LDS budget (" +
                                                std::to_string(max_target_points_f64()) + " points)");
 
     // ---- work decomposition: one workgroup = `apb` consecutive candidates of one pair ----
     const int64_t target_wgs = 256 * 24;
-    int apb = (int)std::min<int64_t>(64, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
+    const int apb = (int)std::min<int64_t>(64, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
     host_work.clear();
     for (int p = 0; p < P; ++p) {
         const PairDesc& d = host_pairs[p];
-        for (int a0 = 0; a0 < d.n_ang; a0 += apb) {
-            WorkItem w{p, a0, std::min(apb, d.n_ang - a0), 0};
-            host_work.push_back(w);
-        }
+        for (int a0 = 0; a0 < d.n_ang; a0 += apb) host_work.push_back(WorkItem{p, a0, std::min(apb, d.n_ang - a0), 0});
     }
     W = (int)host_work.size();
 
-    const Layout L = make_layout(P, W, A, NR, NT, want_costs);
-    in_bytes = L.in_bytes;
-    total_bytes = L.total;
+    // ---- layout ---------------------------------------------------------------------------
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + std::max<size_t>(bytes, 16)); return at; };
+    const size_t o_pairs = take((size_t)P * sizeof(PairDesc));
+    const size_t o_work = take((size_t)W * sizeof(WorkItem));
+    const size_t o_c32 = take((size_t)T * 4), o_s32 = take((size_t)T * 4);
+    const size_t o_c64 = take((size_t)T * 8), o_s64 = take((size_t)T * 8);
+    lvl_in_bytes = o;
+    const size_t o_sq32 = take((size_t)A * 4), o_sq64 = take((size_t)A * 8), o_flag = take((size_t)A);
+    const size_t o_items = take((size_t)A * sizeof(WorkItem)), o_nitems = take(16);
+    const size_t o_bc = take((size_t)P * 8), o_bi = take((size_t)P * 4), o_nr = take((size_t)P * 4);
+    const size_t o_nc = take((size_t)P * 4), o_ni = take((size_t)P * 4 * kMaxNear);
+    off_best_cost = o_bc; res_bytes = o - o_bc;
+    off_all_costs = want_costs ? take((size_t)A * 8) : 0;
+    lvl_bytes = o;
+    r_best_idx = o_bi - o_bc; r_n_rescored = o_nr - o_bc; r_near_cnt = o_nc - o_bc; r_near_idx = o_ni - o_bc;
 
-    // ---- stage inputs in pinned host memory -----------------------------------------------
-    int rc = e->ensure_host(L.in_bytes);
+    // ---- stage inputs -----------------------------------------------------------------------
+    int rc = e->ensure(e->host_lvl, std::max(lvl_in_bytes, res_bytes), true);
     if (rc) return rc;
-    unsigned char* h = (unsigned char*)e->host_buf;
-    float *c32 = (float*)(h + L.cos32), *s32 = (float*)(h + L.sin32);
-    double *c64 = (double*)(h + L.cos64), *s64 = (double*)(h + L.sin64);
-    float *r32x = (float*)(h + L.r32x), *r32y = (float*)(h + L.r32y);
-    float *t32x = (float*)(h + L.t32x), *t32y = (float*)(h + L.t32y);
-    double *r64x = (double*)(h + L.r64x), *r64y = (double*)(h + L.r64y);
-    double *t64x = (double*)(h + L.t64x), *t64y = (double*)(h + L.t64y);
-    host_angles.assign((size_t)A, 0.0);
-    for (int p = 0; p < P; ++p) {
-        PairDesc& d = host_pairs[p];
-        if (trivial[p]) continue;
-        const double* rx = ref_x + ref_off[p]; const double* ry = ref_y + ref_off[p];
-        const double* tx = tgt_x + tgt_off[p]; const double* ty = tgt_y + tgt_off[p];
-        for (int i = 0; i < d.n_ref; ++i) {
-            r64x[d.ref_off + i] = rx[i]; r64y[d.ref_off + i] = ry[i];
-            r32x[d.ref_off + i] = (float)(rx[i] - d.cx); r32y[d.ref_off + i] = (float)(ry[i] - d.cy);
-        }
-        for (int i = 0; i < d.n_tgt; ++i) {
-            t64x[d.tgt_off + i] = tx[i]; t64y[d.tgt_off + i] = ty[i];
-            t32x[d.tgt_off + i] = (float)(tx[i] - d.cx); t32y[d.tgt_off + i] = (float)(ty[i] - d.cy);
-        }
-        const double* ang = angles + ang_off[p] + d.ang_begin;
-        for (int a = 0; a < d.n_ang; ++a) {
-            const double co = std::cos(ang[a]), si = std::sin(ang[a]);
-            c64[d.ang_off + a] = co; s64[d.ang_off + a] = si;
-            c32[d.ang_off + a] = (float)co; s32[d.ang_off + a] = (float)si;
-            host_angles[(size_t)d.ang_off + a] = ang[a];
-        }
-        d.delta = (precision == MM_PRECISION_F32)
-                      ? screen_delta(rx, ry, d.n_ref, tx, ty, d.n_tgt, d.cx, d.cy) : 0.0;
+    unsigned char* h = (unsigned char*)e->host_lvl.p;
+    float *c32 = (float*)(h + o_c32), *s32 = (float*)(h + o_s32);
+    double *c64 = (double*)(h + o_c64), *s64 = (double*)(h + o_s64);
+    for (int64_t t = 0; t < T; ++t) {
+        const double co = std::cos(host_tables[(size_t)t]), si = std::sin(host_tables[(size_t)t]);
+        c64[t] = co; s64[t] = si; c32[t] = (float)co; s32[t] = (float)si;
     }
-    std::memcpy(h + L.pairs, host_pairs.data(), (size_t)P * sizeof(PairDesc));
-    if (W) std::memcpy(h + L.work, host_work.data(), (size_t)W * sizeof(WorkItem));
+    if (P) std::memcpy(h + o_pairs, host_pairs.data(), (size_t)P * sizeof(PairDesc));
+    if (W) std::memcpy(h + o_work, host_work.data(), (size_t)W * sizeof(WorkItem));
 
-    // ---- device blob ------------------------------------------------------------------------
     if (transient) {
-        rc = e->ensure_dev(L.total);
+        rc = e->ensure(e->dev_lvl, lvl_bytes, false);
         if (rc) return rc;
-        blob = (unsigned char*)e->dev_buf;
-    } else {
-        MM_HIP(hipMalloc((void**)&blob, L.total));
+        lvl_blob = (unsigned char*)e->dev_lvl.p; own_lvl = false;
+    } else if (lvl_bytes > lvl_cap) {
+        if (lvl_blob) { MM_HIP(hipStreamSynchronize(e->stream)); (void)hipFree(lvl_blob); lvl_blob = nullptr; }
+        MM_HIP(hipMalloc((void**)&lvl_blob, lvl_bytes));
+        lvl_cap = lvl_bytes; own_lvl = true;
     }
-    MM_HIP(hipMemcpyAsync(blob, h, L.in_bytes, hipMemcpyHostToDevice, e->stream));
+    MM_HIP(hipMemcpyAsync(lvl_blob, h, lvl_in_bytes, hipMemcpyHostToDevice, e->stream));
     if (!transient) MM_HIP(hipStreamSynchronize(e->stream));  // host staging buffer is reused
 
-    dev.pairs = (const PairDesc*)(blob + L.pairs);
-    dev.work = (const WorkItem*)(blob + L.work);
+    unsigned char* B = lvl_blob;
+    dev.pairs = (const PairDesc*)(B + o_pairs); dev.work = (const WorkItem*)(B + o_work);
     dev.n_pairs = P; dev.n_work = W;
-    dev.cos32 = (const float*)(blob + L.cos32); dev.sin32 = (const float*)(blob + L.sin32);
-    dev.cos64 = (const double*)(blob + L.cos64); dev.sin64 = (const double*)(blob + L.sin64);
-    dev.ref32x = (const float*)(blob + L.r32x); dev.ref32y = (const float*)(blob + L.r32y);
-    dev.tgt32x = (const float*)(blob + L.t32x); dev.tgt32y = (const float*)(blob + L.t32y);
-    dev.ref64x = (const double*)(blob + L.r64x); dev.ref64y = (const double*)(blob + L.r64y);
-    dev.tgt64x = (const double*)(blob + L.t64x); dev.tgt64y = (const double*)(blob + L.t64y);
-    dev.sq32 = (float*)(blob + L.sq32); dev.sq64 = (double*)(blob + L.sq64);
-    dev.flag = (uint8_t*)(blob + L.flag);
-    dev.items = (WorkItem*)(blob + L.items); dev.n_items = (int32_t*)(blob + L.n_items);
-    dev.best_cost = (double*)(blob + L.best_cost); dev.best_idx = (int32_t*)(blob + L.best_idx);
-    dev.n_rescored = (int32_t*)(blob + L.n_rescored);
-    dev.all_costs = want_costs ? (double*)(blob + L.all_costs) : nullptr;
-    off_best_cost = L.best_cost; off_best_idx = L.best_idx; off_n_rescored = L.n_rescored;
-    off_all_costs = L.all_costs;
+    dev.cos32 = (const float*)(B + o_c32); dev.sin32 = (const float*)(B + o_s32);
+    dev.cos64 = (const double*)(B + o_c64); dev.sin64 = (const double*)(B + o_s64);
+    dev.sq32 = (float*)(B + o_sq32); dev.sq64 = (double*)(B + o_sq64); dev.flag = (uint8_t*)(B + o_flag);
+    dev.items = (WorkItem*)(B + o_items); dev.n_items = (int32_t*)(B + o_nitems);
+    dev.best_cost = (double*)(B + o_bc); dev.best_idx = (int32_t*)(B + o_bi); dev.n_rescored = (int32_t*)(B + o_nr);
+    dev.near_cnt = (int32_t*)(B + o_nc); dev.near_idx = (int32_t*)(B + o_ni);
+    dev.all_costs = want_costs ? (double*)(B + off_all_costs) : nullptr;
     return MM_OK;
 }
 
@@ -301,7 +301,7 @@ int Plan::run(bool screen_only)
         MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
         e = launch_shortlist(dev, s);
         if (e != hipSuccess) return hip_error(e, "shortlist kernel launch");
-        e = launch_rescore(dev, max_na, max_nbp, (int)A, s);
+        e = launch_rescore(dev, max_na, max_nbp, (int)std::min<int64_t>(A, INT32_MAX), s);
         if (e != hipSuccess) return hip_error(e, "rescore kernel launch");
         e = launch_finalize(dev, 1, s);
         if (e != hipSuccess) return hip_error(e, "finalize kernel launch");
@@ -317,60 +317,97 @@ int Plan::run(bool screen_only)
     return MM_OK;
 }
 
-int Plan::fetch(int32_t* best_idx, double* best_angle, double* best_cost, int32_t* n_rescored, double* all_costs)
+int Plan::fetch(BatchResult& out, double* all_costs_plan_order)
 {
-    // results are contiguous: best_cost | best_idx | n_rescored (+ all_costs)
-    const size_t res_bytes = (off_n_rescored + align_up((size_t)P * 4)) - off_best_cost;
-    const size_t cost_bytes = (all_costs && dev.all_costs) ? (size_t)A * 8 : 0;
-    int rc = eng->ensure_host(std::max(in_bytes, res_bytes + cost_bytes + 256));
-    if (rc) return rc;
-    unsigned char* h = (unsigned char*)eng->host_buf;
-    if (P > 0) MM_HIP(hipMemcpyAsync(h, blob + off_best_cost, res_bytes, hipMemcpyDeviceToHost, eng->stream));
-    if (cost_bytes) MM_HIP(hipMemcpyAsync(h + align_up(res_bytes), dev.all_costs, cost_bytes, hipMemcpyDeviceToHost, eng->stream));
+    const size_t cost_bytes = (all_costs_plan_order && dev.all_costs) ? (size_t)A * 8 : 0;
+    unsigned char* h = (unsigned char*)eng->host_lvl.p;  // sized in stage_level
+    if (P > 0) MM_HIP(hipMemcpyAsync(h, lvl_blob + off_best_cost, res_bytes, hipMemcpyDeviceToHost, eng->stream));
+    if (cost_bytes)
+        MM_HIP(hipMemcpyAsync(all_costs_plan_order, dev.all_costs, cost_bytes, hipMemcpyDeviceToHost, eng->stream));
     MM_HIP(hipStreamSynchronize(eng->stream));
     const double* hc = (const double*)h;
-    const int32_t* hi = (const int32_t*)(h + (off_best_idx - off_best_cost));
-    const int32_t* hn = (const int32_t*)(h + (off_n_rescored - off_best_cost));
-    const double* hall = (const double*)(h + align_up(res_bytes));
+    const int32_t* hi = (const int32_t*)(h + r_best_idx);
+    const int32_t* hn = (const int32_t*)(h + r_n_rescored);
+    const int32_t* hnc = (const int32_t*)(h + r_near_cnt);
+    const int32_t* hni = (const int32_t*)(h + r_near_idx);
+    out.best_idx.assign(P, -1); out.n_rescored.assign(P, 0); out.near_cnt.assign(P, 0);
+    out.near_idx.assign((size_t)P * kMaxNear, -1); out.best_cost.assign(P, INFINITY);
     for (int p = 0; p < P; ++p) {
         const PairDesc& d = host_pairs[p];
-        int32_t idx; double cost; int32_t nres;
         if (trivial[p]) {
-            // every candidate costs 0.0; the ordered first-minimum is candidate ang_begin
-            // (if this plan's slice is non-empty)
-            const bool any = !std::isnan(first_angle[p]);
-            idx = any ? d.ang_begin : -1; cost = any ? 0.0 : INFINITY; nres = 0;
-        } else {
-            idx = hi[p]; cost = hc[p]; nres = hn[p];
-        }
-        if (best_idx) best_idx[p] = idx;
-        if (best_cost) best_cost[p] = cost;
-        if (n_rescored) n_rescored[p] = nres;
-        if (best_angle) {
-            if (idx < 0) best_angle[p] = NAN;
-            else if (trivial[p]) best_angle[p] = first_angle[p];
-            else best_angle[p] = host_angles[(size_t)d.ang_off + (idx - d.ang_begin)];
-        }
-    }
-    if (all_costs && dev.all_costs) {
-        // scatter from the plan's candidate order to the caller's ang_off indexing
-        for (int p = 0; p < P; ++p) {
-            const PairDesc& d = host_pairs[p];
-            double* dst = all_costs + user_ang_off[p] + d.ang_begin;
-            if (trivial[p]) {
-                const int64_t n = std::max<int64_t>(0, std::min<int64_t>(slice_end, d.ang_full) - d.ang_begin);
-                for (int64_t a = 0; a < n; ++a) dst[a] = 0.0;
-            } else if (d.n_ang > 0) {
-                std::memcpy(dst, hall + d.ang_off, (size_t)d.n_ang * 8);
+            // every candidate costs 0.0; the ordered first minimum is the first candidate of the slice
+            if (d.ang_begin < slice_hi(d)) {
+                out.best_idx[p] = d.ang_begin; out.best_cost[p] = 0.0;
+                out.near_cnt[p] = 1; out.near_idx[(size_t)p * kMaxNear] = d.ang_begin;
             }
+            continue;
         }
+        out.best_idx[p] = hi[p]; out.best_cost[p] = hc[p]; out.n_rescored[p] = hn[p]; out.near_cnt[p] = hnc[p];
+        for (int k = 0; k < kMaxNear; ++k) out.near_idx[(size_t)p * kMaxNear + k] = hni[(size_t)p * kMaxNear + k];
     }
     return MM_OK;
 }
 
+double Plan::angle_of(int p, int32_t idx) const
+{
+    const PairDesc& d = host_pairs[p];
+    if (idx < d.ang_begin) return NAN;
+    const size_t k = (size_t)d.tab_off + (size_t)(idx - d.ang_begin);
+    return k < host_tables.size() ? host_tables[k] : NAN;
+}
+
 Plan::~Plan()
 {
-    if (blob && !transient) (void)hipFree(blob);
+    if (pts_blob && own_pts) (void)hipFree(pts_blob);
+    if (lvl_blob && own_lvl) (void)hipFree(lvl_blob);
+}
+
+int run_batch(Engine* e, const std::vector<SetRef>& sets, const std::vector<PairSpec>& pairs, int precision,
+              BatchResult& out)
+{
+    Plan plan;
+    int rc = plan.stage_sets(e, sets, /*transient=*/true);
+    if (rc) return rc;
+    rc = plan.stage_level(pairs, precision, 0, INT32_MAX, false);
+    if (rc) return rc;
+    rc = plan.run(false);
+    if (rc) return rc;
+    return plan.fetch(out, nullptr);
+}
+
+// Translate the public CSR batch description into sets + pairs.
+static int make_specs(int n_pairs, const int64_t* ref_off, const double* ref_x, const double* ref_y,
+                      const int64_t* tgt_off, const double* tgt_x, const double* tgt_y, const int64_t* ang_off,
+                      const double* angles, const double* cx, const double* cy, const int32_t* flags,
+                      std::vector<SetRef>& sets, std::vector<PairSpec>& pairs)
+{
+    if (n_pairs < 0) return set_error(MM_ERR_INVALID, "n_pairs < 0");
+    sets.clear(); pairs.clear();
+    sets.reserve(2 * (size_t)n_pairs); pairs.reserve((size_t)n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        const int64_t nr = ref_off[p + 1] - ref_off[p], nt = tgt_off[p + 1] - tgt_off[p], na = ang_off[p + 1] - ang_off[p];
+        if (nr < 0 || nt < 0 || na < 0 || nr > INT32_MAX || nt > INT32_MAX || na > INT32_MAX)
+            return set_error(MM_ERR_INVALID, "bad extent in batch offsets");
+        sets.push_back(SetRef{ref_x + ref_off[p], ref_y + ref_off[p], (int32_t)nr, cx[p], cy[p]});
+        sets.push_back(SetRef{tgt_x + tgt_off[p], tgt_y + tgt_off[p], (int32_t)nt, cx[p], cy[p]});
+        pairs.push_back(PairSpec{2 * p, 2 * p + 1, cx[p], cy[p], flags ? flags[p] : 0, angles + ang_off[p], (int32_t)na, 0.0, 0.0});
+    }
+    return MM_OK;
+}
+
+// Scatter plan-order costs into the caller's ang_off indexing (slices, empty-set pairs).
+static void scatter_costs(const Plan& plan, const double* plan_costs, const int64_t* ang_off, double* all_costs)
+{
+    for (int p = 0; p < plan.P; ++p) {
+        const PairDesc& d = plan.host_pairs[p];
+        double* dst = all_costs + ang_off[p] + d.ang_begin;
+        if (plan.trivial[p]) {
+            const int32_t n = std::max(0, plan.slice_hi(d) - d.ang_begin);
+            for (int32_t a = 0; a < n; ++a) dst[a] = 0.0;
+        } else if (d.n_ang > 0) {
+            std::memcpy(dst, plan_costs + d.out_off, (size_t)d.n_ang * 8);
+        }
+    }
 }
 
 }  // namespace mm
@@ -422,8 +459,8 @@ void mm_engine_destroy(mm_engine* h)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    if (e->host_buf) (void)hipHostFree(e->host_buf);
-    if (e->dev_buf) (void)hipFree(e->dev_buf);
+    for (Engine::Buf* b : {&e->host_pts, &e->host_lvl}) if (b->p) (void)hipHostFree(b->p);
+    for (Engine::Buf* b : {&e->dev_pts, &e->dev_lvl}) if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -485,14 +522,23 @@ int mm_best_rotation_batch(mm_engine* h, int n_pairs,
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     if (n_pairs == 0) return MM_OK;
     MM_HIP(hipSetDevice(e->device));
+    std::vector<SetRef> sets; std::vector<PairSpec> pairs;
+    int rc = make_specs(n_pairs, ref_off, ref_x, ref_y, tgt_off, tgt_x, tgt_y, ang_off, angles, cx, cy, flags, sets, pairs);
+    if (rc) return rc;
     Plan plan;
-    int rc = plan.build(e, n_pairs, ref_off, ref_x, ref_y, tgt_off, tgt_x, tgt_y, ang_off, angles, cx, cy, flags,
-                        precision, 0, INT32_MAX, all_costs != nullptr, /*transient=*/true);
-    if (rc) return rc;
-    rc = plan.run(false);
-    if (rc) return rc;
-    rc = plan.fetch(best_idx, best_angle, best_cost, n_rescored, all_costs);
-    if (rc) return rc;
+    if ((rc = plan.stage_sets(e, sets, true))) return rc;
+    if ((rc = plan.stage_level(pairs, precision, 0, INT32_MAX, all_costs != nullptr))) return rc;
+    if ((rc = plan.run(false))) return rc;
+    BatchResult res;
+    std::vector<double> costs(all_costs ? (size_t)plan.A : 0);
+    if ((rc = plan.fetch(res, all_costs ? costs.data() : nullptr))) return rc;
+    for (int p = 0; p < n_pairs; ++p) {
+        if (best_idx) best_idx[p] = res.best_idx[p];
+        if (best_cost) best_cost[p] = res.best_cost[p];
+        if (n_rescored) n_rescored[p] = res.n_rescored[p];
+        if (best_angle) best_angle[p] = res.best_idx[p] >= 0 ? angles[ang_off[p] + res.best_idx[p]] : NAN;
+    }
+    if (all_costs) scatter_costs(plan, costs.data(), ang_off, all_costs);
     return MM_OK;
 }
 
@@ -517,12 +563,9 @@ int mm_hausdorff_2d(mm_engine* h, const double* ax, const double* ay, int na,
                     const double* bx, const double* by, int nb, double* out)
 {
     if (!out) return set_error(MM_ERR_INVALID, "out == NULL");
+    if (!h) return set_error(MM_ERR_INVALID, "engine == NULL");
     if (na < 0 || nb < 0) return set_error(MM_ERR_INVALID, "negative set size");
-    if (na == 0 || nb == 0) {  // process_utils.rs:86-88
-        if (!h) return set_error(MM_ERR_INVALID, "engine == NULL");
-        *out = 0.0;
-        return MM_OK;
-    }
+    if (na == 0 || nb == 0) { *out = 0.0; return MM_OK; }  // process_utils.rs:86-88
     const double zero = 0.0;
     double cost = NAN;
     // angle 0 with the rotate() shortcut leaves the target untouched -> plain hausdorff_distance
@@ -532,6 +575,12 @@ int mm_hausdorff_2d(mm_engine* h, const double* ax, const double* ay, int na,
     *out = cost;
     return MM_OK;
 }
+
+// ---- persistent plans ------------------------------------------------------------------
+struct PlanHandle {
+    Plan plan;
+    std::vector<int64_t> ang_off;  // caller's candidate offsets
+};
 
 int mm_plan_create(mm_engine* h, int n_pairs,
                    const int64_t* ref_off, const double* ref_x, const double* ref_y,
@@ -544,69 +593,85 @@ int mm_plan_create(mm_engine* h, int n_pairs,
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine/out == NULL");
     *out = nullptr;
     MM_HIP(hipSetDevice(e->device));
-    Plan* p = new Plan();
-    int rc = p->build(e, n_pairs, ref_off, ref_x, ref_y, tgt_off, tgt_x, tgt_y, ang_off, angles, cx, cy, flags,
-                      precision, angle_begin, angle_end, /*want_costs=*/true, /*transient=*/false);
-    if (rc) { delete p; return rc; }
-    *out = reinterpret_cast<mm_plan*>(p);
+    std::vector<SetRef> sets; std::vector<PairSpec> pairs;
+    int rc = make_specs(n_pairs, ref_off, ref_x, ref_y, tgt_off, tgt_x, tgt_y, ang_off, angles, cx, cy, flags, sets, pairs);
+    if (rc) return rc;
+    PlanHandle* ph = new PlanHandle();
+    ph->ang_off.assign(ang_off, ang_off + n_pairs + 1);
+    if ((rc = ph->plan.stage_sets(e, sets, false)) || (rc = ph->plan.stage_level(pairs, precision, angle_begin, angle_end, true))) {
+        delete ph;
+        return rc;
+    }
+    *out = reinterpret_cast<mm_plan*>(ph);
     return MM_OK;
 }
 
 void mm_plan_destroy(mm_plan* h)
 {
-    Plan* p = reinterpret_cast<Plan*>(h);
+    PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return;
-    (void)hipSetDevice(p->eng->device);
-    (void)hipStreamSynchronize(p->eng->stream);
+    (void)hipSetDevice(p->plan.eng->device);
+    (void)hipStreamSynchronize(p->plan.eng->stream);
     delete p;
 }
 
 int mm_plan_run(mm_plan* h)
 {
-    Plan* p = reinterpret_cast<Plan*>(h);
+    PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
-    return p->run(false);
+    return p->plan.run(false);
 }
 
 int mm_plan_run_screen_only(mm_plan* h)
 {
-    Plan* p = reinterpret_cast<Plan*>(h);
+    PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
-    return p->run(true);
+    return p->plan.run(true);
 }
 
 int mm_plan_fetch(mm_plan* h, int32_t* best_idx, double* best_angle, double* best_cost,
                   int32_t* n_rescored, double* all_costs)
 {
-    Plan* p = reinterpret_cast<Plan*>(h);
+    PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
-    return p->fetch(best_idx, best_angle, best_cost, n_rescored, all_costs);
+    Plan& plan = p->plan;
+    BatchResult res;
+    std::vector<double> costs(all_costs ? (size_t)plan.A : 0);
+    int rc = plan.fetch(res, all_costs ? costs.data() : nullptr);
+    if (rc) return rc;
+    for (int q = 0; q < plan.P; ++q) {
+        if (best_idx) best_idx[q] = res.best_idx[q];
+        if (best_cost) best_cost[q] = res.best_cost[q];
+        if (n_rescored) n_rescored[q] = res.n_rescored[q];
+        if (best_angle) best_angle[q] = res.best_idx[q] >= 0 ? plan.angle_of(q, res.best_idx[q]) : NAN;
+    }
+    if (all_costs) scatter_costs(plan, costs.data(), p->ang_off.data(), all_costs);
+    return MM_OK;
 }
 
 int mm_plan_result_dev(mm_plan* h, void** best_cost_dev, void** best_idx_dev)
 {
-    Plan* p = reinterpret_cast<Plan*>(h);
+    PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
-    if (best_cost_dev) *best_cost_dev = p->dev.best_cost;
-    if (best_idx_dev) *best_idx_dev = p->dev.best_idx;
+    if (best_cost_dev) *best_cost_dev = p->plan.dev.best_cost;
+    if (best_idx_dev) *best_idx_dev = p->plan.dev.best_idx;
     return MM_OK;
 }
 
 int mm_plan_time(mm_plan* h, int iters, int screen_only, float* ms_avg)
 {
-    Plan* p = reinterpret_cast<Plan*>(h);
+    PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p || !ms_avg || iters <= 0) return set_error(MM_ERR_INVALID, "mm_plan_time: bad arguments");
+    Plan& plan = p->plan;
     hipEvent_t t0, t1;
     MM_HIP(hipEventCreate(&t0));
     MM_HIP(hipEventCreate(&t1));
-    int rc = p->run(screen_only != 0);  // warm-up
+    int rc = plan.run(screen_only != 0);  // warm-up
     if (rc) return rc;
-    MM_HIP(hipEventRecord(t0, p->eng->stream));
-    for (int i = 0; i < iters; ++i) {
-        rc = p->run(screen_only != 0);
-        if (rc) return rc;
-    }
-    MM_HIP(hipEventRecord(t1, p->eng->stream));
+    MM_HIP(hipEventRecord(t0, plan.eng->stream));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = plan.run(screen_only != 0))) return rc;
+    MM_HIP(hipEventRecord(t1, plan.eng->stream));
     MM_HIP(hipEventSynchronize(t1));
     float ms = 0.f;
     MM_HIP(hipEventElapsedTime(&ms, t0, t1));
@@ -618,11 +683,11 @@ int mm_plan_time(mm_plan* h, int iters, int screen_only, float* ms_avg)
 
 int mm_plan_stats(mm_plan* h, int64_t* n_candidates, double* pair_evals, int64_t* hbm_bytes)
 {
-    Plan* p = reinterpret_cast<Plan*>(h);
+    PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
-    if (n_candidates) *n_candidates = p->A;
-    if (pair_evals) *pair_evals = p->pair_evals;
-    if (hbm_bytes) *hbm_bytes = (int64_t)p->total_bytes;
+    if (n_candidates) *n_candidates = p->plan.A;
+    if (pair_evals) *pair_evals = p->plan.pair_evals;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p->plan.hbm_bytes();
     return MM_OK;
 }
 

@@ -20,11 +20,13 @@ int hip_error(hipError_t e, const char* what);
 // transient plans behind mm_best_rotation_batch, so the per-call cost in the sequential
 // chain is one H2D copy, the kernel launches and one D2H copy.
 struct Engine {
+    struct Buf { void* p = nullptr; size_t cap = 0; };
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    void* host_buf = nullptr; size_t host_cap = 0;
-    void* dev_buf = nullptr;  size_t dev_cap = 0;
+    Buf host_pts, host_lvl;   // pinned staging: point pool / level (+ results)
+    Buf dev_pts, dev_lvl;     // device buffers of transient plans
+    int ensure(Buf& b, size_t bytes, bool host);
     // profiling of the scoring kernel (mm_engine_profile*)
     bool profile = false;
     std::vector<hipEvent_t> events;   // pairs: [2k] before, [2k+1] after launch k
@@ -33,38 +35,67 @@ struct Engine {
     int64_t prof_candidates = 0;
     int profile_begin();
     int profile_end(double pair_evals, int64_t candidates);
-    int ensure_host(size_t bytes);
-    int ensure_dev(size_t bytes);
 };
 
+// ---- internal batch description (the C ABI wrappers translate into this) --------------
+struct SetRef {            // one point set: SoA f64 as given + the centre its f32 copy is relative to
+    const double* x; const double* y; int32_t n; double cx, cy;
+};
+struct PairSpec {          // one search
+    int32_t ref_set, tgt_set;      // indices into the set list
+    double cx, cy;                 // rotation centre (must equal the centre of both sets' f32 copies)
+    int32_t flags;
+    const double* angles; int32_t n_angles;   // candidate list (pairs passing the same pointer share tables)
+    double tie_tol;                // near-tie tolerance on the exact cost (0 -> exact ties only)
+    double delta_extra;            // added to the f32 screening bound
+};
+struct BatchResult {
+    std::vector<int32_t> best_idx, n_rescored, near_cnt, near_idx;  // near_idx: kMaxNear per pair
+    std::vector<double> best_cost;
+};
+
+// A staged batch: point pool (uploaded once) + a re-stageable level (descriptors, candidate
+// tables, outputs).  Transient plans borrow the engine's grow-only buffers.
 struct Plan {
     Engine* eng = nullptr;
-    int P = 0, W = 0;
-    int64_t A = 0;
-    int precision = MM_PRECISION_F32;
     bool transient = false;
+    int precision = MM_PRECISION_F32;
+    // sets
+    std::vector<int32_t> set_off, set_len;
+    std::vector<double> set_rho;   // max distance of a point from the set's centre
+    int64_t n_points = 0;
+    unsigned char* pts_blob = nullptr; size_t pts_bytes = 0; bool own_pts = false;
+    // level
+    int P = 0, W = 0;
+    int64_t A = 0;            // candidates in this plan (sum of slices)
+    int64_t T = 0;            // cos/sin table entries
     int max_na = 1, max_nbp = 16;
     double pair_evals = 0.0;
-    size_t in_bytes = 0, total_bytes = 0;
-    size_t off_best_cost = 0, off_best_idx = 0, off_n_rescored = 0, off_all_costs = 0;
-    unsigned char* blob = nullptr;
+    unsigned char* lvl_blob = nullptr; size_t lvl_cap = 0; bool own_lvl = false;
+    size_t lvl_in_bytes = 0, lvl_bytes = 0;
+    size_t off_best_cost = 0, res_bytes = 0, off_all_costs = 0;
+    size_t r_best_idx = 0, r_n_rescored = 0, r_near_cnt = 0, r_near_idx = 0;  // offsets inside the result block
+    int32_t slice_end = INT32_MAX;
     BatchDev dev{};
     std::vector<PairDesc> host_pairs;
     std::vector<WorkItem> host_work;
-    std::vector<double> host_angles;       // slice-local candidate angles
-    std::vector<double> first_angle;       // per pair: first candidate of the slice (trivial pairs)
-    std::vector<int64_t> user_ang_off;     // caller's candidate offsets (for all_costs scatter)
-    int32_t slice_end = INT32_MAX;
-    std::vector<uint8_t> trivial;          // pair has an empty set: every cost is 0.0
+    std::vector<double> host_tables;          // distinct candidate lists (slice-local), dev tables mirror them
+    std::vector<uint8_t> trivial;             // pair has an empty set: every cost is 0.0
+    bool want_costs = false;
 
-    int build(Engine* e, int n_pairs, const int64_t* ref_off, const double* ref_x, const double* ref_y,
-              const int64_t* tgt_off, const double* tgt_x, const double* tgt_y,
-              const int64_t* ang_off, const double* angles, const double* cx, const double* cy,
-              const int32_t* flags, int precision, int32_t angle_begin, int32_t angle_end,
-              bool want_costs, bool transient);
+    int stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient);
+    int stage_level(const std::vector<PairSpec>& pairs, int precision, int32_t angle_begin, int32_t angle_end,
+                    bool want_costs);
     int run(bool screen_only);
-    int fetch(int32_t* best_idx, double* best_angle, double* best_cost, int32_t* n_rescored, double* all_costs);
+    int fetch(BatchResult& out, double* all_costs_plan_order);
+    size_t hbm_bytes() const { return pts_bytes + lvl_bytes; }
+    int32_t slice_hi(const PairDesc& d) const { return d.ang_full < slice_end ? d.ang_full : slice_end; }
+    double angle_of(int p, int32_t idx) const;
     ~Plan();
 };
+
+// One-shot batch on the engine's transient buffers (build, run, fetch).
+int run_batch(Engine* e, const std::vector<SetRef>& sets, const std::vector<PairSpec>& pairs, int precision,
+              BatchResult& out);
 
 }  // namespace mm

@@ -168,6 +168,7 @@ static int run_searches(Engine* e, std::vector<SearchJob>& jobs, double step_deg
 {
     const std::vector<Level> levels = search_levels(step_deg, range_deg, bruteforce);
     const int J = (int)jobs.size();
+    if (J == 0) return MM_OK;
     std::vector<double> centre(J, 0.0);
     std::vector<std::vector<double>> lists(J);
     for (size_t l = 0; l < levels.size(); ++l) {
@@ -180,28 +181,226 @@ static int run_searches(Engine* e, std::vector<SearchJob>& jobs, double step_deg
             active.push_back(j);
         }
         if (active.empty()) continue;
-        std::vector<int64_t> ro{0}, to{0}, ao{0};
-        std::vector<double> rx, ry, tx, ty, ang, cxs, cys;
-        std::vector<int32_t> fl;
+        std::vector<SetRef> sets;
+        std::vector<PairSpec> pairs;
         for (int j : active) {
-            const SearchJob& s = jobs[j];
-            rx.insert(rx.end(), s.rx.begin(), s.rx.end()); ry.insert(ry.end(), s.ry.begin(), s.ry.end());
-            tx.insert(tx.end(), s.tx.begin(), s.tx.end()); ty.insert(ty.end(), s.ty.begin(), s.ty.end());
-            ang.insert(ang.end(), lists[j].begin(), lists[j].end());
-            ro.push_back((int64_t)rx.size()); to.push_back((int64_t)tx.size()); ao.push_back((int64_t)ang.size());
-            cxs.push_back(s.cx); cys.push_back(s.cy); fl.push_back(s.flags);
+            const SearchJob& sj = jobs[j];
+            const int32_t sid = (int32_t)sets.size();
+            sets.push_back(SetRef{sj.rx.data(), sj.ry.data(), (int32_t)sj.rx.size(), sj.cx, sj.cy});
+            sets.push_back(SetRef{sj.tx.data(), sj.ty.data(), (int32_t)sj.tx.size(), sj.cx, sj.cy});
+            pairs.push_back(PairSpec{sid, sid + 1, sj.cx, sj.cy, sj.flags, lists[j].data(), (int32_t)lists[j].size(), 0.0, 0.0});
             if (pose_evals) *pose_evals += (int64_t)lists[j].size();
         }
-        std::vector<int32_t> bidx(active.size());
-        std::vector<double> bang(active.size()), bcost(active.size());
-        int rc = mm_best_rotation_batch(reinterpret_cast<mm_engine*>(e), (int)active.size(), ro.data(), rx.data(),
-                                        ry.data(), to.data(), tx.data(), ty.data(), ao.data(), ang.data(),
-                                        cxs.data(), cys.data(), fl.data(), precision, bidx.data(), bang.data(),
-                                        bcost.data(), nullptr, nullptr);
+        BatchResult res;
+        int rc = run_batch(e, sets, pairs, precision, res);
         if (rc) return rc;
-        for (size_t k = 0; k < active.size(); ++k) centre[active[k]] = lists[active[k]][bidx[k]];
+        for (size_t k = 0; k < active.size(); ++k) centre[active[k]] = lists[active[k]][res.best_idx[k]];
     }
     for (int j = 0; j < J; ++j) jobs[j].result = centre[j];
+    return MM_OK;
+}
+
+// -------------------------------------------------------------------------------------
+// Decoupled within-pullback search ("screen all pairs at once, then walk the chain").
+//
+// In exact arithmetic the cost of step i does not depend on the chain state: frame i-1
+// and frame i have both been rotated by the same cumulative angle about a common centre
+// (align_within.rs:79-90), and a rigid motion preserves the Hausdorff distance.  So every
+// (frame pair, candidate) of every pullback can be scored in ONE launch on the original
+// frames, each centred on its own centroid.  In floating point the chain-state cost and
+// the decoupled cost differ by rounding only; we bound that difference by
+// eps = 2^-42 * scale (scale = largest coordinate magnitude involved, >= 40x the worst
+// case of the handful of roundings involved) and keep the reference's result exactly:
+//   * screening keeps every candidate within 2*(delta_f32 + eps) of the f32 minimum,
+//   * those are re-scored in f64 on the decoupled sets,
+//   * a pair is RESOLVED if exactly one candidate is within 2*eps of the f64 minimum (or
+//     all such candidates are the same angle value, e.g. the duplicated -pi when
+//     range == limes == 180 deg: equal angles give equal chain costs and the lowest index
+//     wins, process_utils.rs:72);
+//   * anything else is searched again on the chain state in the walk below, exactly as
+//     mode 0 does.
+// The walk itself (pre-rotation, translation, rotation, logs) is the reference's.
+// -------------------------------------------------------------------------------------
+struct WithinPlan {
+    Engine* e = nullptr;
+    int n_geoms = 0;
+    std::vector<mm_geometry*> geoms;
+    double step_deg = 0, range_deg = 0;
+    bool bruteforce = false;
+    int64_t sample_size = 0;
+    int precision = MM_PRECISION_F32;
+    std::vector<SampleSpec> spec;
+    int32_t max_frames = 0;
+    // decoupled stage
+    std::vector<std::vector<double>> sx, sy;  // centred search sets, one per (geom, frame)
+    std::vector<int32_t> set_base;            // first set id of each geometry
+    std::vector<double> eps;                  // per geometry
+    std::vector<int> job_geom, job_frame;     // job j = (geometry, frame i >= 1)
+    std::vector<int32_t> job_base;            // first job of each geometry
+    std::vector<Level> levels;
+    std::vector<double> level0;               // shared candidate list of level 0
+    bool level0_ok = false; double level0_early = 0.0;
+    Plan plan;
+    bool staged = false;
+
+    int prepare();
+    int search(std::vector<double>& centre, std::vector<uint8_t>& resolved, std::vector<int64_t>& evals);
+    int walk(const std::vector<double>& centre, const std::vector<uint8_t>& resolved, const std::vector<int64_t>& evals,
+             mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
+};
+
+int WithinPlan::prepare()
+{
+    spec.resize(n_geoms);
+    max_frames = 0;
+    for (int g = 0; g < n_geoms; ++g) {
+        const mm_geometry* G = geoms[g];
+        if (!G || G->n_frames <= 0) return set_error(MM_ERR_NO_FRAMES, "Geometry contains no frames");
+        if (G->lumen_off[1] - G->lumen_off[0] <= 0) return set_error(MM_ERR_NO_POINTS, "Lumen contours have no points");
+        if (sample_size <= 0) return set_error(MM_ERR_SAMPLE_SIZE, "sample_size must be > 0");
+        spec[g] = sample_spec(G, sample_size);
+        max_frames = std::max(max_frames, G->n_frames);
+    }
+    levels = search_levels(step_deg, range_deg, bruteforce);
+    level0_ok = enumerate_angles(levels[0].step, levels[0].range, false, 0.0, range_deg, level0, level0_early);
+
+    // centred search sets of the ORIGINAL frames + per-geometry rounding scale
+    set_base.assign(n_geoms + 1, 0); job_base.assign(n_geoms + 1, 0);
+    sx.clear(); sy.clear(); job_geom.clear(); job_frame.clear();
+    eps.assign(n_geoms, 0.0);
+    for (int g = 0; g < n_geoms; ++g) {
+        const mm_geometry* G = geoms[g];
+        set_base[g] = (int32_t)sx.size();
+        job_base[g] = (int32_t)job_geom.size();
+        double scale = 0.0;
+        for (int32_t i = 0; i < G->n_frames; ++i) {
+            std::vector<double> x, y;
+            frame_search_set(G, i, spec[g], x, y);
+            const double cx = G->centroid[3 * i], cy = G->centroid[3 * i + 1];
+            for (size_t k = 0; k < x.size(); ++k) {
+                scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
+                x[k] -= cx; y[k] -= cy;
+                scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
+            }
+            sx.push_back(std::move(x)); sy.push_back(std::move(y));
+            if (i >= 1) { job_geom.push_back(g); job_frame.push_back(i); }
+        }
+        // chain-state coordinates stay within |frame-0 centroid| + radius: 4x covers it amply
+        eps[g] = std::ldexp(4.0 * scale + 1.0, -42);
+    }
+    set_base[n_geoms] = (int32_t)sx.size();
+    job_base[n_geoms] = (int32_t)job_geom.size();
+
+    std::vector<SetRef> sets(sx.size());
+    for (size_t s = 0; s < sx.size(); ++s) sets[s] = SetRef{sx[s].data(), sy[s].data(), (int32_t)sx[s].size(), 0.0, 0.0};
+    int rc = plan.stage_sets(e, sets, /*transient=*/false);
+    if (rc) return rc;
+    staged = true;
+    return MM_OK;
+}
+
+int WithinPlan::search(std::vector<double>& centre, std::vector<uint8_t>& resolved, std::vector<int64_t>& evals)
+{
+    const int J = (int)job_geom.size();
+    centre.assign(J, 0.0); resolved.assign(J, 1); evals.assign(J, 0);
+    std::vector<std::vector<double>> lists(J);
+    for (size_t l = 0; l < levels.size(); ++l) {
+        std::vector<int> active;
+        std::vector<PairSpec> pairs;
+        for (int j = 0; j < J; ++j) {
+            if (!resolved[j]) continue;
+            const double* lp; int32_t ln;
+            if (l == 0) {
+                if (!level0_ok) { centre[j] = level0_early; continue; }
+                lp = level0.data(); ln = (int32_t)level0.size();
+            } else {
+                double early = 0.0;
+                if (!enumerate_angles(levels[l].step, levels[l].range, true, centre[j], range_deg, lists[j], early)) {
+                    centre[j] = early;
+                    continue;
+                }
+                lp = lists[j].data(); ln = (int32_t)lists[j].size();
+            }
+            const int g = job_geom[j], i = job_frame[j];
+            const int32_t sid = set_base[g] + i;
+            pairs.push_back(PairSpec{sid - 1, sid, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, lp, ln, 2.0 * eps[g], eps[g]});
+            active.push_back(j);
+            evals[j] += ln;
+        }
+        if (active.empty()) continue;
+        int rc = plan.stage_level(pairs, precision, 0, INT32_MAX, false);
+        if (rc) return rc;
+        if ((rc = plan.run(false))) return rc;
+        BatchResult res;
+        if ((rc = plan.fetch(res, nullptr))) return rc;
+        for (size_t k = 0; k < active.size(); ++k) {
+            const int j = active[k];
+            const double* lp = pairs[k].angles;
+            const int32_t n = res.near_cnt[k];
+            bool ok = (n == 1);
+            if (!ok && n >= 2 && n <= kMaxNear) {  // all near-ties are the same angle value?
+                ok = true;
+                const double a0 = lp[res.near_idx[k * kMaxNear]];
+                for (int q = 1; q < n; ++q) ok = ok && (std::memcmp(&a0, &lp[res.near_idx[k * kMaxNear + q]], 8) == 0);
+            }
+            if (ok) centre[j] = lp[res.best_idx[k]];
+            else resolved[j] = 0;  // decided on the chain state in walk()
+        }
+    }
+    return MM_OK;
+}
+
+int WithinPlan::walk(const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
+                     const std::vector<int64_t>& evals, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
+{
+    std::vector<double> cumulative(n_geoms, 0.0);
+    for (int32_t i = 1; i < max_frames; ++i) {
+        std::vector<SearchJob> jobs;      // unresolved steps: searched on the chain state
+        std::vector<int> job_owner;
+        struct Step { int g; double tx, ty, cx, cy, best; bool pending; };
+        std::vector<Step> steps;
+        for (int g = 0; g < n_geoms; ++g) {
+            mm_geometry* G = geoms[g];
+            if (i >= G->n_frames) continue;
+            const double pcx = G->centroid[3 * (i - 1)], pcy = G->centroid[3 * (i - 1) + 1];
+            if (cumulative[g] != 0.0)  // align_within.rs:79-82
+                mm_frame_rotate(G, i, cumulative[g], G->centroid[3 * i], G->centroid[3 * i + 1]);
+            const double tx = pcx - G->centroid[3 * i], ty = pcy - G->centroid[3 * i + 1];  // :84-88
+            mm_frame_translate(G, i, tx, ty, 0.0);                                            // :90
+            Step st{g, tx, ty, G->centroid[3 * i], G->centroid[3 * i + 1], 0.0, false};
+            const int j = job_base[g] + (i - 1);
+            if (resolved[j]) {
+                st.best = centre[j];
+                if (pose_evals) *pose_evals += evals[j];
+            } else {
+                SearchJob job;
+                frame_search_set(G, i, spec[g], job.tx, job.ty);      // :92-93
+                frame_search_set(G, i - 1, spec[g], job.rx, job.ry);  // :94-95
+                job.cx = st.cx; job.cy = st.cy; job.flags = MM_SEARCH_SKIP_ZERO;
+                jobs.push_back(std::move(job));
+                job_owner.push_back((int)steps.size());
+                st.pending = true;
+                if (n_unresolved) ++*n_unresolved;
+            }
+            steps.push_back(st);
+        }
+        if (!jobs.empty()) {
+            int rc = run_searches(e, jobs, step_deg, range_deg, bruteforce, precision, pose_evals);
+            if (rc) return rc;
+            for (size_t k = 0; k < jobs.size(); ++k) steps[job_owner[k]].best = jobs[k].result;
+        }
+        for (const Step& st : steps) {
+            mm_geometry* G = geoms[st.g];
+            mm_frame_rotate(G, i, st.best, st.cx, st.cy);  // :121-122
+            cumulative[st.g] += st.best;                   // :123
+            if (logs && logs[st.g]) {
+                mm_alignlog& L = logs[st.g][i - 1];
+                L.contour_id = G->id[i]; L.matched_to = G->id[i - 1];
+                L.rot_deg = rad2deg(st.best); L.tx = st.tx; L.ty = st.ty;
+                L.cx = G->centroid[3 * i]; L.cy = G->centroid[3 * i + 1];
+            }
+        }
+    }
     return MM_OK;
 }
 
@@ -289,7 +488,15 @@ int mm_align_within(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step
     Engine* e = reinterpret_cast<Engine*>(eh);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     if (n_geoms <= 0 || !geoms) return set_error(MM_ERR_INVALID, "no geometries");
-    if (mode != 0) return set_error(MM_ERR_INVALID, "mm_align_within: mode 1 (decoupled) is not available yet");
+    if (mode != 0 && mode != 1) return set_error(MM_ERR_INVALID, "mm_align_within: mode must be 0 (chain) or 1 (decoupled)");
+    if (mode == 1) {
+        mm_within_plan* wp = nullptr;
+        int rc = mm_within_plan_create(eh, n_geoms, geoms, step_deg, range_deg, bruteforce, sample_size, precision, &wp);
+        if (rc) return rc;
+        rc = mm_within_plan_run(wp, logs, pose_evals, nullptr);
+        mm_within_plan_destroy(wp);
+        return rc;
+    }
     if (pose_evals) *pose_evals = 0;
     int32_t max_frames = 0;
     std::vector<SampleSpec> spec(n_geoms);
@@ -339,6 +546,43 @@ int mm_align_within(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step
         }
     }
     return MM_OK;
+}
+
+int mm_within_plan_create(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step_deg, double range_deg,
+                          int bruteforce, int64_t sample_size, int precision, mm_within_plan** out)
+{
+    Engine* e = reinterpret_cast<Engine*>(eh);
+    if (!e || !out) return set_error(MM_ERR_INVALID, "engine/out == NULL");
+    *out = nullptr;
+    if (n_geoms <= 0 || !geoms) return set_error(MM_ERR_INVALID, "no geometries");
+    WithinPlan* wp = new WithinPlan();
+    wp->e = e; wp->n_geoms = n_geoms; wp->geoms.assign(geoms, geoms + n_geoms);
+    wp->step_deg = step_deg; wp->range_deg = range_deg; wp->bruteforce = bruteforce != 0;
+    wp->sample_size = sample_size; wp->precision = precision;
+    int rc = wp->prepare();
+    if (rc) { delete wp; return rc; }
+    *out = reinterpret_cast<mm_within_plan*>(wp);
+    return MM_OK;
+}
+
+int mm_within_plan_run(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
+    if (pose_evals) *pose_evals = 0;
+    if (n_unresolved) *n_unresolved = 0;
+    std::vector<double> centre; std::vector<uint8_t> resolved; std::vector<int64_t> evals;
+    int rc = wp->search(centre, resolved, evals);
+    if (rc) return rc;
+    return wp->walk(centre, resolved, evals, logs, pose_evals, n_unresolved);
+}
+
+void mm_within_plan_destroy(mm_within_plan* h)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp) return;
+    (void)hipStreamSynchronize(wp->e->stream);
+    delete wp;
 }
 
 // align_between.rs:11-68 for n_pairs independent (a, b) pairs.

@@ -138,8 +138,7 @@ template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB>
 __global__ void __launch_bounds__(NLI * 16)
 k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
          int n_work_host, const int* __restrict__ n_work_dev,
-         const T* __restrict__ refx, const T* __restrict__ refy,
-         const T* __restrict__ tgtx, const T* __restrict__ tgty,
+         const T* __restrict__ ptx, const T* __restrict__ pty,
          const T* __restrict__ cosv, const T* __restrict__ sinv,
          T* __restrict__ out_sq)
 {
@@ -174,7 +173,7 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
         __syncthreads();  // previous work item is done with LDS
         for (int j = tid; j < nbp; j += NT) {
             T2 t;
-            if (j < nb) { t.x = tgtx[pd.tgt_off + j]; t.y = tgty[pd.tgt_off + j]; }
+            if (j < nb) { t.x = ptx[pd.tgt_off + j]; t.y = pty[pd.tgt_off + j]; }
             else        { t.x = -TT::big();           t.y = -TT::big(); }
             s_tgt[j] = t;
         }
@@ -187,7 +186,7 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
             for (int r = 0; r < R; ++r) {
                 const int row = rb * ROWS_PER_BLOCK + r * NLI + li;
                 const int rc = row < na ? row : na - 1;
-                const T vx = refx[pd.ref_off + rc], vy = refy[pd.ref_off + rc];
+                const T vx = ptx[pd.ref_off + rc], vy = pty[pd.ref_off + rc];
                 ax[r] = row < na ? vx : TT::big();
                 ay[r] = row < na ? vy : TT::big();
             }
@@ -198,8 +197,8 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
         const bool skip_zero = (pd.flags & MM_SEARCH_SKIP_ZERO) != 0;
 
         for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
-            const T c = cosv[pd.ang_off + a];
-            const T s = sinv[pd.ang_off + a];
+            const T c = cosv[pd.tab_off + a];
+            const T s = sinv[pd.tab_off + a];
 
             __syncthreads();  // S0: readers of s_b / s_colmin / s_red from the previous angle are done
             for (int j = tid; j < nbp; j += NT) {
@@ -321,7 +320,7 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
             m = wave_max(m);
             if ((tid & 63) == 0) atomicMax(&s_red[0], TT::bits(m));
             __syncthreads();  // S3
-            if (tid == 0) out_sq[pd.ang_off + a] = TT::from(s_red[0]);
+            if (tid == 0) out_sq[pd.out_off + a] = TT::from(s_red[0]);
         }
     }
 }
@@ -342,7 +341,7 @@ k_shortlist(const PairDesc* __restrict__ pairs, const float* __restrict__ sq32,
     __syncthreads();
     unsigned int m = 0x7f800000u;
     for (int a = tid; a < pd.n_ang; a += 256) {
-        const unsigned int u = __float_as_uint(sq32[pd.ang_off + a]);
+        const unsigned int u = __float_as_uint(sq32[pd.out_off + a]);
         m = u < m ? u : m;
     }
     atomicMin(&s_min, m);
@@ -350,9 +349,9 @@ k_shortlist(const PairDesc* __restrict__ pairs, const float* __restrict__ sq32,
     const double hmin = sqrt((double)__uint_as_float(s_min));
     const double thr = hmin + 2.0 * pd.delta;
     for (int a = tid; a < pd.n_ang; a += 256) {
-        const double h = sqrt((double)sq32[pd.ang_off + a]);
+        const double h = sqrt((double)sq32[pd.out_off + a]);
         const bool keep = h <= thr;
-        flag[pd.ang_off + a] = keep ? 1 : 0;
+        flag[pd.out_off + a] = keep ? 1 : 0;
         if (keep) {
             const int slot = atomicAdd(n_items, 1);
             WorkItem w; w.pair = p; w.a0 = a; w.cnt = 1; w.pad = 0;
@@ -369,29 +368,33 @@ __global__ void __launch_bounds__(256)
 k_finalize(const PairDesc* __restrict__ pairs, const double* __restrict__ sq64,
            const float* __restrict__ sq32, const uint8_t* __restrict__ flag,
            double* __restrict__ best_cost, int* __restrict__ best_idx,
-           int* __restrict__ n_rescored, double* __restrict__ all_costs)
+           int* __restrict__ n_rescored, int* __restrict__ near_cnt, int* __restrict__ near_idx,
+           double* __restrict__ all_costs)
 {
     __shared__ double s_cost[256];
     __shared__ int s_idx[256];
     __shared__ int s_cnt[256];
+    __shared__ int s_near[kMaxNear];
+    __shared__ int s_nnear;
     const int p = blockIdx.x;
     const PairDesc pd = pairs[p];
     const int tid = threadIdx.x;
     double bc = __longlong_as_double(0x7ff0000000000000ll);
     int bi = 0x7fffffff, cnt = 0;
     for (int a = tid; a < pd.n_ang; a += 256) {
-        const bool f = flag ? (flag[pd.ang_off + a] != 0) : true;
+        const bool f = flag ? (flag[pd.out_off + a] != 0) : true;
         double h;
         if (f) {
-            h = sqrt(sq64[pd.ang_off + a]);  // process_utils.rs:120 (max before sqrt == sqrt before max)
+            h = sqrt(sq64[pd.out_off + a]);  // process_utils.rs:120 (max before sqrt == sqrt before max)
             ++cnt;
             if (h < bc) { bc = h; bi = a; }  // a increases per thread: first minimum kept
         } else {
-            h = sqrt((double)sq32[pd.ang_off + a]);
+            h = sqrt((double)sq32[pd.out_off + a]);
         }
-        if (all_costs) all_costs[pd.ang_off + a] = h;
+        if (all_costs) all_costs[pd.out_off + a] = h;
     }
     s_cost[tid] = bc; s_idx[tid] = bi; s_cnt[tid] = cnt;
+    if (tid == 0) s_nnear = 0;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
         if (tid < st) {
@@ -402,11 +405,36 @@ k_finalize(const PairDesc* __restrict__ pairs, const double* __restrict__ sq64,
         }
         __syncthreads();
     }
+    const double gbest = s_cost[0];
+    const bool any = s_idx[0] != 0x7fffffff;
+    // near-ties: exact-scored candidates within tol2 of the minimum (ascending, first kMaxNear)
+    if (near_cnt && any) {
+        const double thr = gbest + pd.tol2;
+        for (int a = tid; a < pd.n_ang; a += 256) {
+            const bool f = flag ? (flag[pd.out_off + a] != 0) : true;
+            if (f && sqrt(sq64[pd.out_off + a]) <= thr) {
+                const int slot = atomicAdd(&s_nnear, 1);
+                if (slot < kMaxNear) s_near[slot] = a;
+            }
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
-        const bool any = s_idx[0] != 0x7fffffff;
-        best_cost[p] = any ? s_cost[0] : __longlong_as_double(0x7ff0000000000000ll);
+        best_cost[p] = any ? gbest : __longlong_as_double(0x7ff0000000000000ll);
         best_idx[p] = any ? (s_idx[0] + pd.ang_begin) : -1;
         if (n_rescored) n_rescored[p] = s_cnt[0];
+        if (near_cnt) {
+            const int n = s_nnear;
+            near_cnt[p] = n;
+            const int m = n < kMaxNear ? n : kMaxNear;
+            for (int i = 1; i < m; ++i) {  // insertion sort of <= 8 entries
+                const int v = s_near[i];
+                int j = i - 1;
+                while (j >= 0 && s_near[j] > v) { s_near[j + 1] = s_near[j]; --j; }
+                s_near[j + 1] = v;
+            }
+            for (int i = 0; i < kMaxNear; ++i) near_idx[p * kMaxNear + i] = i < m ? s_near[i] + pd.ang_begin : -1;
+        }
     }
 }
 
@@ -423,7 +451,7 @@ const char* screen_kernel_name() { return "k_search<float"; }
 
 template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB>
 static hipError_t launch_one(const BatchDev& b, const WorkItem* work, int n_work, const int* n_work_dev,
-                             int grid, size_t lds, const T* rx, const T* ry, const T* tx, const T* ty,
+                             int grid, size_t lds, const T* px, const T* py,
                              const T* cv, const T* sv, T* out, hipStream_t s)
 {
     auto kern = k_search<T, R, NLI, EXACT, MULTI_RB>;
@@ -433,7 +461,7 @@ static hipError_t launch_one(const BatchDev& b, const WorkItem* work, int n_work
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NLI * 16), lds, s, b.pairs, work, n_work, n_work_dev,
-                       rx, ry, tx, ty, cv, sv, out);
+                       px, py, cv, sv, out);
     return hipGetLastError();
 }
 
@@ -445,8 +473,8 @@ hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStre
     if (b.n_work <= 0) return hipSuccess;
     const size_t lds = lds_bytes_f32(max_nbp);
     const int grid = b.n_work;
-#define MM_F32(Rv, MRB) launch_one<float, Rv, 16, false, MRB>(b, b.work, b.n_work, nullptr, grid, lds, b.ref32x, b.ref32y, \
-                                                         b.tgt32x, b.tgt32y, b.cos32, b.sin32, b.sq32, s)
+#define MM_F32(Rv, MRB) launch_one<float, Rv, 16, false, MRB>(b, b.work, b.n_work, nullptr, grid, lds, b.p32x, b.p32y, \
+                                                         b.cos32, b.sin32, b.sq32, s)
     if (max_na <= 16 * 2) return MM_F32(2, false);
     if (max_na <= 16 * 8) return MM_F32(8, false);
     if (max_na <= 16 * 14) return MM_F32(14, false);
@@ -464,8 +492,8 @@ static hipError_t launch_f64(const BatchDev& b, int max_na, int max_nbp, int gri
     const WorkItem* work = FROM_QUEUE ? b.items : b.work;
     const int* nd = FROM_QUEUE ? b.n_items : nullptr;
     const int nw = FROM_QUEUE ? 0 : b.n_work;
-#define MM_F64(Rv, NLIv, MRB) launch_one<double, Rv, NLIv, true, MRB>(b, work, nw, nd, grid, lds, b.ref64x, b.ref64y, \
-                                                                 b.tgt64x, b.tgt64y, b.cos64, b.sin64, b.sq64, s)
+#define MM_F64(Rv, NLIv, MRB) launch_one<double, Rv, NLIv, true, MRB>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, \
+                                                                 b.cos64, b.sin64, b.sq64, s)
     if (max_na <= 16 * 4) return MM_F64(4, 16, false);
     if (max_na <= 16 * 14) return MM_F64(14, 16, false);
     if (max_na <= 32 * 9) return MM_F64(9, 32, false);
@@ -499,7 +527,8 @@ hipError_t launch_finalize(const BatchDev& b, int use_flags, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_finalize, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.sq64, b.sq32,
-                       use_flags ? b.flag : nullptr, b.best_cost, b.best_idx, b.n_rescored, b.all_costs);
+                       use_flags ? b.flag : nullptr, b.best_cost, b.best_idx, b.n_rescored, b.near_cnt, b.near_idx,
+                       b.all_costs);
     return hipGetLastError();
 }
 

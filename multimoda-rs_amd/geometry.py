@@ -181,6 +181,47 @@ def align_within(engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: floa
     return logs, int(pe.value)
 
 
+class WithinPlan:
+    """Decoupled within-pullback alignment with the point sets staged in HBM up front
+    (``mm_within_plan_*``): ``WithinPlan(...)`` stages, ``run()`` searches + walks the chain.
+    Same results as :func:`align_within`; a plan runs once."""
+
+    def __init__(self, engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: float, range_deg: float,
+                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32):
+        self.engine = engine
+        self.geoms = list(geoms)
+        G = len(self.geoms)
+        self._structs = [g.c_struct() for g in self.geoms]
+        self._gptrs = (C.POINTER(N.MMGeometry) * G)(*[C.pointer(s) for s in self._structs])
+        self._h = C.c_void_p()
+        N.check(N.lib().mm_within_plan_create(engine.handle, G, C.cast(self._gptrs, C.c_void_p), float(step_deg),
+                                              float(range_deg), int(bool(bruteforce)), int(sample_size),
+                                              int(precision), C.byref(self._h)), "mm_within_plan_create")
+
+    def run(self):
+        """Returns (logs per geometry, pose_evals, n_unresolved)."""
+        G = len(self.geoms)
+        log_bufs = [(N.MMAlignLog * max(g.n_frames - 1, 1))() for g in self.geoms]
+        lptrs = (C.c_void_p * G)(*[C.cast(b, C.c_void_p) for b in log_bufs])
+        pe, nu = C.c_int64(0), C.c_int64(0)
+        N.check(N.lib().mm_within_plan_run(self._h, C.cast(lptrs, C.c_void_p), C.byref(pe), C.byref(nu)),
+                "mm_within_plan_run")
+        logs = [[(l.contour_id, l.matched_to, l.rot_deg, l.tx, l.ty, l.cx, l.cy) for l in b[: g.n_frames - 1]]
+                for b, g in zip(log_bufs, self.geoms)]
+        return logs, int(pe.value), int(nu.value)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            N.lib().mm_within_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def align_between(engine: N.Engine, pairs: Sequence[Sequence[FlatGeometry]], rot_deg: float, step_rot_deg: float,
                   sample_size: int, precision: int = N.MM_PRECISION_F32):
     """``align_between_geometries`` (align_between.rs:11-68) for independent (a, b) pairs; every

@@ -213,6 +213,48 @@ def test_chain_synthetic_bit_identical(engine, oracle, mm, bruteforce, step, rng
     assert evals > 0
 
 
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", [
+    (True, 1.0, 180.0, 501), (True, 0.5, 180.0, 500), (False, 0.5, 90.0, 500), (False, 0.05, 45.0, 200),
+    (False, 0.005, 20.0, 501), (True, 3.0, 45.0, 64)])
+def test_decoupled_mode_bit_identical_to_chain_oracle(engine, oracle, mm, bruteforce, step, rng_deg, ss):
+    """mode 1: all frame pairs screened in one launch on the ORIGINAL frames, then the exact
+    chain walk.  Logs and geometry must equal the oracle's sequential chain bit for bit."""
+    geoms = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((9, 6, 9, 7))]
+    ogeoms = [to_oracle(oracle, g) for g in geoms]
+    wp = mm.WithinPlan(engine, geoms, step, rng_deg, bruteforce, ss)
+    logs, evals, unresolved = wp.run()
+    wp.close()
+    total_ref_evals = 0
+    for g, og, lg in zip(geoms, ogeoms, logs):
+        ol = oracle.align_within_chain(og, step, rng_deg, bruteforce, ss, n_threads=8)
+        assert lg == ol
+        assert geoms_equal(g, og)
+    assert unresolved <= 2            # generic data: (almost) every step is resolved by the one-shot screen
+    if bruteforce:
+        n_ang = len(mm.search_angles(step, rng_deg)[0])
+        assert evals == n_ang * sum(g.n_frames - 1 for g in geoms)
+
+
+def test_decoupled_mode_symmetric_shapes_fall_back_to_chain_state(engine, oracle, mm):
+    """Perfect circles: every candidate ties up to rounding, so the one-shot screen cannot
+    decide and each step must be re-searched on the chain state -- still bit-identical."""
+    t = np.arange(120) * (2 * math.pi / 120)
+    lum = [np.stack([4.5 + 0.01 * k + 2 * np.cos(t), 4.4 + 2 * np.sin(t), np.full_like(t, 0.5 * k)], 1) for k in range(5)]
+    g = mm.FlatGeometry.from_frames(lum, ref_points={0: (6.5, 4.4, 0.0)})
+    og = to_oracle(oracle, g)
+    logs, _ = mm.align_within(engine, [g], 2.0, 60.0, True, 120, mode=1)
+    assert logs[0] == oracle.align_within_chain(og, 2.0, 60.0, True, 120)
+    assert geoms_equal(g, og)
+    # the reference's own dummy geometry through the decoupled path (align_within.rs:791-830)
+    g2 = mm.FlatGeometry.from_frames(**refgeom.to_arrays(refgeom.dummy_frames()))
+    og2 = to_oracle(oracle, g2)
+    logs2, _ = mm.align_within(engine, [g2], 0.01, 30.0, False, 6, mode=1)
+    assert logs2[0] == oracle.align_within_chain(og2, 0.01, 30.0, False, 6)
+    assert geoms_equal(g2, og2)
+    for (_, _, rot, *_r) in logs2[0]:
+        assert rot == pytest.approx(-15.0, abs=1e-6)
+
+
 def test_chain_validation_errors(engine, mm):
     g = mm.synthetic_pullback(3, 32)
     with pytest.raises(RuntimeError, match="sample_size must be > 0"):
