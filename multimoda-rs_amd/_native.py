@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -235,12 +236,15 @@ class Engine:
     """One HIP device + stream (``mm_engine``)."""
 
     def __init__(self, device: int = -1, stream: Optional[int] = None):
+        self._children = weakref.WeakSet()   # plans staged on this engine: closed before the engine
         self._h = C.c_void_p()
         check(lib().mm_engine_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)),
               "mm_engine_create")
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            for child in list(self._children):
+                child.close()
             lib().mm_engine_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -332,6 +336,7 @@ class Plan:
         self.engine = engine
         self.batch = batch
         self._h = C.c_void_p()
+        engine._children.add(self)
         check(lib().mm_plan_create(engine.handle, *batch._args(), precision, int(angle_begin), int(angle_end),
                                    C.byref(self._h)), "mm_plan_create")
 

