@@ -13,7 +13,23 @@
 
 #include "mm_engine.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace mm {
+
+// MM_TRACE=1: phase timings of the host orchestration on stderr (diagnostics only)
+static bool trace_on() { static const bool on = std::getenv("MM_TRACE") != nullptr; return on; }
+struct TraceTimer {
+    const char* what; std::chrono::steady_clock::time_point t0;
+    explicit TraceTimer(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~TraceTimer() {
+        if (trace_on())
+            std::fprintf(stderr, "[mm trace] %-28s %9.3f ms\n", what,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 static constexpr double kPi = 3.14159265358979323846264338327950288;
 
@@ -249,9 +265,14 @@ struct WithinPlan {
     std::vector<double> level0;               // shared candidate list of level 0
     bool level0_ok = false; double level0_early = 0.0;
     Plan plan;
-    bool staged = false;
+    bool staged = false, level0_staged = false;
+    std::vector<PairSpec> lvl_pairs;
+    std::vector<int> lvl_active;
+    std::vector<std::vector<double>> lists;   // per-job candidate lists of levels >= 1
 
     int prepare();
+    void build_level_pairs(size_t l, const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
+                           std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out);
     int search(std::vector<double>& centre, std::vector<uint8_t>& resolved, std::vector<int64_t>& evals);
     int walk(const std::vector<double>& centre, const std::vector<uint8_t>& resolved, const std::vector<int64_t>& evals,
              mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
@@ -303,47 +324,68 @@ int WithinPlan::prepare()
     for (size_t s = 0; s < sx.size(); ++s) sets[s] = SetRef{sx[s].data(), sy[s].data(), (int32_t)sx[s].size(), 0.0, 0.0};
     int rc = plan.stage_sets(e, sets, /*transient=*/false);
     if (rc) return rc;
+    // level 0 has no centre: its candidate list, descriptors and tables are known now
+    if (level0_ok) {
+        build_level_pairs(0, std::vector<double>(), std::vector<uint8_t>(job_geom.size(), 1), lvl_pairs, lvl_active, nullptr);
+        if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
+        level0_staged = true;
+    }
     staged = true;
     return MM_OK;
+}
+
+// PairSpecs of one level for the jobs that are still resolved; `lists` holds per-job
+// candidate lists for levels >= 1 (level 0 shares one list).
+void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
+                                   std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out)
+{
+    const int J = (int)job_geom.size();
+    pairs.clear(); active.clear();
+    if (l > 0 && (int)lists.size() != J) lists.assign(J, std::vector<double>());
+    for (int j = 0; j < J; ++j) {
+        if (!resolved[j]) continue;
+        const double* lp; int32_t ln;
+        if (l == 0) {
+            if (!level0_ok) { if (centre_out) (*centre_out)[j] = level0_early; continue; }
+            lp = level0.data(); ln = (int32_t)level0.size();
+        } else {
+            double early = 0.0;
+            if (!enumerate_angles(levels[l].step, levels[l].range, true, centre[j], range_deg, lists[j], early)) {
+                if (centre_out) (*centre_out)[j] = early;
+                continue;
+            }
+            lp = lists[j].data(); ln = (int32_t)lists[j].size();
+        }
+        const int g = job_geom[j], i = job_frame[j];
+        const int32_t sid = set_base[g] + i;
+        pairs.push_back(PairSpec{sid - 1, sid, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, lp, ln, 2.0 * eps[g], eps[g]});
+        active.push_back(j);
+    }
 }
 
 int WithinPlan::search(std::vector<double>& centre, std::vector<uint8_t>& resolved, std::vector<int64_t>& evals)
 {
     const int J = (int)job_geom.size();
     centre.assign(J, 0.0); resolved.assign(J, 1); evals.assign(J, 0);
-    std::vector<std::vector<double>> lists(J);
     for (size_t l = 0; l < levels.size(); ++l) {
-        std::vector<int> active;
-        std::vector<PairSpec> pairs;
-        for (int j = 0; j < J; ++j) {
-            if (!resolved[j]) continue;
-            const double* lp; int32_t ln;
-            if (l == 0) {
-                if (!level0_ok) { centre[j] = level0_early; continue; }
-                lp = level0.data(); ln = (int32_t)level0.size();
-            } else {
-                double early = 0.0;
-                if (!enumerate_angles(levels[l].step, levels[l].range, true, centre[j], range_deg, lists[j], early)) {
-                    centre[j] = early;
-                    continue;
-                }
-                lp = lists[j].data(); ln = (int32_t)lists[j].size();
-            }
-            const int g = job_geom[j], i = job_frame[j];
-            const int32_t sid = set_base[g] + i;
-            pairs.push_back(PairSpec{sid - 1, sid, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, lp, ln, 2.0 * eps[g], eps[g]});
-            active.push_back(j);
-            evals[j] += ln;
+        int rc;
+        if (!(l == 0 && level0_staged)) {
+            TraceTimer t("within: stage level");
+            build_level_pairs(l, centre, resolved, lvl_pairs, lvl_active, &centre);
+            if (lvl_active.empty()) continue;
+            if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
         }
-        if (active.empty()) continue;
-        int rc = plan.stage_level(pairs, precision, 0, INT32_MAX, false);
-        if (rc) return rc;
-        if ((rc = plan.run(false))) return rc;
+        if (lvl_active.empty()) continue;
         BatchResult res;
-        if ((rc = plan.fetch(res, nullptr))) return rc;
-        for (size_t k = 0; k < active.size(); ++k) {
-            const int j = active[k];
-            const double* lp = pairs[k].angles;
+        {
+            TraceTimer t("within: search kernels");
+            if ((rc = plan.run(false))) return rc;
+            if ((rc = plan.fetch(res, nullptr))) return rc;
+        }
+        for (size_t k = 0; k < lvl_active.size(); ++k) {
+            const int j = lvl_active[k];
+            const double* lp = lvl_pairs[k].angles;
+            evals[j] += lvl_pairs[k].n_angles;
             const int32_t n = res.near_cnt[k];
             bool ok = (n == 1);
             if (!ok && n >= 2 && n <= kMaxNear) {  // all near-ties are the same angle value?
@@ -361,6 +403,7 @@ int WithinPlan::search(std::vector<double>& centre, std::vector<uint8_t>& resolv
 int WithinPlan::walk(const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
                      const std::vector<int64_t>& evals, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
 {
+    TraceTimer tw("within: chain walk");
     std::vector<double> cumulative(n_geoms, 0.0);
     for (int32_t i = 1; i < max_frames; ++i) {
         std::vector<SearchJob> jobs;      // unresolved steps: searched on the chain state
@@ -602,6 +645,7 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     if (n_pairs <= 0 || !a || !b) return set_error(MM_ERR_INVALID, "no geometry pairs");
     if (pose_evals) *pose_evals = 0;
+    TraceTimer t0("between: total");
     std::vector<SearchJob> jobs(n_pairs);
     std::vector<std::array<double, 3>> a_ref(n_pairs);
     for (int p = 0; p < n_pairs; ++p) {
@@ -625,8 +669,13 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
         if (!job.rx.empty()) { job.cx = sx / (double)job.rx.size(); job.cy = sy / (double)job.rx.size(); }
         job.flags = 0;  // no angle==0 shortcut in this closure (:194-209)
     }
-    int rc = run_searches(e, jobs, step_rot_deg, rot_deg, /*bruteforce=*/false, precision, pose_evals);  // :46-47
+    int rc;
+    {
+        TraceTimer t("between: searches");
+        rc = run_searches(e, jobs, step_rot_deg, rot_deg, /*bruteforce=*/false, precision, pose_evals);  // :46-47
+    }
     if (rc) return rc;
+    TraceTimer t2("between: apply");
     for (int p = 0; p < n_pairs; ++p) {
         mm_geometry *A = a[p], *B = b[p];
         const double best = jobs[p].result;
