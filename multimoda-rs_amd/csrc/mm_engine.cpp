@@ -481,6 +481,12 @@ int mm_engine_profile(mm_engine* h, int enable)
     MM_HIP(hipStreamSynchronize(e->stream));
     e->profile = enable != 0;
     e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0;
+    // hipEventCreate is slow (~0.5 ms): build the pool now, outside any timed region
+    while (e->profile && e->events.size() < 2 * 2048) {
+        hipEvent_t ev;
+        MM_HIP(hipEventCreate(&ev));
+        e->events.push_back(ev);
+    }
     return MM_OK;
 }
 
