@@ -125,11 +125,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # MM_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (RCCL refuses
+    # two ranks on the same device); the driver's multi-GPU runs use nccl (= RCCL over xGMI)
+    backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = WORKLOADS[args.workload]
     mode = 0 if args.mode == "chain" else 1
@@ -139,34 +145,35 @@ def main():
     # Every step works on a fresh copy of the case.  In decoupled mode the copies are staged
     # into HBM (mm.WithinPlan) before the timed region: inputs resident, as the contract asks;
     # the staging-inclusive rate is reported separately.
-    # N > 1 (interim): pullbacks are independent chains, rank r owns pullbacks r, r+N, ...
+    # N > 1: the candidate axis is sharded -- rank r scores candidates [n*r/N, n*(r+1)/N) of
+    # every frame pair; per-shard bests are exchanged over RCCL (multimoda_rs_amd.distributed)
+    # and every rank then walks the chain and runs the small between stage (strong scaling).
+    if world > 1 and mode != 1:
+        raise SystemExit("--gpus N > 1 shards the decoupled search; use --mode decoupled")
     n_total = args.warmup + args.steps
     t_stage0 = time.perf_counter()
     cases, plans = [], []
     for _ in range(n_total):
         geoms = [g.copy() for g in base]
-        mine = geoms if world == 1 else [geoms[i] for i in range(4) if i % world == rank]
-        cases.append((geoms, mine))
-        plans.append(mm.WithinPlan(eng, mine, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"])
-                     if (mode == 1 and mine) else None)
+        cases.append(geoms)
+        plan = None
+        if mode == 1:
+            plan = mm.WithinPlan(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"])
+            if world > 1:
+                plan.set_shard(rank, world)
+        plans.append(plan)
     eng.synchronize()
     t_stage = (time.perf_counter() - t_stage0) / n_total
     it = iter(range(n_total))
 
     def one_step():
         k = next(it)
-        geoms, mine = cases[k]
+        geoms = cases[k]
         if world == 1:
             return full_alignment(mm, eng, geoms, cfg, plans[k])
-        if not mine:
-            return [], None, 0, 0
-        if plans[k] is not None:
-            logs, evals, unres = plans[k].run()
-        else:
-            logs, evals = mm.align_within(eng, mine, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                                          precision=mm.MM_PRECISION_F32, mode=0)
-            unres = 0
-        return logs, None, evals, unres
+        logs, evals, unres = plans[k].run_sharded()
+        rot, e2 = between_stage(mm, eng, geoms, cfg)
+        return logs, rot, evals + e2, unres
 
     def barrier():
         if world > 1:
@@ -200,12 +207,10 @@ def main():
     eng.profile(False)
 
     if world > 1:
-        t = torch.tensor([dt, float(evals)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(evals)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0].item())
-        evals = int(t[1].item())
+        dt = float(tmax[0].item())     # max over ranks; every rank holds the same whole-job pose-eval count
 
     if rank == 0:
         na = nb = cfg["sample_size"] + 20
@@ -230,7 +235,7 @@ def main():
                                    f"bruteforce grid", "mode": args.mode, "pose_evals_per_step": evals // max(args.steps, 1),
                        "chain_steps_researched_on_chain_state": unresolved,
                        "value_incl_host_staging": evals / (dt + t_stage * args.steps),
-                       "parallelism": f"{'pullback' if world > 1 else 'single'}-sharded x{world}"},
+                       "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU"},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,

@@ -209,6 +209,30 @@ int  mm_within_plan_run(mm_within_plan* p, mm_alignlog** logs, int64_t* pose_eva
                         int64_t* n_unresolved);
 void mm_within_plan_destroy(mm_within_plan* p);
 
+/* The same search with the candidate axis sharded over `world` ranks (one process per GPU).
+ * run() == for every level { level_local; merge over ranks; level_commit }; walk.  Between
+ * level_local and level_commit the caller exchanges the per-job arrays between ranks
+ * (torch.distributed all_gather over RCCL/xGMI) and merges them with mm_merge_shards, which
+ * is host-only and also serves world == 1.  Every rank then holds the same winners and walks
+ * the chain redundantly (deterministic host f64).
+ *   set_shard    before the first level: this rank's share of every candidate list is
+ *                [n*rank/world, n*(rank+1)/world)
+ *   dims         number of jobs (frame pairs, all pullbacks), levels, and per-job tie tolerance
+ *   level_local  arrays of n_jobs: exact first minimum inside the slice (cost, idx, angle),
+ *                uniform = all near-ties of the slice are one angle value, active = takes part
+ *   level_commit ok[j] != 0 -> winner `angle[j]`; 0 -> re-searched on the chain state in walk */
+int  mm_within_plan_set_shard(mm_within_plan* p, int rank, int world);
+int  mm_within_plan_dims(mm_within_plan* p, int32_t* n_jobs, int32_t* n_levels, double* tol);
+int  mm_within_plan_level_local(mm_within_plan* p, int level, double* cost, int32_t* uniform,
+                                double* angle, int32_t* idx, int32_t* active);
+int  mm_within_plan_level_commit(mm_within_plan* p, int level, const uint8_t* ok, const double* angle);
+int  mm_within_plan_walk(mm_within_plan* p, mm_alignlog** logs, int64_t* pose_evals,
+                         int64_t* n_unresolved);
+/* arrays cost/uniform/angle/idx are [world][n] rank-major; tol [n] (nullable); outputs [n] */
+int  mm_merge_shards(int world, int n, const double* cost, const int32_t* uniform,
+                     const double* angle, const int32_t* idx, const double* tol,
+                     uint8_t* ok, double* out_angle, int32_t* out_idx, double* out_cost);
+
 /* align_between_geometries (align_between.rs:11-68) for n_pairs independent (a,b) pairs
  * (entry.rs:206-277 runs two at a time); b is moved onto a.  best_rotation[p] receives
  * the searched angle (radians). */

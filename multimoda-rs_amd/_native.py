@@ -26,7 +26,9 @@ EXPORTS = [
     "mm_hausdorff_2d", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
-    "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy", "mm_catheter_lumen_vec", "mm_extract_between_points",
+    "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy",
+    "mm_within_plan_set_shard", "mm_within_plan_dims", "mm_within_plan_level_local", "mm_within_plan_level_commit",
+    "mm_within_plan_walk", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
     "mm_frame_translate", "mm_frame_rotate",
 ]
 
@@ -128,6 +130,18 @@ def lib():
     L.mm_within_plan_run.argtypes = [P, P, C.POINTER(I64), C.POINTER(I64)]
     L.mm_within_plan_destroy.restype = None
     L.mm_within_plan_destroy.argtypes = [P]
+    L.mm_within_plan_set_shard.restype = I
+    L.mm_within_plan_set_shard.argtypes = [P, I, I]
+    L.mm_within_plan_dims.restype = I
+    L.mm_within_plan_dims.argtypes = [P, C.POINTER(I32), C.POINTER(I32), P]
+    L.mm_within_plan_level_local.restype = I
+    L.mm_within_plan_level_local.argtypes = [P, I, P, P, P, P, P]
+    L.mm_within_plan_level_commit.restype = I
+    L.mm_within_plan_level_commit.argtypes = [P, I, P, P]
+    L.mm_within_plan_walk.restype = I
+    L.mm_within_plan_walk.argtypes = [P, P, C.POINTER(I64), C.POINTER(I64)]
+    L.mm_merge_shards.restype = I
+    L.mm_merge_shards.argtypes = [I, I, P, P, P, P, P, P, P, P, P]
     L.mm_align_between.restype = I
     L.mm_align_between.argtypes = [P, I, P, P, D, D, I64, I, P, C.POINTER(I64)]
     L.mm_catheter_lumen_vec.restype = I64

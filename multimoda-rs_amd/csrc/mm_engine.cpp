@@ -163,6 +163,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
 
     host_pairs.assign(P, PairDesc{});
     trivial.assign(P, 0);
+    pair_slice_end.assign(P, 0);
     host_tables.clear();
     A = 0; T = 0;
     max_na = 1; max_nbp = 16;
@@ -175,8 +176,10 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
             return set_error(MM_ERR_INVALID, "pair references a set that was not staged");
         if (sp.n_angles < 0) return set_error(MM_ERR_INVALID, "negative candidate count");
         const int32_t nr = set_len[sp.ref_set], nt = set_len[sp.tgt_set];
-        const int32_t b = std::min(angle_begin, sp.n_angles), en = std::min(angle_end, sp.n_angles);
+        const int32_t b = std::min(std::max(angle_begin, sp.slice_begin), sp.n_angles);
+        const int32_t en = std::min(std::min(angle_end, sp.slice_end), sp.n_angles);
         const int32_t na = std::max(en - b, 0);
+        pair_slice_end[p] = std::max(en, b);
         PairDesc& d = host_pairs[p];
         d.ref_off = set_off[sp.ref_set]; d.n_ref = nr;
         d.tgt_off = set_off[sp.tgt_set]; d.n_tgt = nt;
@@ -336,7 +339,7 @@ int Plan::fetch(BatchResult& out, double* all_costs_plan_order)
         const PairDesc& d = host_pairs[p];
         if (trivial[p]) {
             // every candidate costs 0.0; the ordered first minimum is the first candidate of the slice
-            if (d.ang_begin < slice_hi(d)) {
+            if (d.ang_begin < slice_hi(p)) {
                 out.best_idx[p] = d.ang_begin; out.best_cost[p] = 0.0;
                 out.near_cnt[p] = 1; out.near_idx[(size_t)p * kMaxNear] = d.ang_begin;
             }
@@ -402,7 +405,7 @@ static void scatter_costs(const Plan& plan, const double* plan_costs, const int6
         const PairDesc& d = plan.host_pairs[p];
         double* dst = all_costs + ang_off[p] + d.ang_begin;
         if (plan.trivial[p]) {
-            const int32_t n = std::max(0, plan.slice_hi(d) - d.ang_begin);
+            const int32_t n = std::max(0, plan.slice_hi(p) - d.ang_begin);
             for (int32_t a = 0; a < n; ++a) dst[a] = 0.0;
         } else if (d.n_ang > 0) {
             std::memcpy(dst, plan_costs + d.out_off, (size_t)d.n_ang * 8);

@@ -48,6 +48,7 @@ struct PairSpec {          // one search
     const double* angles; int32_t n_angles;   // candidate list (pairs passing the same pointer share tables)
     double tie_tol;                // near-tie tolerance on the exact cost (0 -> exact ties only)
     double delta_extra;            // added to the f32 screening bound
+    int32_t slice_begin = 0, slice_end = INT32_MAX;   // this pair's share of the candidate axis
 };
 struct BatchResult {
     std::vector<int32_t> best_idx, n_rescored, near_cnt, near_idx;  // near_idx: kMaxNear per pair
@@ -89,7 +90,8 @@ struct Plan {
     int run(bool screen_only);
     int fetch(BatchResult& out, double* all_costs_plan_order);
     size_t hbm_bytes() const { return pts_bytes + lvl_bytes; }
-    int32_t slice_hi(const PairDesc& d) const { return d.ang_full < slice_end ? d.ang_full : slice_end; }
+    std::vector<int32_t> pair_slice_end;      // per pair: end of the candidate slice this plan owns
+    int32_t slice_hi(int p) const { return pair_slice_end[(size_t)p]; }
     double angle_of(int p, int32_t idx) const;
     ~Plan();
 };

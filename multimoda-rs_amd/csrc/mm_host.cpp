@@ -270,12 +270,20 @@ struct WithinPlan {
     std::vector<int> lvl_active;
     std::vector<std::vector<double>> lists;   // per-job candidate lists of levels >= 1
 
+    // search state (persists across the level_local / commit calls)
+    std::vector<double> centre;
+    std::vector<uint8_t> resolved;
+    std::vector<int64_t> evals;
+    int rank = 0, world = 1;          // this plan's share of the candidate axis
+    bool searched = false;
+
     int prepare();
+    int level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
+    int level_commit(size_t l, const uint8_t* ok, const double* angle);
     void build_level_pairs(size_t l, const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
                            std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out);
-    int search(std::vector<double>& centre, std::vector<uint8_t>& resolved, std::vector<int64_t>& evals);
-    int walk(const std::vector<double>& centre, const std::vector<uint8_t>& resolved, const std::vector<int64_t>& evals,
-             mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
+    int search();
+    int walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
 };
 
 int WithinPlan::prepare()
@@ -358,51 +366,91 @@ void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centre, 
         }
         const int g = job_geom[j], i = job_frame[j];
         const int32_t sid = set_base[g] + i;
-        pairs.push_back(PairSpec{sid - 1, sid, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, lp, ln, 2.0 * eps[g], eps[g]});
+        PairSpec sp{sid - 1, sid, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, lp, ln, 2.0 * eps[g], eps[g]};
+        sp.slice_begin = (int32_t)((int64_t)ln * rank / world);          // this rank's share of the
+        sp.slice_end = (int32_t)((int64_t)ln * (rank + 1) / world);      // candidate axis
+        pairs.push_back(sp);
         active.push_back(j);
     }
 }
 
-int WithinPlan::search(std::vector<double>& centre, std::vector<uint8_t>& resolved, std::vector<int64_t>& evals)
+// One level over this rank's candidate slice.  Per job (n_jobs entries): active = the job
+// takes part in this level; cost/idx/angle = exact first minimum inside the slice (+inf/-1
+// if the slice is empty); uniform = every candidate of the slice within the tie tolerance
+// of that minimum is the same angle value.
+int WithinPlan::level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active)
 {
     const int J = (int)job_geom.size();
-    centre.assign(J, 0.0); resolved.assign(J, 1); evals.assign(J, 0);
-    for (size_t l = 0; l < levels.size(); ++l) {
-        int rc;
-        if (!(l == 0 && level0_staged)) {
-            TraceTimer t("within: stage level");
-            build_level_pairs(l, centre, resolved, lvl_pairs, lvl_active, &centre);
-            if (lvl_active.empty()) continue;
-            if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
+    if (l == 0) { centre.assign(J, 0.0); resolved.assign(J, 1); evals.assign(J, 0); searched = true; }
+    for (int j = 0; j < J; ++j) { cost[j] = INFINITY; uniform[j] = 1; angle[j] = 0.0; idx[j] = -1; active[j] = 0; }
+    int rc;
+    if (!(l == 0 && level0_staged)) {
+        TraceTimer t("within: stage level");
+        build_level_pairs(l, centre, resolved, lvl_pairs, lvl_active, &centre);
+        if (lvl_active.empty()) return MM_OK;
+        if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
+    }
+    if (lvl_active.empty()) return MM_OK;
+    BatchResult res;
+    {
+        TraceTimer t("within: search kernels");
+        if ((rc = plan.run(false))) return rc;
+        if ((rc = plan.fetch(res, nullptr))) return rc;
+    }
+    for (size_t k = 0; k < lvl_active.size(); ++k) {
+        const int j = lvl_active[k];
+        const double* lp = lvl_pairs[k].angles;
+        active[j] = 1;
+        if (res.best_idx[k] < 0) continue;  // empty slice
+        cost[j] = res.best_cost[k]; idx[j] = res.best_idx[k]; angle[j] = lp[res.best_idx[k]];
+        const int32_t n = res.near_cnt[k];
+        bool ok = (n == 1);
+        if (!ok && n >= 2 && n <= kMaxNear) {
+            ok = true;
+            const double a0 = lp[res.near_idx[k * kMaxNear]];
+            for (int q = 1; q < n; ++q) ok = ok && (std::memcmp(&a0, &lp[res.near_idx[k * kMaxNear + q]], 8) == 0);
         }
-        if (lvl_active.empty()) continue;
-        BatchResult res;
-        {
-            TraceTimer t("within: search kernels");
-            if ((rc = plan.run(false))) return rc;
-            if ((rc = plan.fetch(res, nullptr))) return rc;
-        }
-        for (size_t k = 0; k < lvl_active.size(); ++k) {
-            const int j = lvl_active[k];
-            const double* lp = lvl_pairs[k].angles;
-            evals[j] += lvl_pairs[k].n_angles;
-            const int32_t n = res.near_cnt[k];
-            bool ok = (n == 1);
-            if (!ok && n >= 2 && n <= kMaxNear) {  // all near-ties are the same angle value?
-                ok = true;
-                const double a0 = lp[res.near_idx[k * kMaxNear]];
-                for (int q = 1; q < n; ++q) ok = ok && (std::memcmp(&a0, &lp[res.near_idx[k * kMaxNear + q]], 8) == 0);
-            }
-            if (ok) centre[j] = lp[res.best_idx[k]];
-            else resolved[j] = 0;  // decided on the chain state in walk()
-        }
+        uniform[j] = ok ? 1 : 0;
     }
     return MM_OK;
 }
 
-int WithinPlan::walk(const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
-                     const std::vector<int64_t>& evals, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
+// Record the merged (all ranks) outcome of level l: ok[j] != 0 -> the level's winner is
+// `angle[j]`; ok[j] == 0 -> the step is re-searched on the chain state during the walk.
+int WithinPlan::level_commit(size_t l, const uint8_t* ok, const double* angle)
 {
+    if (!searched) return set_error(MM_ERR_INVALID, "level_commit before level_local");
+    for (size_t k = 0; k < lvl_active.size(); ++k) {
+        const int j = lvl_active[k];
+        evals[j] += lvl_pairs[k].n_angles;
+        if (ok[j]) centre[j] = angle[j];
+        else resolved[j] = 0;
+    }
+    (void)l;
+    return MM_OK;
+}
+
+int WithinPlan::search()
+{
+    const int J = (int)job_geom.size();
+    std::vector<double> cost(J), angle(J), tol(J), out_angle(J), out_cost(J);
+    std::vector<int32_t> uniform(J), idx(J), active(J), out_idx(J);
+    std::vector<uint8_t> ok(J);
+    for (int j = 0; j < J; ++j) tol[j] = 2.0 * eps[job_geom[j]];
+    for (size_t l = 0; l < levels.size(); ++l) {
+        int rc = level_local(l, cost.data(), uniform.data(), angle.data(), idx.data(), active.data());
+        if (rc) return rc;
+        if ((rc = mm_merge_shards(1, J, cost.data(), uniform.data(), angle.data(), idx.data(), tol.data(), ok.data(),
+                                  out_angle.data(), out_idx.data(), out_cost.data())))
+            return rc;
+        if ((rc = level_commit(l, ok.data(), out_angle.data()))) return rc;
+    }
+    return MM_OK;
+}
+
+int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
+{
+    if (!searched) return set_error(MM_ERR_INVALID, "walk before the search levels were run");
     TraceTimer tw("within: chain walk");
     std::vector<double> cumulative(n_geoms, 0.0);
     for (int32_t i = 1; i < max_frames; ++i) {
@@ -622,10 +670,91 @@ int mm_within_plan_run(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_eval
     if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
     if (pose_evals) *pose_evals = 0;
     if (n_unresolved) *n_unresolved = 0;
-    std::vector<double> centre; std::vector<uint8_t> resolved; std::vector<int64_t> evals;
-    int rc = wp->search(centre, resolved, evals);
+    int rc = wp->search();
     if (rc) return rc;
-    return wp->walk(centre, resolved, evals, logs, pose_evals, n_unresolved);
+    return wp->walk(logs, pose_evals, n_unresolved);
+}
+
+int mm_within_plan_set_shard(mm_within_plan* h, int rank, int world)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || world <= 0 || rank < 0 || rank >= world) return set_error(MM_ERR_INVALID, "bad shard");
+    if (wp->searched) return set_error(MM_ERR_INVALID, "shard must be set before the first level");
+    if (rank != wp->rank || world != wp->world) {
+        wp->rank = rank; wp->world = world; wp->level0_staged = false;
+        if (wp->level0_ok) {  // re-stage level 0 for the new slice now, not inside the search
+            wp->build_level_pairs(0, std::vector<double>(), std::vector<uint8_t>(wp->job_geom.size(), 1), wp->lvl_pairs,
+                                  wp->lvl_active, nullptr);
+            int rc = wp->plan.stage_level(wp->lvl_pairs, wp->precision, 0, INT32_MAX, false);
+            if (rc) return rc;
+            wp->level0_staged = true;
+        }
+    }
+    return MM_OK;
+}
+
+int mm_within_plan_dims(mm_within_plan* h, int32_t* n_jobs, int32_t* n_levels, double* tol)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
+    const int J = (int)wp->job_geom.size();
+    if (n_jobs) *n_jobs = J;
+    if (n_levels) *n_levels = (int32_t)wp->levels.size();
+    if (tol) for (int j = 0; j < J; ++j) tol[j] = 2.0 * wp->eps[wp->job_geom[j]];
+    return MM_OK;
+}
+
+int mm_within_plan_level_local(mm_within_plan* h, int level, double* cost, int32_t* uniform, double* angle,
+                               int32_t* idx, int32_t* active)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
+    return wp->level_local((size_t)level, cost, uniform, angle, idx, active);
+}
+
+int mm_within_plan_level_commit(mm_within_plan* h, int level, const uint8_t* ok, const double* angle)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
+    return wp->level_commit((size_t)level, ok, angle);
+}
+
+int mm_within_plan_walk(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
+    if (pose_evals) *pose_evals = 0;
+    if (n_unresolved) *n_unresolved = 0;
+    return wp->walk(logs, pose_evals, n_unresolved);
+}
+
+// Merge per-shard results of `world` ranks (arrays are [world][n], rank-major).  For job j
+// the winner is the first index of minimal cost over the whole candidate axis; ok[j] = the
+// winner is decided, i.e. every shard whose minimum lies within tol[j] of the global minimum
+// reports a uniform near-set and all those shards agree on the angle value bit for bit.
+int mm_merge_shards(int world, int n, const double* cost, const int32_t* uniform, const double* angle,
+                    const int32_t* idx, const double* tol, uint8_t* ok, double* out_angle, int32_t* out_idx,
+                    double* out_cost)
+{
+    if (world <= 0 || n < 0) return set_error(MM_ERR_INVALID, "mm_merge_shards: bad sizes");
+    for (int j = 0; j < n; ++j) {
+        double gbest = INFINITY;
+        for (int r = 0; r < world; ++r) gbest = std::fmin(gbest, cost[(size_t)r * n + j]);
+        ok[j] = 1; out_angle[j] = 0.0; out_idx[j] = -1; out_cost[j] = gbest;
+        if (!(gbest < INFINITY)) continue;  // no shard had a candidate
+        // first index of minimal cost (process_utils.rs:72), shards own increasing index ranges
+        for (int r = 0; r < world; ++r) {
+            const size_t k = (size_t)r * n + j;
+            if (cost[k] == gbest && (out_idx[j] < 0 || idx[k] < out_idx[j])) { out_idx[j] = idx[k]; out_angle[j] = angle[k]; }
+        }
+        const double thr = gbest + (tol ? tol[j] : 0.0);
+        for (int r = 0; r < world; ++r) {
+            const size_t k = (size_t)r * n + j;
+            if (idx[k] < 0 || !(cost[k] <= thr)) continue;
+            if (!uniform[k] || std::memcmp(&angle[k], &out_angle[j], 8) != 0) ok[j] = 0;
+        }
+    }
+    return MM_OK;
 }
 
 void mm_within_plan_destroy(mm_within_plan* h)

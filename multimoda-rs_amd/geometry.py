@@ -211,6 +211,55 @@ class WithinPlan:
                 for b, g in zip(log_bufs, self.geoms)]
         return logs, int(pe.value), int(nu.value)
 
+    # -- candidate axis sharded over ranks (one process per GPU) ---------------------------
+    def set_shard(self, rank: int, world: int):
+        N.check(N.lib().mm_within_plan_set_shard(self._h, int(rank), int(world)), "mm_within_plan_set_shard")
+
+    def dims(self):
+        """(n_jobs, n_levels, per-job tie tolerance)."""
+        nj, nl = C.c_int32(0), C.c_int32(0)
+        N.check(N.lib().mm_within_plan_dims(self._h, C.byref(nj), C.byref(nl), None), "mm_within_plan_dims")
+        tol = np.zeros(nj.value, dtype=np.float64)
+        N.check(N.lib().mm_within_plan_dims(self._h, None, None, N._ptr(tol)), "mm_within_plan_dims")
+        return int(nj.value), int(nl.value), tol
+
+    def level_local(self, level: int, n_jobs: int):
+        out = {"cost": np.zeros(n_jobs), "uniform": np.zeros(n_jobs, dtype=np.int32), "angle": np.zeros(n_jobs),
+               "idx": np.zeros(n_jobs, dtype=np.int32), "active": np.zeros(n_jobs, dtype=np.int32)}
+        N.check(N.lib().mm_within_plan_level_local(self._h, int(level), N._ptr(out["cost"]), N._ptr(out["uniform"]),
+                                                   N._ptr(out["angle"]), N._ptr(out["idx"]), N._ptr(out["active"])),
+                "mm_within_plan_level_local")
+        return out
+
+    def level_commit(self, level: int, ok: np.ndarray, angle: np.ndarray):
+        ok = np.ascontiguousarray(ok, dtype=np.uint8)
+        angle = np.ascontiguousarray(angle, dtype=np.float64)
+        N.check(N.lib().mm_within_plan_level_commit(self._h, int(level), N._ptr(ok), N._ptr(angle)),
+                "mm_within_plan_level_commit")
+
+    def walk(self):
+        G = len(self.geoms)
+        log_bufs = [(N.MMAlignLog * max(g.n_frames - 1, 1))() for g in self.geoms]
+        lptrs = (C.c_void_p * G)(*[C.cast(b, C.c_void_p) for b in log_bufs])
+        pe, nu = C.c_int64(0), C.c_int64(0)
+        N.check(N.lib().mm_within_plan_walk(self._h, C.cast(lptrs, C.c_void_p), C.byref(pe), C.byref(nu)),
+                "mm_within_plan_walk")
+        logs = [[(l.contour_id, l.matched_to, l.rot_deg, l.tx, l.ty, l.cx, l.cy) for l in b[: g.n_frames - 1]]
+                for b, g in zip(log_bufs, self.geoms)]
+        return logs, int(pe.value), int(nu.value)
+
+    def run_sharded(self, group=None):
+        """run() with the candidate axis sharded over the ranks of a torch.distributed group
+        (set_shard must have been called): per level, local search -> exchange -> merge ->
+        commit; then every rank walks the chain.  Same return value as run()."""
+        from . import distributed as D
+        n_jobs, n_levels, tol = self.dims()
+        for l in range(n_levels):
+            local = self.level_local(l, n_jobs)
+            ok, angle, _idx, _cost = D.merge_level(local, tol, group)
+            self.level_commit(l, ok, angle)
+        return self.walk()
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             N.lib().mm_within_plan_destroy(self._h)
