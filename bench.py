@@ -8,8 +8,10 @@ A "step" is one full 4-phase alignment of a synthetic case (4 pullbacks x F fram
 points, N = 521 points per set): 4 within-pullback chains (bruteforce) and the AB|CD,
 AC|BD between-pullback alignments, all through the product's C ABI.  Workloads
 (SURVEY.md section 8(d)):
-  config2: F = 128, step 1 deg,  range 180 deg -> 361 candidates/search (default)
-  config3: F = 512, step 0.5 deg, range 180 deg -> 721 candidates/search
+  config2: F = 128, step 1 deg,  range 180 deg -> 361 candidates/search
+  config3: F = 512, step 0.5 deg, range 180 deg -> 721 candidates/search (default: the
+           512-frame x 501-pt case BASELINE.json's targets are quoted on, and the one its
+           multi-GPU config shards)
 
 Usage: python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0.
@@ -99,9 +101,9 @@ def cpu_baseline(cfg, geoms, threads, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -263,6 +265,16 @@ def main():
             out["check"] = {"pullback0_logs_identical": bool(res[0][0] == ol)}
         print(json.dumps(out))
     if world > 1:
+        # every rank must have produced the same alignment (merged winners -> identical host walk)
+        import hashlib
+        digest = hashlib.sha256(repr((res[0], None if res[1] is None else res[1].tolist())).encode()).digest()[:8]
+        t = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(torch.int64)
+        t = t.cuda() if backend == "nccl" else t
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit("ranks disagree on the alignment result")
         dist.destroy_process_group()
     eng.close()
 

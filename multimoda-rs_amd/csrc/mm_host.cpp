@@ -14,6 +14,7 @@
 #include "mm_engine.h"
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 
@@ -452,6 +453,40 @@ int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresol
 {
     if (!searched) return set_error(MM_ERR_INVALID, "walk before the search levels were run");
     TraceTimer tw("within: chain walk");
+    // Fast path: every step was decided by the one-shot search -> the pullbacks are
+    // independent pure-host chains; walk them concurrently, one thread per pullback, like the
+    // reference's crossbeam scope (entry.rs:140-203).
+    bool all_resolved = true;
+    for (uint8_t r : resolved) all_resolved = all_resolved && (r != 0);
+    if (all_resolved) {
+        auto walk_one = [&](int g) {
+            mm_geometry* G = geoms[g];
+            double cumulative = 0.0;
+            for (int32_t i = 1; i < G->n_frames; ++i) {
+                const double pcx = G->centroid[3 * (i - 1)], pcy = G->centroid[3 * (i - 1) + 1];
+                if (cumulative != 0.0)  // align_within.rs:79-82
+                    mm_frame_rotate(G, i, cumulative, G->centroid[3 * i], G->centroid[3 * i + 1]);
+                const double tx = pcx - G->centroid[3 * i], ty = pcy - G->centroid[3 * i + 1];  // :84-88
+                mm_frame_translate(G, i, tx, ty, 0.0);                                            // :90
+                const double cx = G->centroid[3 * i], cy = G->centroid[3 * i + 1];
+                const double best = centre[job_base[g] + (i - 1)];
+                mm_frame_rotate(G, i, best, cx, cy);  // :121-122
+                cumulative += best;                   // :123
+                if (logs && logs[g]) {
+                    mm_alignlog& L = logs[g][i - 1];
+                    L.contour_id = G->id[i]; L.matched_to = G->id[i - 1];
+                    L.rot_deg = rad2deg(best); L.tx = tx; L.ty = ty;
+                    L.cx = G->centroid[3 * i]; L.cy = G->centroid[3 * i + 1];
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int g = 1; g < n_geoms; ++g) th.emplace_back(walk_one, g);
+        walk_one(0);
+        for (std::thread& t : th) t.join();
+        if (pose_evals) for (int64_t v : evals) *pose_evals += v;
+        return MM_OK;
+    }
     std::vector<double> cumulative(n_geoms, 0.0);
     for (int32_t i = 1; i < max_frames; ++i) {
         std::vector<SearchJob> jobs;      // unresolved steps: searched on the chain state
@@ -783,6 +818,11 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
         const size_t ia = ref_or_proximal(A), ib = ref_or_proximal(B);  // :19-24
         if (ia >= (size_t)A->n_frames || ib >= (size_t)B->n_frames)
             return set_error(MM_ERR_REF_INDEX, "reference frame index out of range");
+    }
+    // the pairs are independent (the reference runs them in a crossbeam scope, entry.rs:206-277)
+    auto prep = [&](int p) {
+        mm_geometry *A = a[p], *B = b[p];
+        const size_t ia = ref_or_proximal(A), ib = ref_or_proximal(B);
         a_ref[p] = {A->centroid[3 * ia], A->centroid[3 * ia + 1], A->centroid[3 * ia + 2]};
         const double dx = a_ref[p][0] - B->centroid[3 * ib], dy = a_ref[p][1] - B->centroid[3 * ib + 1],
                      dz = a_ref[p][2] - B->centroid[3 * ib + 2];                    // :33-37
@@ -797,6 +837,12 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
         for (double v : job.ry) sy += v;
         if (!job.rx.empty()) { job.cx = sx / (double)job.rx.size(); job.cy = sy / (double)job.rx.size(); }
         job.flags = 0;  // no angle==0 shortcut in this closure (:194-209)
+    };
+    {
+        std::vector<std::thread> th;
+        for (int p = 1; p < n_pairs; ++p) th.emplace_back(prep, p);
+        prep(0);
+        for (std::thread& t : th) t.join();
     }
     int rc;
     {
@@ -805,7 +851,7 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
     }
     if (rc) return rc;
     TraceTimer t2("between: apply");
-    for (int p = 0; p < n_pairs; ++p) {
+    auto apply = [&](int p) {
         mm_geometry *A = a[p], *B = b[p];
         const double best = jobs[p].result;
         // :95-145 rotate the whole of B about A's reference-frame centroid (no shortcut)
@@ -828,6 +874,12 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
                      fz = A->centroid[3 * ia + 2] - B->centroid[3 * ib + 2];  // :60-66
         for (int32_t i = 0; i < B->n_frames; ++i) mm_frame_translate(B, i, fx, fy, fz);  // :68
         if (best_rotation) best_rotation[p] = best;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int p = 1; p < n_pairs; ++p) th.emplace_back(apply, p);
+        apply(0);
+        for (std::thread& t : th) t.join();
     }
     return MM_OK;
 }
