@@ -85,6 +85,27 @@ int mm_hausdorff_2d(mm_engine* e,
                     const double* bx, const double* by, int nb,
                     double* out);
 
+/* Batched metric: out[p] = hausdorff_distance(A_p, B_p), f64-exact.  This is the call at
+ * centerline_align/align_algorithms.rs:431 for every (index, angle) candidate of
+ * refine_alignment_hausdorff at once.  first_min (nullable) receives the index of the first
+ * strict minimum (`if hausdorff_dist < min_hausdorff`, :433-437; candidates are in the
+ * caller's enumeration order), -1 if n_pairs == 0. */
+int mm_hausdorff_batch(mm_engine* e, int n_pairs,
+                       const int64_t* a_off, const double* ax, const double* ay,
+                       const int64_t* b_off, const double* bx, const double* by,
+                       double* out, int32_t* first_min);
+
+/* Host helpers of refine_alignment_hausdorff (align_algorithms.rs:339-451), exact:
+ *   mm_refine_angles            `angle = init - range; while angle <= init + range { ..; angle += step }`
+ *                               (accumulated, :386-387,439); returns the count
+ *   mm_filter_points_in_region  indices of the points inside the +-5 mm box around two
+ *                               centerline points (:454-505); xyz triples
+ *   mm_refine_downsample_count  clamp(ceil(|filtered| / (M*F) * M), 1, M)  (:415-418)        */
+int64_t mm_refine_angles(double initial, double range, double step, double* out, int64_t cap);
+int64_t mm_filter_points_in_region(const double* xyz, int64_t n, const double* start_xyz,
+                                   const double* end_xyz, int64_t* out_idx, int64_t cap);
+int64_t mm_refine_downsample_count(int64_t n_filtered, int64_t n_points_per_frame, int64_t n_frames);
+
 /* ---- candidate enumeration of search_range (process_utils.rs:43-67) ---------------- */
 /* Host-side, exact: writes up to `cap` wrapped angles, returns their count. When the
  * reference returns early (step <= 0, or stop <= start) *degenerate = 1 and

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 from . import _native
 from ._native import (MM_PRECISION_F32, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine, Plan,
-                      device_count, search_angles)
+                      device_count, filter_points_in_region, refine_angles, refine_downsample_count, search_angles)
 from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
                        contour_centroid, search_set)
 from .synth import synthetic_case, synthetic_pullback
@@ -19,7 +19,8 @@ from .synth import synthetic_case, synthetic_pullback
 __version__ = "0.1.0"
 
 __all__ = [
-    "Engine", "Batch", "Plan", "FlatGeometry", "device_count", "search_angles",
+    "Engine", "Batch", "Plan", "FlatGeometry", "device_count", "search_angles", "refine_angles",
+    "filter_points_in_region", "refine_downsample_count",
     "align_within", "align_between", "WithinPlan", "search_set", "between_points",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",

@@ -23,7 +23,8 @@ EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
     "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream",
     "mm_engine_profile", "mm_engine_profile_read",
-    "mm_hausdorff_2d", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
+    "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
+    "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
     "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy",
@@ -98,6 +99,14 @@ def lib():
     L.mm_engine_profile_read.argtypes = [P, C.POINTER(I64), C.POINTER(D), C.POINTER(D), C.POINTER(I64)]
     L.mm_hausdorff_2d.restype = I
     L.mm_hausdorff_2d.argtypes = [P, P, P, I, P, P, I, C.POINTER(D)]
+    L.mm_hausdorff_batch.restype = I
+    L.mm_hausdorff_batch.argtypes = [P, I, P, P, P, P, P, P, P, C.POINTER(I32)]
+    L.mm_refine_angles.restype = I64
+    L.mm_refine_angles.argtypes = [D, D, D, P, I64]
+    L.mm_filter_points_in_region.restype = I64
+    L.mm_filter_points_in_region.argtypes = [P, I64, P, P, P, I64]
+    L.mm_refine_downsample_count.restype = I64
+    L.mm_refine_downsample_count.argtypes = [I64, I64, I64]
     L.mm_search_angles.restype = I64
     L.mm_search_angles.argtypes = [D, D, I, D, D, P, I64, C.POINTER(I), C.POINTER(D)]
     L.mm_best_rotation.restype = I
@@ -208,6 +217,31 @@ def search_angles(step_deg: float, range_deg: float, center: Optional[float] = N
     return out, bool(deg.value), early.value
 
 
+def refine_angles(initial: float, search_range: float, step: float) -> np.ndarray:
+    """Accumulated angle enumeration of refine_alignment_hausdorff (align_algorithms.rs:386-439)."""
+    n = lib().mm_refine_angles(initial, search_range, step, None, 0)
+    out = np.empty(int(n), dtype=np.float64)
+    if n:
+        lib().mm_refine_angles(initial, search_range, step, _ptr(out), n)
+    return out
+
+
+def filter_points_in_region(points_xyz, start_xyz, end_xyz) -> np.ndarray:
+    """Indices of the points inside the +-5 mm bounding box of two centerline points
+    (align_algorithms.rs:454-505)."""
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float64).reshape(-1, 3)
+    s = np.ascontiguousarray(start_xyz, dtype=np.float64)
+    e = np.ascontiguousarray(end_xyz, dtype=np.float64)
+    idx = np.empty(pts.shape[0], dtype=np.int64)
+    m = lib().mm_filter_points_in_region(_ptr(pts), pts.shape[0], _ptr(s), _ptr(e), _ptr(idx), pts.shape[0])
+    return idx[:m].copy()
+
+
+def refine_downsample_count(n_filtered: int, n_points_per_frame: int, n_frames: int) -> int:
+    """align_algorithms.rs:415-418"""
+    return int(lib().mm_refine_downsample_count(n_filtered, n_points_per_frame, n_frames))
+
+
 class Batch:
     """Host-side description of a batch of searches (SoA f64 + CSR offsets)."""
 
@@ -306,6 +340,29 @@ class Engine:
         check(lib().mm_hausdorff_2d(self._h, _ptr(ax), _ptr(ay), len(ax), _ptr(bx), _ptr(by), len(bx), C.byref(out)),
               "mm_hausdorff_2d")
         return out.value
+
+    def hausdorff_batch(self, pairs):
+        """``hausdorff_distance`` for a list of (A, B) point-set pairs in one launch; returns
+        (costs, index of the first strict minimum) -- the evaluation + selection of
+        refine_alignment_hausdorff (align_algorithms.rs:431-437)."""
+        n = len(pairs)
+        A = [_xy(a) for a, _ in pairs]
+        B = [_xy(b) for _, b in pairs]
+
+        def pack(sets):
+            off = np.zeros(n + 1, dtype=np.int64)
+            off[1:] = np.cumsum([s.shape[0] for s in sets])
+            x = np.concatenate([s[:, 0] for s in sets]) if n else np.zeros(0)
+            y = np.concatenate([s[:, 1] for s in sets]) if n else np.zeros(0)
+            return off, _f64(x), _f64(y)
+
+        ao, ax, ay = pack(A)
+        bo, bx, by = pack(B)
+        out = np.zeros(n, dtype=np.float64)
+        fm = C.c_int32(-1)
+        check(lib().mm_hausdorff_batch(self._h, n, _ptr(ao), _ptr(ax), _ptr(ay), _ptr(bo), _ptr(bx), _ptr(by),
+                                       _ptr(out), C.byref(fm)), "mm_hausdorff_batch")
+        return out, int(fm.value)
 
     # -- one search ------------------------------------------------------------------
     def best_rotation(self, ref, tgt, angles, centre, skip_zero=True, precision=MM_PRECISION_F32,

@@ -585,6 +585,45 @@ int mm_hausdorff_2d(mm_engine* h, const double* ax, const double* ay, int na,
     return MM_OK;
 }
 
+int mm_hausdorff_batch(mm_engine* h, int n_pairs, const int64_t* a_off, const double* ax, const double* ay,
+                       const int64_t* b_off, const double* bx, const double* by, double* out, int32_t* first_min)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    if (n_pairs < 0 || (n_pairs > 0 && !out)) return set_error(MM_ERR_INVALID, "mm_hausdorff_batch: bad arguments");
+    if (first_min) *first_min = -1;
+    if (n_pairs == 0) return MM_OK;
+    MM_HIP(hipSetDevice(e->device));
+    static const double zero = 0.0;
+    std::vector<SetRef> sets; std::vector<PairSpec> pairs;
+    const int cap = max_target_points_f64();
+    for (int p = 0; p < n_pairs; ++p) {
+        const int64_t na = a_off[p + 1] - a_off[p], nb = b_off[p + 1] - b_off[p];
+        if (na < 0 || nb < 0 || na > INT32_MAX || nb > INT32_MAX) return set_error(MM_ERR_INVALID, "bad set extent");
+        SetRef A{ax + a_off[p], ay + a_off[p], (int32_t)na, 0.0, 0.0}, B{bx + b_off[p], by + b_off[p], (int32_t)nb, 0.0, 0.0};
+        // hausdorff_distance is symmetric bit for bit (max of the two directed terms over the same
+        // squared distances): put the smaller set on the LDS-staged (target) side if the other one
+        // would not fit
+        const bool swap = nb > cap && na <= cap;
+        const int32_t sid = (int32_t)sets.size();
+        sets.push_back(swap ? B : A);
+        sets.push_back(swap ? A : B);
+        // angle 0 with the rotate() shortcut leaves the target untouched
+        pairs.push_back(PairSpec{sid, sid + 1, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, &zero, 1, 0.0, 0.0});
+    }
+    BatchResult res;
+    int rc = run_batch(e, sets, pairs, MM_PRECISION_F64, res);
+    if (rc) return rc;
+    int32_t best = -1;
+    double best_cost = INFINITY;   // f64::MAX in the reference; costs are finite
+    for (int p = 0; p < n_pairs; ++p) {
+        out[p] = res.best_cost[p];
+        if (out[p] < best_cost) { best_cost = out[p]; best = p; }
+    }
+    if (first_min) *first_min = best;
+    return MM_OK;
+}
+
 // ---- persistent plans ------------------------------------------------------------------
 struct PlanHandle {
     Plan plan;

@@ -556,6 +556,48 @@ int64_t mm_search_angles(double step_deg, double range_deg, int has_center, doub
     return (int64_t)v.size();
 }
 
+// align_algorithms.rs:386-387,439: accumulated angle enumeration of the refine grid
+int64_t mm_refine_angles(double initial, double range, double step, double* out, int64_t cap)
+{
+    int64_t n = 0;
+    if (!(step > 0.0)) return 0;  // the reference would loop forever
+    double angle = initial - range;
+    while (angle <= initial + range) {
+        if (out && n < cap) out[n] = angle;
+        ++n;
+        angle += step;
+    }
+    return n;
+}
+
+// align_algorithms.rs:454-505
+int64_t mm_filter_points_in_region(const double* xyz, int64_t n, const double* s, const double* e,
+                                   int64_t* out_idx, int64_t cap)
+{
+    const double margin = 5.0;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(s[k], e[k]) - margin; hi[k] = std::fmax(s[k], e[k]) + margin; }
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = xyz + 3 * i;
+        if (p[0] >= lo[0] && p[0] <= hi[0] && p[1] >= lo[1] && p[1] <= hi[1] && p[2] >= lo[2] && p[2] <= hi[2]) {
+            if (out_idx && m < cap) out_idx[m] = i;
+            ++m;
+        }
+    }
+    return m;
+}
+
+// align_algorithms.rs:415-418
+int64_t mm_refine_downsample_count(int64_t n_filtered, int64_t n_points_per_frame, int64_t n_frames)
+{
+    const double ratio = (double)n_filtered / ((double)n_points_per_frame * (double)n_frames);
+    int64_t n = (int64_t)std::ceil(ratio * (double)n_points_per_frame);
+    if (n < 1) n = 1;
+    if (n > n_points_per_frame) n = n_points_per_frame;
+    return n;
+}
+
 // frame.rs:17-38
 void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double dz)
 {

@@ -500,3 +500,47 @@ int orc_align_between(orc_geometry* a, orc_geometry* b, double rot_deg, double s
     if (best_rotation_out) *best_rotation_out = best;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * align_algorithms.rs:339-451 helpers
+ * ---------------------------------------------------------------------------------- */
+size_t orc_refine_angles(double initial, double range, double step, double* out, size_t cap)
+{
+    size_t n = 0;
+    if (!(step > 0.0)) return 0;
+    double angle = initial - range;                           /* :386 */
+    while (angle <= initial + range) {                        /* :387 */
+        if (out && n < cap) out[n] = angle;
+        ++n;
+        angle += step;                                        /* :439 */
+    }
+    return n;
+}
+
+size_t orc_filter_points_in_region(const orc_point* pts, size_t n, const orc_point* s,
+                                   const orc_point* e, int64_t* out_idx, size_t cap)
+{
+    const double margin = 5.0;                                /* :460 */
+    const double min_x = fmin(s->x, e->x) - margin, max_x = fmax(s->x, e->x) + margin;
+    const double min_y = fmin(s->y, e->y) - margin, max_y = fmax(s->y, e->y) + margin;
+    const double min_z = fmin(s->z, e->z) - margin, max_z = fmax(s->z, e->z) + margin;
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {                          /* :493-504 */
+        const orc_point* p = &pts[i];
+        if (p->x >= min_x && p->x <= max_x && p->y >= min_y && p->y <= max_y && p->z >= min_z && p->z <= max_z) {
+            if (out_idx && m < cap) out_idx[m] = (int64_t)i;
+            ++m;
+        }
+    }
+    return m;
+}
+
+size_t orc_refine_downsample_count(size_t n_filtered, size_t n_points_per_frame, size_t n_frames)
+{
+    double ratio = (double)n_filtered / ((double)n_points_per_frame * (double)n_frames); /* :415-416 */
+    double nd = ceil(ratio * (double)n_points_per_frame);                                /* :417 */
+    size_t n = nd <= 0.0 ? 0 : (size_t)nd;
+    if (n < 1) n = 1;                                                                    /* :418 clamp */
+    if (n > n_points_per_frame) n = n_points_per_frame;
+    return n;
+}

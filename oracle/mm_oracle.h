@@ -143,6 +143,15 @@ size_t orc_extract_between_points(const orc_geometry* g, size_t sample_size,
 int orc_align_between(orc_geometry* a, orc_geometry* b, double rot_deg, double step_rot_deg,
                       size_t sample_size, double* best_rotation_out, int n_threads);
 
+/* ---- refine_alignment_hausdorff (centerline_align/align_algorithms.rs:339-451) -------- */
+/* accumulated angle enumeration, :386-387,439 */
+size_t orc_refine_angles(double initial, double range, double step, double* out, size_t cap);
+/* filter_points_in_region, :454-505; returns count, writes indices */
+size_t orc_filter_points_in_region(const orc_point* pts, size_t n, const orc_point* start,
+                                   const orc_point* end, int64_t* out_idx, size_t cap);
+/* n_downsample, :415-418 */
+size_t orc_refine_downsample_count(size_t n_filtered, size_t n_points_per_frame, size_t n_frames);
+
 #ifdef __cplusplus
 }
 #endif

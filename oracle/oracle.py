@@ -120,6 +120,12 @@ def lib():
     L.orc_catheter_lumen_vec.restype = C.c_size_t
     L.orc_catheter_lumen_vec.argtypes = [C.POINTER(_Geometry), C.c_int32, C.c_size_t, C.c_int,
                                          C.c_size_t, P]
+    L.orc_refine_angles.restype = C.c_size_t
+    L.orc_refine_angles.argtypes = [C.c_double, C.c_double, C.c_double, P, C.c_size_t]
+    L.orc_filter_points_in_region.restype = C.c_size_t
+    L.orc_filter_points_in_region.argtypes = [P, C.c_size_t, P, P, P, C.c_size_t]
+    L.orc_refine_downsample_count.restype = C.c_size_t
+    L.orc_refine_downsample_count.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t]
     _lib = L
     return L
 
@@ -373,3 +379,39 @@ def catheter_lumen_vec(g: OracleGeometry, i, sample_size) -> np.ndarray:
     cg = g._c()
     n = lib().orc_catheter_lumen_vec(C.byref(cg), i, int(sample_size), has_sc, sc, _p(out))
     return out[:n].copy()
+
+
+# ---------------------------------------------------------------------------------------
+# refine_alignment_hausdorff helpers (align_algorithms.rs:339-451)
+# ---------------------------------------------------------------------------------------
+def refine_angles(initial, search_range, step) -> np.ndarray:
+    n = lib().orc_refine_angles(initial, search_range, step, None, 0)
+    out = np.empty(n, dtype=np.float64)
+    if n:
+        lib().orc_refine_angles(initial, search_range, step, _p(out), n)
+    return out
+
+
+def filter_points_in_region(points_xyz, start_xyz, end_xyz) -> np.ndarray:
+    pts = _pts(points_xyz)
+    s = _pts(np.asarray(start_xyz, dtype=np.float64).reshape(1, 3))
+    e = _pts(np.asarray(end_xyz, dtype=np.float64).reshape(1, 3))
+    idx = np.empty(pts.shape[0], dtype=np.int64)
+    m = lib().orc_filter_points_in_region(_p(pts), pts.shape[0], _p(s), _p(e), _p(idx), pts.shape[0])
+    return idx[:m].copy()
+
+
+def refine_downsample_count(n_filtered, n_points_per_frame, n_frames) -> int:
+    return int(lib().orc_refine_downsample_count(n_filtered, n_points_per_frame, n_frames))
+
+
+def refine_select(candidate_sets):
+    """Evaluation + selection of refine_alignment_hausdorff (:431-437): candidates in
+    enumeration order, strict `<` keeps the first minimum. candidate_sets: list of
+    (filtered_ccta_points, flat_geometry_points); returns (costs, best index or -1)."""
+    costs = np.array([hausdorff(a, b) for a, b in candidate_sets], dtype=np.float64)
+    best, best_cost = -1, np.finfo(np.float64).max
+    for i, c in enumerate(costs):
+        if c < best_cost:
+            best, best_cost = i, c
+    return costs, best

@@ -88,3 +88,23 @@ def test_dummy_geometry_builders():
     assert len(g) == 6 and g[3].ref is None and g[0].ref is not None
     assert g[1].pts[0][0] == pytest.approx(1.0, abs=1e-6) and g[1].pts[0][1] == pytest.approx(3.0, abs=1e-6)
     assert [fr.centroid[2] for fr in g] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+
+
+def test_refine_helpers_match_oracle(built, mm, oracle):
+    """Host pieces of refine_alignment_hausdorff (align_algorithms.rs:339-451)."""
+    for init, rng, step in [(0.0, 0.5235987755982988, 0.017453292519943295), (0.3, 0.1, 0.03), (-1.0, 0.0, 0.1),
+                            (0.0, 1.0471975511965976, 0.017453292519943295)]:
+        a, oa = mm.refine_angles(init, rng, step), oracle.refine_angles(init, rng, step)
+        assert np.array_equal(a, oa) and len(a) >= 1
+    assert len(mm.refine_angles(0.0, 0.2617993877991494, 0.017453292519943295)) in (30, 31)   # +-15 deg at 1 deg
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-20, 20, size=(5000, 3))
+    s, e = np.array([1.0, -2.0, 3.0]), np.array([4.0, 6.0, -1.0])
+    idx = mm.filter_points_in_region(pts, s, e)
+    assert np.array_equal(idx, oracle.filter_points_in_region(pts, s, e))
+    assert 0 < len(idx) < 5000
+    lo, hi = np.minimum(s, e) - 5.0, np.maximum(s, e) + 5.0
+    assert np.array_equal(idx, np.nonzero(np.all((pts >= lo) & (pts <= hi), axis=1))[0])
+    for nf, m, f in [(0, 501, 20), (1, 501, 20), (3000, 501, 20), (10020, 501, 20), (50000, 501, 20), (777, 200, 11)]:
+        assert mm.refine_downsample_count(nf, m, f) == oracle.refine_downsample_count(nf, m, f)
+    assert mm.refine_downsample_count(50000, 501, 20) == 501 and mm.refine_downsample_count(0, 501, 20) == 1

@@ -333,3 +333,51 @@ def test_fullsize_f32_and_f64_paths_agree(engine, mm):
     assert np.array_equal(a["best_idx"], b["best_idx"])
     assert np.array_equal(a["best_cost"], b["best_cost"])
     assert a["n_rescored"].sum() < 0.05 * len(refs) * len(angles)
+
+
+# ---------------------------------------------------------------------------------------
+# third call site: refine_alignment_hausdorff's candidate grid (align_algorithms.rs:369-441)
+# ---------------------------------------------------------------------------------------
+def test_refine_grid_costs_and_selection(engine, oracle, mm):
+    """(index shift x accumulated angle) candidates: for each, hausdorff(filtered CCTA points,
+    placed + downsampled frames) on x,y only, strict `<` keeps the first minimum.  The placement
+    here is a plain 2-D stand-in (the reference's nalgebra placement is host code outside this
+    path); oracle and device get identical sets."""
+    rng = np.random.default_rng(21)
+    n_frames, m = 12, 200
+    t = np.arange(m) * (2 * math.pi / m)
+    frames = [np.stack([1.5 * np.cos(t) * (1 + 0.1 * np.sin(3 * t + k)), 1.2 * np.sin(t), np.full(m, 0.5 * k)], 1)
+              for k in range(n_frames)]
+    cloud = np.concatenate([f + rng.normal(0, 0.03, f.shape) for f in frames] +
+                           [rng.uniform(-12, 12, size=(4000, 3))])                 # wall points + far clutter
+    angles = mm.refine_angles(0.0, math.radians(8.0), math.radians(1.0))
+    cands, sets = [], []
+    for delta in range(-2, 3):
+        start = np.array([0.1 * delta, 0.0, 0.0]); end = np.array([0.1 * delta, 0.0, 0.5 * (n_frames - 1)])
+        idx = mm.filter_points_in_region(cloud, start, end)
+        filtered = cloud[idx]
+        nd = mm.refine_downsample_count(len(filtered), m, n_frames)
+        for ang in angles:
+            c, s = math.cos(ang), math.sin(ang)
+            placed = []
+            for f in frames:
+                g = np.stack([f[:, 0] * c - f[:, 1] * s + 0.1 * delta, f[:, 0] * s + f[:, 1] * c, f[:, 2]], 1)
+                placed.append(oracle.downsample(g, nd) if nd < m else g)
+            sets.append((filtered, np.concatenate(placed)))
+            cands.append((delta, ang))
+    costs, first = engine.hausdorff_batch(sets)
+    ocosts, ofirst = oracle.refine_select(sets)
+    assert np.array_equal(costs, ocosts)
+    assert first == ofirst and cands[first][0] == 0 and abs(cands[first][1]) < 1e-9
+
+
+def test_hausdorff_batch_large_and_swapped_sets(engine, oracle):
+    rng = np.random.default_rng(8)
+    pairs = [(rng.normal(size=(9000, 2)), rng.normal(size=(300, 2))),     # many rows, few columns
+             (rng.normal(size=(300, 2)), rng.normal(size=(9000, 2))),     # columns exceed the LDS budget -> roles swapped
+             (rng.normal(size=(50, 2)), rng.normal(size=(60, 2)))]
+    costs, first = engine.hausdorff_batch(pairs)
+    ref = np.array([oracle.hausdorff(a, b) for a, b in pairs])
+    assert np.array_equal(costs, ref) and first == int(np.argmin(ref))
+    with pytest.raises(RuntimeError, match="LDS budget"):
+        engine.hausdorff_batch([(rng.normal(size=(5000, 2)), rng.normal(size=(5000, 2)))])
