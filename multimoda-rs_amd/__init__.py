@@ -14,6 +14,10 @@ from ._native import (MM_PRECISION_F32, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, B
                       device_count, filter_points_in_region, refine_angles, refine_downsample_count, search_angles)
 from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
                        contour_centroid, search_set)
+from .io import InputData, Record, build_geometry_from_inputdata, numpy_to_inputdata, process_directory
+from .api import (GeometryPair, align_frames_in_geometries, from_array_doublepair, from_array_full,
+                  from_array_single, from_array_singlepair, from_file_doublepair, from_file_full,
+                  from_file_single, from_file_singlepair)
 from .synth import synthetic_case, synthetic_pullback
 
 __version__ = "0.1.0"
@@ -22,6 +26,10 @@ __all__ = [
     "Engine", "Batch", "Plan", "FlatGeometry", "device_count", "search_angles", "refine_angles",
     "filter_points_in_region", "refine_downsample_count",
     "align_within", "align_between", "WithinPlan", "search_set", "between_points",
+    "from_file_full", "from_file_doublepair", "from_file_singlepair", "from_file_single",
+    "from_array_full", "from_array_doublepair", "from_array_singlepair", "from_array_single",
+    "InputData", "Record", "numpy_to_inputdata", "build_geometry_from_inputdata", "process_directory",
+    "GeometryPair", "align_frames_in_geometries",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

@@ -1,0 +1,417 @@
+"""The reference's Python entry points for this path, mirrored: ``from_file_*`` /
+``from_array_*`` in the full / double-pair / single-pair / single modes
+(multimodars/_processing.py:42-1007 -> binding/functions.rs:143-1423 -> binding/entry.rs).
+
+Orchestration follows entry.rs: build geometries (io.py), align frames within every pullback
+(device search, decoupled mode), the lumen-affecting post-steps of
+``align_frames_in_geometry`` (align_within.rs:136-170), then the between-pullback alignments in
+the reference's order (AB | CD, then AC | BD).  Same argument names, meaning and defaults as
+the reference, with two deliberate differences: ``write_obj`` and ``postprocessing`` default to
+False, because OBJ export (to_object/*) and the z-resampling / trimming of
+``postprocess_geom_pair`` are outside this path; passing True
+raises NotImplementedError instead of silently skipping work.  Wall-contour synthesis
+(wall.rs) and hole filling are not restated either: neither changes a lumen coordinate that
+enters the search, and a geometry WITH a z-gap raises instead of being silently mis-handled.
+
+Return values: ``FlatGeometry`` / ``GeometryPair`` (numpy containers) instead of the PyO3 value
+classes; logs are the reference's 7-tuples ``(id, matched_to, rot_deg, tx, ty, cx, cy)``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from . import geometry as G
+from .io import EXTRA_KINDS, InputData, build_geometry_from_inputdata, sort_contour_points
+
+AlignLog = List[Tuple[int, int, float, float, float, float, float]]
+TOLERANCE = 0.03  # entry.rs:21 (used by postprocessing only)
+
+_engine: Optional[N.Engine] = None
+
+
+def default_engine() -> N.Engine:
+    """One lazily created engine on the current device (fails loudly without a GPU)."""
+    global _engine
+    if _engine is None or not _engine.handle.value:
+        _engine = N.Engine()
+    return _engine
+
+
+@dataclass
+class GeometryPair:
+    """types/native/geometry_pair.rs: geom_a (e.g. diastole / rest) and geom_b aligned onto it."""
+    geom_a: G.FlatGeometry
+    geom_b: G.FlatGeometry
+    label: str = ""
+
+
+def _make_pair(a: G.FlatGeometry, b: G.FlatGeometry) -> GeometryPair:
+    """GeometryPair::new: label = "<a> - <b>" (the labels the reference's plumbing tests check,
+    binding/functions.rs:1607-1616)."""
+    return GeometryPair(a, b, f"{a.label} - {b.label}")
+
+
+# ---------------------------------------------------------------------------------------
+# post-steps of align_frames_in_geometry that move lumen coordinates (align_within.rs:136-170)
+# ---------------------------------------------------------------------------------------
+def _median(values):
+    v = sorted(values)
+    n = len(v)
+    if n == 0:
+        return 0.0
+    return v[n // 2] if n % 2 == 1 else (v[n // 2 - 1] + v[n // 2]) / 2.0
+
+
+def _detect_holes(g: G.FlatGeometry):
+    """align_within.rs:352-376"""
+    z = g.centroids[:, 2]
+    diffs = [abs(float(z[i]) - float(z[i - 1])) for i in range(1, g.n_frames)]
+    if not diffs:
+        return False, 0.0
+    baseline = _median(diffs)
+    if baseline <= 2.220446049250313e-16:
+        return False, baseline
+    return any(d >= 1.5 * baseline for d in diffs), baseline
+
+
+def _dist3(p, q):
+    dx, dy, dz = float(p[0]) - float(q[0]), float(p[1]) - float(q[1]), float(p[2]) - float(q[2])
+    return math.sqrt(dx * dx + dy * dy + dz * dz)
+
+
+def _find_farthest_points(pts: np.ndarray):
+    """contour.rs:227-242 (first pair with the strictly largest 3-D distance)."""
+    d = pts[:, None, :] - pts[None, :, :]
+    d2 = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
+    n = pts.shape[0]
+    iu = np.triu_indices(n, k=1)
+    vals = d2[iu]
+    if vals.size == 0 or vals.max() <= 0.0:
+        return (0, 0), 0.0
+    k = int(np.argmax(vals))            # first maximum in (i asc, j asc) order == the reference's strict `>`
+    return (int(iu[0][k]), int(iu[1][k])), float(vals[k])
+
+
+def _find_closest_opposite_3d(pts: np.ndarray):
+    """contour.rs:313-333"""
+    n = pts.shape[0]
+    half = n // 2
+    best, best_pair = float("inf"), (0, half)
+    for i in range(n):
+        j = (i + half) % n
+        dd = _dist3(pts[i], pts[j])
+        if dd < best:
+            best, best_pair = dd, (i, j)
+    return best_pair, best
+
+
+def _elliptic_ratio(pts: np.ndarray) -> float:
+    """contour.rs:335-343"""
+    major = _find_farthest_points(pts)[1]
+    minor = _find_closest_opposite_3d(pts)[1]
+    return minor / major if major < minor else major / minor
+
+
+def _angle_ref_point_to_right(g: G.FlatGeometry, ref_idx: int, anomalous: bool) -> float:
+    """align_within.rs:256-318"""
+    if not g.has_ref[ref_idx]:
+        raise RuntimeError("No reference point found in frame")
+    rp = g.ref[ref_idx]
+    lum = g.frame_lumen(ref_idx)
+    if anomalous:
+        (i, j), _ = _find_farthest_points(lum)
+        p1, p2 = tuple(float(v) for v in lum[i]), tuple(float(v) for v in lum[j])
+    else:
+        p1 = tuple(float(v) for v in g.centroids[ref_idx])
+        p2 = (float(rp[0]), float(rp[1]), float(rp[2]))
+    dx, dy = p2[0] - p1[0], p2[1] - p1[1]
+    line_angle = math.atan2(dy, dx)
+    desired = math.pi / 2.0 if anomalous else 0.0
+    two_pi = 2.0 * math.pi
+    rotation = math.fmod(desired - line_angle, two_pi)
+    if rotation < 0.0:
+        rotation += two_pi
+
+    def rotate2(pt, center, angle):
+        ddx, ddy = pt[0] - center[0], pt[1] - center[1]
+        c, s = math.cos(angle), math.sin(angle)
+        return (ddx * c - ddy * s + center[0], ddx * s + ddy * c + center[1])
+
+    center = (p1[0], p1[1])
+    ref2 = (float(rp[0]), float(rp[1]))
+    rotated_ref = rotate2(ref2, center, rotation)
+    all_good = True
+    for op in ((p1[0], p1[1]), (p2[0], p2[1])):
+        # approx::abs_diff_eq! default epsilon = f64::EPSILON
+        if abs(op[0] - ref2[0]) <= 2.220446049250313e-16 and abs(op[1] - ref2[1]) <= 2.220446049250313e-16:
+            continue
+        if rotated_ref[0] <= rotate2(op, center, rotation)[0]:
+            all_good = False
+            break
+    if not all_good:
+        rotation = math.fmod(rotation + math.pi, two_pi)
+        if rotation < 0.0:
+            rotation += two_pi
+    return rotation
+
+
+def _sort_frame_points(g: G.FlatGeometry):
+    """Frame::sort_frame_points for every frame: lumen and every extras contour (frame.rs:119-125)."""
+    counts = g.meta.get("extra_counts")
+    for i in range(g.n_frames):
+        lo, hi = int(g.lumen_off[i]), int(g.lumen_off[i + 1])
+        g.lumen[lo:hi] = sort_contour_points(g.lumen[lo:hi])
+        if g.cath_off is not None:
+            lo, hi = int(g.cath_off[i]), int(g.cath_off[i + 1])
+            g.cath[lo:hi] = sort_contour_points(g.cath[lo:hi])
+        if g.extra_off is not None and counts:
+            lo = int(g.extra_off[i])
+            for k in EXTRA_KINDS:
+                n = int(counts[k][i])
+                if n:
+                    g.extra[lo:lo + n] = sort_contour_points(g.extra[lo:lo + n])
+                    lo += n
+
+
+def _rotate_geometry(g: G.FlatGeometry, angle: float):
+    """Geometry::rotate_geometry (geometry.rs:241-250): every frame about its own centroid, then
+    its contours re-sorted."""
+    if angle == 0.0:
+        return
+    import ctypes as C
+    s = g.c_struct()
+    for i in range(g.n_frames):
+        N.lib().mm_frame_rotate(C.byref(s), i, angle, float(g.centroids[i, 0]), float(g.centroids[i, 1]))
+    _sort_frame_points(g)
+
+
+def _smooth_frames(g: G.FlatGeometry):
+    """Geometry::smooth_frames (geometry.rs:165-239) for the lumen: 3-frame moving average of x, y
+    (first / last frame mirrored); z and the frame centroid stay.  Frames must have equal point
+    counts (the reference indexes prev/next by the current frame's count)."""
+    F = g.n_frames
+    cnt = np.diff(g.lumen_off)
+    if F == 0 or not np.all(cnt == cnt[0]):
+        raise NotImplementedError("smooth=True needs the same number of lumen points in every frame")
+    if g.extra_off is not None and g.meta.get("extra_counts", {}).get("eem", np.zeros(1)).sum():
+        raise NotImplementedError("smooth=True with EEM contours is not restated (geometry.rs:226-236)")
+    m = int(cnt[0])
+    L = g.lumen.reshape(F, m, 3)
+    prev = np.concatenate([L[:1], L[:-1]], axis=0)
+    nxt = np.concatenate([L[1:], L[-1:]], axis=0)
+    out = L.copy()
+    out[:, :, 0] = (prev[:, :, 0] + L[:, :, 0] + nxt[:, :, 0]) / 3.0
+    out[:, :, 1] = (prev[:, :, 1] + L[:, :, 1] + nxt[:, :, 1]) / 3.0
+    g.lumen[:] = out.reshape(-1, 3)
+
+
+def _ref_or_proximal(g: G.FlatGeometry) -> int:
+    """find_ref_frame_idx().unwrap_or(find_proximal_end_idx()) (geometry.rs:42-69)"""
+    for i in range(g.n_frames):
+        if g.has_ref is not None and g.has_ref[i]:
+            return int(g.ids[i])
+    n = g.n_frames
+    if n == 0:
+        return 0
+    if n == 1:
+        return int(g.lumen_ids[0])
+    return int(g.lumen_ids[0] if g.orig_frames[0] > g.orig_frames[-1] else g.lumen_ids[-1])
+
+
+def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
+    """align_within.rs:136-160 after the chain; returns the anomalous flag."""
+    hole, _ = _detect_holes(g)
+    if hole:
+        raise NotImplementedError("hole filling (align_within.rs:378-445) is not restated: the pullback has a z-gap")
+    lum = g.frame_lumen(ref_idx)
+    a_th = g.meta.get("aortic_thickness")
+    p_th = g.meta.get("pulmonary_thickness")
+    anomalous = (_elliptic_ratio(lum) > 2.0 or (a_th is not None and a_th[ref_idx] is not None)
+                 or (p_th is not None and p_th[ref_idx] is not None))        # align_within.rs:249-254
+    _rotate_geometry(g, _angle_ref_point_to_right(g, ref_idx, anomalous))
+    if smooth:
+        _smooth_frames(g)
+    g.meta["anomalous"] = bool(anomalous)
+    return bool(anomalous)
+
+
+def align_frames_in_geometries(geoms: Sequence[G.FlatGeometry], step_deg: float, range_deg: float, smooth: bool,
+                               bruteforce: bool, sample_size: int, engine: Optional[N.Engine] = None,
+                               precision: int = N.MM_PRECISION_F32, mode: int = 1):
+    """``align_frames_in_geometry`` (align_within.rs:24-171) for several pullbacks at once (the
+    reference's crossbeam scope, entry.rs:140-203).  In place; returns (logs, anomalous flags)."""
+    eng = engine or default_engine()
+    for g in geoms:                                      # align_within.rs:32-40
+        if g.n_frames == 0:
+            raise RuntimeError("Geometry contains no frames")
+        if int(g.lumen_off[1] - g.lumen_off[0]) == 0:
+            raise RuntimeError("Lumen contours have no points")
+    if sample_size == 0:
+        raise RuntimeError("sample_size must be > 0")
+    ref_idx = [_ref_or_proximal(g) for g in geoms]       # :42-44, before the chain
+    logs, _ = G.align_within(eng, geoms, step_deg, range_deg, bruteforce, sample_size, precision=precision, mode=mode)
+    flags = [_finish_within(g, r, smooth) for g, r in zip(geoms, ref_idx)]
+    return logs, flags
+
+
+# ---------------------------------------------------------------------------------------
+# prepare_n_geometries (preprocessing.rs:27-201)
+# ---------------------------------------------------------------------------------------
+def _basename(path: str) -> str:
+    b = os.path.basename(os.path.normpath(path))
+    return b if b else "unknown"
+
+
+def _prepare_from_paths(paths: Sequence[str], labels, n_expected, image_center, radius, n_points, single_diastole=None):
+    use_labels = labels is not None and len(labels) == n_expected
+    geoms, idx = [], 0
+    for p in paths:
+        phases = [single_diastole] if single_diastole is not None else [True, False]
+        for dia in phases:
+            label = labels[idx] if use_labels else _basename(p)
+            geoms.append(build_geometry_from_inputdata(None, p, label, dia, image_center, radius, n_points))
+            idx += 1
+    return geoms
+
+
+def _prepare_from_inputs(inputs: Sequence[InputData], image_center, radius, n_points):
+    return [build_geometry_from_inputdata(d, None, d.label, d.diastole, image_center, radius, n_points) for d in inputs]
+
+
+def _check_unsupported(write_obj, postprocessing):
+    if write_obj:
+        raise NotImplementedError("write_obj=True: OBJ/MTL export (to_object/*, io/output.rs) is outside this path")
+    if postprocessing:
+        raise NotImplementedError("postprocessing=True: postprocess_geom_pair (postprocessing.rs:12) is outside this path")
+
+
+# ---------------------------------------------------------------------------------------
+# the four modes (entry.rs:71, 363, 572, 691)
+# ---------------------------------------------------------------------------------------
+def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batches=True):
+    eng = engine or default_engine()
+    logs, _flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
+    a, b, c, d = geoms
+    G.align_between(eng, [(a, b), (c, d)], rng, step, sample_size)                 # entry.rs:206-240
+    pair_ab = _make_pair(a.copy(), b.copy())
+    pair_cd = _make_pair(c.copy(), d.copy())
+    if not both_batches:
+        return pair_ab, pair_cd, tuple(logs)
+    G.align_between(eng, [(a, c), (b, d)], rng, step, sample_size)                 # entry.rs:243-277
+    pair_ac = _make_pair(a.copy(), c.copy())
+    pair_bd = _make_pair(b.copy(), d.copy())
+    return pair_ab, pair_cd, pair_ac, pair_bd, tuple(logs)
+
+
+def from_array_full(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData, input_data_d: InputData,
+                    step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0, sample_size: int = 500,
+                    image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20, write_obj: bool = False,
+                    watertight: bool = True, contour_types=None, output_path_ab: str = "output/rest",
+                    output_path_cd: str = "output/stress", output_path_ac: str = "output/diastole",
+                    output_path_bd: str = "output/systole", interpolation_steps: int = 0, bruteforce: bool = False,
+                    smooth: bool = True, postprocessing: bool = False, engine: Optional[N.Engine] = None):
+    """_processing.py:553 / functions.rs:827 / entry.rs:71 -> (pair_ab, pair_cd, pair_ac, pair_bd, (logs x4))."""
+    _check_unsupported(write_obj, postprocessing)
+    geoms = _prepare_from_inputs([input_data_a, input_data_b, input_data_c, input_data_d], image_center, radius, n_points)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+
+
+def from_file_full(input_path_ab: str, input_path_cd: str, labels=None, step_rotation_deg: float = 0.5,
+                   range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
+                   radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                   contour_types=None, output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
+                   output_path_ac: str = "output/diastole", output_path_bd: str = "output/systole",
+                   interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
+                   postprocessing: bool = False, engine: Optional[N.Engine] = None):
+    """_processing.py:42 / functions.rs:168 / entry.rs:71."""
+    _check_unsupported(write_obj, postprocessing)
+    geoms = _prepare_from_paths([input_path_ab, input_path_cd], labels, 4, image_center, radius, n_points)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+
+
+def from_array_doublepair(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData,
+                          input_data_d: InputData, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
+                          sample_size: int = 500, image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20,
+                          write_obj: bool = False, watertight: bool = True, contour_types=None,
+                          output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
+                          interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
+                          postprocessing: bool = False, engine: Optional[N.Engine] = None):
+    """_processing.py:698 / entry.rs:363 -> (pair_ab, pair_cd, (logs x4))."""
+    _check_unsupported(write_obj, postprocessing)
+    geoms = _prepare_from_inputs([input_data_a, input_data_b, input_data_c, input_data_d], image_center, radius, n_points)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False)
+
+
+def from_file_doublepair(input_path_ab: str, input_path_cd: str, labels=None, step_rotation_deg: float = 0.5,
+                         range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
+                         radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                         contour_types=None, output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
+                         interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
+                         postprocessing: bool = False, engine: Optional[N.Engine] = None):
+    """_processing.py:201 / entry.rs:363."""
+    _check_unsupported(write_obj, postprocessing)
+    geoms = _prepare_from_paths([input_path_ab, input_path_cd], labels, 4, image_center, radius, n_points)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False)
+
+
+def _pair(geoms, step, rng, smooth, bruteforce, sample_size, engine):
+    eng = engine or default_engine()
+    logs, _flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
+    a, b = geoms
+    G.align_between(eng, [(a, b)], rng, step, sample_size)                          # entry.rs:655
+    return _make_pair(a, b), (logs[0], logs[1])
+
+
+def from_array_singlepair(input_data_a: InputData, input_data_b: InputData, step_rotation_deg: float = 0.5,
+                          range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
+                          radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                          contour_types=None, output_path: str = "output/singlepair", interpolation_steps: int = 0,
+                          bruteforce: bool = False, smooth: bool = True, postprocessing: bool = False,
+                          engine: Optional[N.Engine] = None):
+    """_processing.py:822 / entry.rs:572 -> (pair, (logs_a, logs_b))."""
+    _check_unsupported(write_obj, postprocessing)
+    geoms = _prepare_from_inputs([input_data_a, input_data_b], image_center, radius, n_points)
+    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+
+
+def from_file_singlepair(input_path: str, labels=None, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
+                         sample_size: int = 500, image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20,
+                         write_obj: bool = False, watertight: bool = True, contour_types=None,
+                         output_path: str = "output/singlepair", interpolation_steps: int = 0, bruteforce: bool = False,
+                         smooth: bool = True, postprocessing: bool = False, engine: Optional[N.Engine] = None):
+    """_processing.py:333 / functions.rs:517 / entry.rs:572: one folder read twice (diastole, systole)."""
+    _check_unsupported(write_obj, postprocessing)
+    geoms = _prepare_from_paths([input_path], labels, 2, image_center, radius, n_points)
+    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+
+
+def from_array_single(input_data: InputData, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
+                      sample_size: int = 500, image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20,
+                      write_obj: bool = False, watertight: bool = True, contour_types=None,
+                      output_path: str = "output/single", bruteforce: bool = False, smooth: bool = True,
+                      engine: Optional[N.Engine] = None):
+    """_processing.py:922 / functions.rs:1350 / entry.rs:691 -> (geometry, logs)."""
+    _check_unsupported(write_obj, False)
+    geoms = _prepare_from_inputs([input_data], image_center, radius, n_points)
+    logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
+                                         engine)
+    return geoms[0], logs[0]
+
+
+def from_file_single(input_path: str, labels=None, diastole: bool = True, step_rotation_deg: float = 0.5,
+                     range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
+                     radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                     contour_types=None, output_path: str = "output/single", bruteforce: bool = False,
+                     smooth: bool = True, engine: Optional[N.Engine] = None):
+    """_processing.py:449 / functions.rs:656 / entry.rs:691."""
+    _check_unsupported(write_obj, False)
+    geoms = _prepare_from_paths([input_path], labels, 1, image_center, radius, n_points, single_diastole=diastole)
+    logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
+                                         engine)
+    return geoms[0], logs[0]

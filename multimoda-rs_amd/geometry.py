@@ -65,6 +65,7 @@ class FlatGeometry:
     has_ref: Optional[np.ndarray] = None  # (F,) u8
     ref: Optional[np.ndarray] = None      # (F,3) f64
     label: str = ""
+    meta: dict = field(default_factory=dict)   # host-only bookkeeping (extras layout, wall thickness records)
 
     # ------------------------------------------------------------------------------
     @property
@@ -113,7 +114,8 @@ class FlatGeometry:
         cp = lambda a: None if a is None else a.copy()
         return FlatGeometry(cp(self.ids), cp(self.lumen_ids), cp(self.orig_frames), cp(self.centroids),
                             cp(self.lumen_off), cp(self.lumen), cp(self.cath_off), cp(self.cath),
-                            cp(self.extra_off), cp(self.extra), cp(self.has_ref), cp(self.ref), self.label)
+                            cp(self.extra_off), cp(self.extra), cp(self.has_ref), cp(self.ref), self.label,
+                            dict(self.meta))
 
     def frame_lumen(self, i: int) -> np.ndarray:
         return self.lumen[self.lumen_off[i]:self.lumen_off[i + 1]]

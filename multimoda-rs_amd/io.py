@@ -1,0 +1,332 @@
+"""Input data and geometry builder: host-side restatement of the reference's
+``io/input.rs`` (CSV readers) and ``io/build.rs:9-205`` (``build_geometry_from_inputdata``)
+with the ``Geometry`` helpers it calls (``reorder_frames`` geometry.rs:72-155,
+``sort_contour_points`` contour.rs:368-405, ``ensure_proximal_at_position_zero``
+geometry.rs:325-381).  Pure host bookkeeping around the hot path;
+needed so that ``mm.from_file_*`` / ``mm.from_array_*`` can be driven from the reference's
+own inputs.  Scalars are Python floats (IEEE f64, no fused multiply-add) and ``math.*`` is
+glibc, i.e. the arithmetic of the Rust code on linux-gnu.
+"""
+from __future__ import annotations
+
+import csv
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .geometry import FlatGeometry, contour_centroid
+
+RECORD_FILE_NAME = "combined_sorted_manual.csv"          # input.rs:12
+RECORD_FILE_NAME_ALT = "diastolic_systolic_records.csv"  # input.rs:13
+EXTRA_KINDS = ("eem", "calcification", "sidebranch")
+
+
+@dataclass
+class Record:
+    """types/native/record.rs"""
+    frame: int
+    phase: str
+    measurement_1: Optional[float] = None
+    measurement_2: Optional[float] = None
+
+
+@dataclass
+class InputData:
+    """io/input.rs:28-37; point arrays are (N, 4) ``[frame_index, x, y, z]``
+    (the ``numpy_to_inputdata`` contract of multimodars/_converters.py:204-437)."""
+    lumen: np.ndarray
+    ref_point: np.ndarray                      # (4,) [frame_index, x, y, z]
+    diastole: bool = True
+    label: str = ""
+    eem: Optional[np.ndarray] = None
+    calcification: Optional[np.ndarray] = None
+    sidebranch: Optional[np.ndarray] = None
+    record: Optional[List[Record]] = None
+
+
+def _as_points4(arr, name: str) -> Optional[np.ndarray]:
+    if arr is None:
+        return None
+    a = np.asarray(arr, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError(f"{name}: expected an (N, 4) array [frame_index, x, y, z]")
+    return np.ascontiguousarray(a)
+
+
+def numpy_to_inputdata(lumen_arr, ref_point, diastole: bool, record=None, eem_arr=None, calcification=None,
+                       sidebranch=None, label: str = "") -> InputData:
+    """Mirror of ``multimodars.numpy_to_inputdata`` (_converters.py:204-437)."""
+    lum = _as_points4(lumen_arr, "lumen_arr")
+    if lum is None or lum.shape[0] == 0:
+        raise ValueError("lumen_arr is empty")
+    rp = np.asarray(ref_point, dtype=np.float64).reshape(-1)
+    if rp.shape[0] != 4:
+        raise ValueError("ref_point: expected [frame_index, x, y, z]")
+    recs = None
+    if record is not None:
+        recs = []
+        for row in np.asarray(record, dtype=object).reshape(-1, 4):
+            m1 = None if row[2] is None or (isinstance(row[2], float) and math.isnan(row[2])) else float(row[2])
+            m2 = None if row[3] is None or (isinstance(row[3], float) and math.isnan(row[3])) else float(row[3])
+            recs.append(Record(int(row[0]), str(row[1]), m1, m2))
+    return InputData(lumen=lum, ref_point=rp, diastole=bool(diastole), label=label, eem=_as_points4(eem_arr, "eem_arr"),
+                     calcification=_as_points4(calcification, "calcification"),
+                     sidebranch=_as_points4(sidebranch, "sidebranch"), record=recs)
+
+
+# ---------------------------------------------------------------------------------------
+# CSV readers (io/input.rs)
+# ---------------------------------------------------------------------------------------
+def _detect_delimiter(path: str) -> str:
+    """input.rs:149-170: tabs > commas on the first line -> tab, else comma."""
+    with open(path, "r", newline="") as f:
+        first = f.readline()
+    return "\t" if first.count("\t") > first.count(",") else ","
+
+
+def read_contour_data(path: str) -> np.ndarray:
+    """input.rs:172-194: headerless ``frame,x,y,z`` rows; invalid rows are skipped."""
+    delim = _detect_delimiter(path)
+    rows = []
+    with open(path, "r", newline="") as f:
+        for rec in csv.reader(f, delimiter=delim):
+            try:
+                if len(rec) < 4:
+                    raise ValueError
+                fi = int(rec[0])
+                if fi < 0:
+                    raise ValueError
+                rows.append((float(fi), float(rec[1]), float(rec[2]), float(rec[3])))
+            except ValueError:
+                continue
+    return np.array(rows, dtype=np.float64).reshape(-1, 4)
+
+
+def read_reference_point(path: str) -> np.ndarray:
+    """input.rs:213-233: the first record; an empty file is an error."""
+    pts = read_contour_data(path)
+    if pts.shape[0] == 0:
+        raise RuntimeError(f"reference-point file {path!r} was empty — this data is required")
+    return pts[0].copy()
+
+
+def read_records(path: str) -> List[Record]:
+    """input.rs:235-249 + record.rs: header row, columns by name; unparsable measurements -> None."""
+    delim = _detect_delimiter(path)
+    out = []
+    with open(path, "r", newline="") as f:
+        for row in csv.DictReader(f, delimiter=delim):
+            def opt(v):
+                try:
+                    return float(v)
+                except (TypeError, ValueError):
+                    return None
+            out.append(Record(int(row["frame"]), str(row["phase"]), opt(row.get("measurement_1")),
+                              opt(row.get("measurement_2"))))
+    return out
+
+
+def process_directory(path: str, diastole: bool, label: str) -> InputData:
+    """``InputData::process_directory`` (input.rs:62-146) with the default name mapping of
+    build.rs:22-27."""
+    phase = "diastolic" if diastole else "systolic"
+    contours_path = os.path.join(path, f"{phase}_contours.csv")
+    if not os.path.exists(contours_path):
+        raise RuntimeError(f"required contours file missing: {contours_path!r}")
+    ref_path = os.path.join(path, f"{phase}_reference_points.csv")
+    if not os.path.exists(ref_path):
+        raise RuntimeError(f"required reference-point file missing: {ref_path!r}")
+
+    def optional(prefix):
+        p = os.path.join(path, f"{prefix}_{phase}_contours.csv")
+        return read_contour_data(p) if os.path.exists(p) else None
+
+    rec_path = os.path.join(path, RECORD_FILE_NAME)
+    if not os.path.exists(rec_path):
+        rec_path = os.path.join(path, RECORD_FILE_NAME_ALT)
+    record = read_records(rec_path) if os.path.exists(rec_path) else None
+    return InputData(lumen=read_contour_data(contours_path), ref_point=read_reference_point(ref_path),
+                     diastole=diastole, label=label, eem=optional("eem"), calcification=optional("calcium"),
+                     sidebranch=optional("branch"), record=record)
+
+
+# ---------------------------------------------------------------------------------------
+# contour helpers
+# ---------------------------------------------------------------------------------------
+def sort_contour_points(points: np.ndarray) -> np.ndarray:
+    """``Contour::sort_contour_points`` (contour.rs:368-405): ascending atan2 about the
+    centroid (stable), then rotated so that the point with the highest y comes first."""
+    n = points.shape[0]
+    if n == 0:
+        return points
+    sx = sy = 0.0
+    for p in points:                                   # fold((0,0), |(sx,sy),p| (sx+p.x, sy+p.y))
+        sx += float(p[0]); sy += float(p[1])
+    cx, cy = sx / float(n), sy / float(n)
+    keys = [math.atan2(float(p[1]) - cy, float(p[0]) - cx) for p in points]
+    order = sorted(range(n), key=keys.__getitem__)     # stable, like slice::sort_by
+    pts = points[order]
+    best = 0
+    for i in range(n):                                 # Iterator::max_by keeps the LAST maximum
+        if pts[i, 1] >= pts[best, 1]:
+            best = i
+    return np.concatenate([pts[best:], pts[:best]], axis=0)
+
+
+def create_catheter_points(frame_z: Dict[int, float], image_center, radius: float, n_points: int) -> Dict[int, np.ndarray]:
+    """``Frame::create_catheter_points`` (frame.rs:163-204): per original frame index one circle."""
+    out = {}
+    for frame in sorted(frame_z):
+        z = frame_z[frame]
+        pts = np.empty((n_points, 3), dtype=np.float64)
+        for i in range(n_points):
+            angle = 2.0 * math.pi * float(i) / float(n_points)
+            pts[i, 0] = image_center[0] + radius * math.cos(angle)
+            pts[i, 1] = image_center[1] + radius * math.sin(angle)
+            pts[i, 2] = z
+        out[frame] = pts
+    return out
+
+
+@dataclass
+class _Frame:
+    id: int
+    orig: int
+    lumen: np.ndarray                    # (n,3)
+    centroid: List[float]
+    extras: Dict[str, np.ndarray] = field(default_factory=dict)   # kind -> (n,3)
+    ref: Optional[List[float]] = None
+    aortic: Optional[float] = None
+    pulmonary: Optional[float] = None
+
+
+def _group_by_frame(arr: np.ndarray) -> Dict[int, np.ndarray]:
+    """HashMap<u32, Vec<ContourPoint>> with points in input order (contour.rs:163-166)."""
+    groups: Dict[int, List[int]] = {}
+    for i, fi in enumerate(arr[:, 0]):
+        groups.setdefault(int(fi), []).append(i)
+    return {k: arr[v, 1:4].copy() for k, v in groups.items()}
+
+
+def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: Optional[str] = None, label: str = "",
+                                  diastole: bool = True, image_center=(4.5, 4.5), radius: float = 0.5,
+                                  n_points: int = 20) -> FlatGeometry:
+    """``build_geometry_from_inputdata`` (io/build.rs:9-205)."""
+    if input_data is None:
+        if path is None:
+            raise RuntimeError("Either input_data or path must be provided")
+        input_data = process_directory(path, diastole, label)
+    d = input_data
+
+    # build.rs:37-71 shared original-frame -> sequential-id mapping
+    originals = set(int(f) for f in d.lumen[:, 0])
+    for arr in (d.eem, d.calcification, d.sidebranch):
+        if arr is not None:
+            originals.update(int(f) for f in arr[:, 0])
+    ref_frame = int(d.ref_point[0])
+    originals.add(ref_frame)
+    mapping = {o: i for i, o in enumerate(sorted(originals))}
+
+    meas = {}
+    if d.record:
+        for r in d.record:                                          # contour.rs:172-177
+            meas[r.frame] = (r.measurement_1, r.measurement_2)
+
+    frames: Dict[int, _Frame] = {}
+    for orig, pts in sorted(_group_by_frame(d.lumen).items()):     # build.rs:74-129
+        fid = mapping[orig]
+        m = meas.get(orig, (None, None))
+        fr = _Frame(id=fid, orig=orig, lumen=pts, centroid=list(contour_centroid(pts)), aortic=m[0], pulmonary=m[1])
+        if mapping.get(ref_frame) == fid:
+            fr.ref = [float(d.ref_point[1]), float(d.ref_point[2]), float(d.ref_point[3])]
+        frames[fid] = fr
+    for kind, arr in (("eem", d.eem), ("calcification", d.calcification), ("sidebranch", d.sidebranch)):
+        if arr is None:
+            continue
+        for orig, pts in _group_by_frame(arr).items():             # build.rs:131-150
+            fid = mapping[orig]
+            if fid in frames:
+                frames[fid].extras[kind] = pts
+    if n_points > 0:                                               # build.rs:152-174
+        frame_z = {fr.orig: float(fr.lumen[0, 2]) for fr in frames.values()}
+        for orig, pts in create_catheter_points(frame_z, image_center, radius, n_points).items():
+            fid = mapping[orig]
+            if fid in frames:
+                frames[fid].extras["catheter"] = pts
+
+    flist = [frames[k] for k in sorted(frames)]                    # build.rs:176-177
+
+    if d.record:                                                   # build.rs:184-186 -> geometry.rs:72-155
+        phase = "D" if d.diastole else "S"
+        filtered = [r.frame for r in d.record if r.phase == phase]
+        by_orig = {fr.orig: fr for fr in flist}
+        new, used = [], set()
+        for o in filtered:
+            if o in by_orig and o not in used:
+                new.append(by_orig[o]); used.add(o)
+        rest = sorted((fr for fr in flist if fr.orig not in used), key=lambda fr: fr.orig)
+        flist = new + rest
+        for i, fr in enumerate(flist):
+            fr.id = i                                              # z stays the frame's own original z
+
+    for fr in flist:                                               # build.rs:188-190
+        fr.lumen = sort_contour_points(fr.lumen)
+        for k in list(fr.extras):
+            fr.extras[k] = sort_contour_points(fr.extras[k])
+
+    # build.rs:192 -> geometry.rs:325-381 ensure_proximal_at_position_zero
+    n = len(flist)
+    if n:
+        if n == 1:
+            prox = flist[0].id
+        else:
+            prox = flist[0].id if flist[0].orig > flist[-1].orig else flist[-1].id
+        prox = min(prox, n - 1)
+        if prox != 0:
+            flist.reverse()
+        zs = sorted(fr.centroid[2] for fr in flist)
+        for i, fr in enumerate(flist):
+            fr.id = i
+            z = zs[i]
+            fr.centroid[2] = z
+            fr.lumen[:, 2] = z
+            for k in fr.extras:
+                fr.extras[k][:, 2] = z
+            if fr.ref is not None:
+                fr.ref[2] = z
+    if n == 0:
+        raise RuntimeError("Geometry has no frames")               # integrity_check.rs:9-11
+    return _to_flat(flist, d.label or label)
+
+
+def _to_flat(flist: Sequence[_Frame], label: str) -> FlatGeometry:
+    F = len(flist)
+    has_cath = all("catheter" in fr.extras for fr in flist) and F > 0
+    g = FlatGeometry.from_frames(
+        [fr.lumen for fr in flist],
+        catheters=[fr.extras["catheter"] for fr in flist] if has_cath else None,
+        centroids=[fr.centroid for fr in flist], ids=[fr.id for fr in flist], orig_frames=[fr.orig for fr in flist],
+        ref_points={i: fr.ref for i, fr in enumerate(flist) if fr.ref is not None}, label=label)
+    # every other extras contour, concatenated per frame in EXTRA_KINDS order
+    counts = {k: np.array([fr.extras[k].shape[0] if k in fr.extras else 0 for fr in flist], dtype=np.int64)
+              for k in EXTRA_KINDS}
+    if any(c.sum() for c in counts.values()):
+        off = np.zeros(F + 1, dtype=np.int64)
+        chunks = []
+        for i, fr in enumerate(flist):
+            tot = 0
+            for k in EXTRA_KINDS:
+                if k in fr.extras:
+                    chunks.append(fr.extras[k]); tot += fr.extras[k].shape[0]
+            off[i + 1] = off[i] + tot
+        g.extra_off = off
+        g.extra = np.ascontiguousarray(np.concatenate(chunks, axis=0))
+    g.meta["extra_counts"] = counts
+    g.meta["aortic_thickness"] = [fr.aortic for fr in flist]
+    g.meta["pulmonary_thickness"] = [fr.pulmonary for fr in flist]
+    return g
