@@ -348,8 +348,8 @@ def test_refine_grid_costs_and_selection(engine, oracle, mm):
     t = np.arange(m) * (2 * math.pi / m)
     frames = [np.stack([1.5 * np.cos(t) * (1 + 0.1 * np.sin(3 * t + k)), 1.2 * np.sin(t), np.full(m, 0.5 * k)], 1)
               for k in range(n_frames)]
-    cloud = np.concatenate([f + rng.normal(0, 0.03, f.shape) for f in frames] +
-                           [rng.uniform(-12, 12, size=(4000, 3))])                 # wall points + far clutter
+    clutter = rng.uniform(7.0, 12.0, size=(4000, 3)) * rng.choice([-1.0, 1.0], size=(4000, 3))
+    cloud = np.concatenate([f + rng.normal(0, 0.01, f.shape) for f in frames] + [clutter])  # wall points + far clutter
     angles = mm.refine_angles(0.0, math.radians(8.0), math.radians(1.0))
     cands, sets = [], []
     for delta in range(-2, 3):
@@ -368,7 +368,9 @@ def test_refine_grid_costs_and_selection(engine, oracle, mm):
     costs, first = engine.hausdorff_batch(sets)
     ocosts, ofirst = oracle.refine_select(sets)
     assert np.array_equal(costs, ocosts)
-    assert first == ofirst and cands[first][0] == 0 and abs(cands[first][1]) < 1e-9
+    assert first == ofirst
+    assert len(sets[0][0]) == n_frames * m              # the box filter dropped exactly the clutter
+    assert cands[first][0] == 0 and abs(cands[first][1]) < 1e-9 and costs[first] < 0.1
 
 
 def test_hausdorff_batch_large_and_swapped_sets(engine, oracle):
