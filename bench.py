@@ -41,27 +41,27 @@ FLOPS_PER_PAIR_EVAL = 6.0         # 2 sub, 2 mul, 1 add, 1 min
 BYTES_PER_POSE_EVAL = lambda na, nb: (na + nb) * 2 * 4 + 8   # SURVEY 8(d) no-reuse model
 
 
-def between_stage(mm, eng, geoms, cfg):
+def between_stage(mm, eng, geoms, cfg, precision=1):
     """AB | CD then AC | BD (entry.rs:206-277)."""
     a, b, c, d = geoms
-    r1, e1 = mm.align_between(eng, [(a, b), (c, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"])
-    r2, e2 = mm.align_between(eng, [(a, c), (b, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"])
+    r1, e1 = mm.align_between(eng, [(a, b), (c, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], precision)
+    r2, e2 = mm.align_between(eng, [(a, c), (b, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], precision)
     return np.concatenate([r1, r2]), e1 + e2
 
 
-def full_alignment(mm, eng, geoms, cfg, plan=None):
+def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     """One 4-phase alignment (entry.rs:140-277 order); returns (logs, between angles, pose_evals).
     plan = a pre-staged mm.WithinPlan (decoupled mode, point sets already in HBM) or None
     (faithful per-step chain)."""
     if plan is None:
         logs, evals = mm.align_within(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                                      precision=mm.MM_PRECISION_F32, mode=0)
+                                      precision=precision, mode=0)
         unresolved = 0
     else:
         t0 = time.perf_counter()
         logs, evals, unresolved = plan.run()
         t1 = time.perf_counter()
-    rot, e2 = between_stage(mm, eng, geoms, cfg)
+    rot, e2 = between_stage(mm, eng, geoms, cfg, precision)
     if plan is not None and os.environ.get("MM_TRACE"):
         print(f"[bench trace] within {1e3 * (t1 - t0):.3f} ms, between {1e3 * (time.perf_counter() - t1):.3f} ms",
               file=sys.stderr)
@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
+    ap.add_argument("--precision", default="fast", choices=["f32", "fast", "f64"],
+                    help="candidate scoring: f32 = direct-form f32 screen + exact f64 re-score; fast = expanded-form "
+                         "f32 screen + exact f64 re-score (default); f64 = every candidate in exact f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the CPU baseline (default: the GPU box's CPU share per GPU, 16, or fewer cores)")
@@ -141,6 +144,7 @@ def main():
 
     cfg = WORKLOADS[args.workload]
     mode = 0 if args.mode == "chain" else 1
+    PREC = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "f64": mm.MM_PRECISION_F64}[args.precision]
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
     eng = mm.Engine(local_rank)
 
@@ -160,7 +164,7 @@ def main():
         cases.append(geoms)
         plan = None
         if mode == 1:
-            plan = mm.WithinPlan(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"])
+            plan = mm.WithinPlan(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"], precision=PREC)
             if world > 1:
                 plan.set_shard(rank, world)
         plans.append(plan)
@@ -172,9 +176,9 @@ def main():
         k = next(it)
         geoms = cases[k]
         if world == 1:
-            return full_alignment(mm, eng, geoms, cfg, plans[k])
+            return full_alignment(mm, eng, geoms, cfg, plans[k], PREC)
         logs, evals, unres = plans[k].run_sharded()
-        rot, e2 = between_stage(mm, eng, geoms, cfg)
+        rot, e2 = between_stage(mm, eng, geoms, cfg, PREC)
         return logs, rot, evals + e2, unres
 
     def barrier():
@@ -230,7 +234,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 screen + f64 exact re-score",
+            "dtype": {"f32": "f32 screen (direct form) + f64 exact re-score", "fast": "f32 screen (expanded form) + f64 exact re-score",
+                      "f64": "f64"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: full 4-phase alignment, 4 pullbacks x {cfg['frames']} frames x "
                                    f"{cfg['points']} pts (N={na} pts/set), {cfg['step_deg']} deg x +-{cfg['range_deg']} deg "
@@ -241,7 +246,8 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
-                "kernel": "mm::k_search<float,33,16,false,false>", "launches": prof["launches"],
+                "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33>",
+                           "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "note": "point-set min/max metric: bounded by fp32 VALU issue (SURVEY 8(d)), not HBM/MFMA; "
                         "achieved = pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every launch)",

@@ -10,7 +10,7 @@ package directory name contains a hyphen.
 from __future__ import annotations
 
 from . import _native
-from ._native import (MM_PRECISION_F32, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine, Plan,
+from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_FAST, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine, Plan,
                       device_count, filter_points_in_region, refine_angles, refine_downsample_count, search_angles)
 from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
                        contour_centroid, search_set)
@@ -31,5 +31,5 @@ __all__ = [
     "InputData", "Record", "numpy_to_inputdata", "build_geometry_from_inputdata", "process_directory",
     "GeometryPair", "align_frames_in_geometries",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
-    "MM_PRECISION_F32", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
+    "MM_PRECISION_F32", "MM_PRECISION_F32_FAST", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

@@ -22,6 +22,7 @@ struct PairDesc {
     double  cx, cy;           // rotation centre (exact kernel)
     double  delta;            // f32 screening error bound (same unit as the costs)
     double  tol2;             // candidates within tol2 of the exact minimum are reported as near-ties
+    double  e2;               // absolute error bound of the screened SQUARED value (fast kernel; else 0)
 };
 
 // One workgroup's share: `cnt` consecutive candidates of one pair.
@@ -60,6 +61,9 @@ struct BatchDev {
 // Launchers (mm_kernels.hip).  All asynchronous on `s`.
 struct KernelConfig { int r; int nli; size_t lds; };
 hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
+hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
+int        max_rows_fast();
+int        max_target_points_fast();
 hipError_t launch_exact_all(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_shortlist(const BatchDev& b, hipStream_t s);
 hipError_t launch_rescore(const BatchDev& b, int max_na, int max_nbp, int total_candidates, hipStream_t s);

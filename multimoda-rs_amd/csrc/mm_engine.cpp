@@ -157,8 +157,8 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     want_costs = want_costs_;
     slice_end = angle_end;
     P = (int)pairs.size();
-    if (precision != MM_PRECISION_F64 && precision != MM_PRECISION_F32)
-        return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64 or MM_PRECISION_F32");
+    if (precision != MM_PRECISION_F64 && precision != MM_PRECISION_F32 && precision != MM_PRECISION_F32_FAST)
+        return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64, MM_PRECISION_F32 or MM_PRECISION_F32_FAST");
     if (angle_begin < 0) angle_begin = 0;
 
     host_pairs.assign(P, PairDesc{});
@@ -188,8 +188,12 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         d.flags = sp.flags;
         d.cx = sp.cx; d.cy = sp.cy;
         d.tol2 = sp.tie_tol;
-        d.delta = (precision == MM_PRECISION_F32)
+        d.delta = (precision != MM_PRECISION_F64)
                       ? screen_delta(set_rho[sp.ref_set], set_rho[sp.tgt_set]) + sp.delta_extra : 0.0;
+        {   // expanded-form screening: |d2_f32 - d2| <= 5 u (rho_a + rho_b)^2; we use 8 u (..)^2
+            const double rs = set_rho[sp.ref_set] + set_rho[sp.tgt_set];
+            d.e2 = (precision == MM_PRECISION_F32_FAST) ? 8.0 * 5.9604644775390625e-08 * rs * rs : 0.0;
+        }
         if (nr == 0 || nt == 0) {
             // process_utils.rs:86-88: an empty set makes every cost 0.0 -> the first candidate wins;
             // nothing to launch for this pair (one table entry keeps its first angle).
@@ -217,7 +221,11 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         if (A > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 candidates");
     }
     T = (int64_t)host_tables.size();
-    if (max_nbp > max_target_points_f64() || (precision == MM_PRECISION_F32 && max_nbp > max_target_points_f32()))
+    // the fast screening kernel keeps one row block in registers; bigger sets use the direct form
+    use_fast = (precision == MM_PRECISION_F32_FAST) && max_na <= max_rows_fast() && max_nbp <= max_target_points_fast();
+    if (precision == MM_PRECISION_F32_FAST && !use_fast)
+        for (PairDesc& d : host_pairs) d.e2 = 0.0;
+    if (max_nbp > max_target_points_f64() || (precision != MM_PRECISION_F64 && max_nbp > max_target_points_f32()))
         return set_error(MM_ERR_TOO_LARGE, "target set does not fit the kernel's LDS budget (" +
                                                std::to_string(max_target_points_f64()) + " points)");
 
@@ -295,9 +303,9 @@ int Plan::run(bool screen_only)
     }
     hipError_t e;
     int prc;
-    if (precision == MM_PRECISION_F32) {
+    if (precision != MM_PRECISION_F64) {
         if ((prc = eng->profile_begin())) return prc;
-        e = launch_screen_f32(dev, max_na, max_nbp, s);
+        e = use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s);
         if (e != hipSuccess) return hip_error(e, "screen kernel launch");
         if ((prc = eng->profile_end(pair_evals, A))) return prc;
         if (screen_only) return MM_OK;

@@ -83,6 +83,7 @@ struct Plan {
     std::vector<double> host_tables;          // distinct candidate lists (slice-local), dev tables mirror them
     std::vector<uint8_t> trivial;             // pair has an empty set: every cost is 0.0
     bool want_costs = false;
+    bool use_fast = false;                    // expanded-form screening kernel selected
 
     int stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient);
     int stage_level(const std::vector<PairSpec>& pairs, int precision, int32_t angle_begin, int32_t angle_end,

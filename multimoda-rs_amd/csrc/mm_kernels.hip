@@ -326,6 +326,162 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
 }
 
 // -------------------------------------------------------------------------------------
+// Fast f32 screening kernel (MM_PRECISION_F32_FAST): same lane grid and data flow as
+// k_search<float>, but the squared distance is evaluated in the expanded form
+//     d^2 = |a|^2 + (|b|^2 - 2 a.b) = A2 + fma(-2ax, bx, fma(-2ay, by, B2))
+// i.e. 2 v_pk_fma_f32 + 1 v_pk_add_f32 per two pair-distances instead of
+// 2 v_pk_add + 1 v_pk_mul + 1 v_pk_fma: 6 packed + 4 min3 per 2x2 micro-tile instead of 8 + 4.
+// The price is cancellation: |d2_f32 - d2| <= 5 u (rho_a + rho_b)^2 (u = 2^-24) instead of a
+// relative 2u, so the host widens the shortlist interval accordingly (PairDesc::e2) and the
+// exact f64 re-score still decides every winner.  Rounded results can be a few ulp below
+// zero; minima therefore use SIGNED integer order on the bit patterns (v_min3_i32): exact for
+// non-negative values, and any negative value is within the error bound of zero.
+// Single row block only (Na <= 16 R); larger reference sets use k_search.
+// -------------------------------------------------------------------------------------
+static __device__ __forceinline__ float imin3f(float a, float b, float c)
+{
+    int ia = __float_as_int(a), ib = __float_as_int(b), ic = __float_as_int(c);
+    int m = ia < ib ? ia : ib;
+    m = m < ic ? m : ic;
+    return __int_as_float(m);
+}
+static __device__ __forceinline__ float imin2f(float a, float b)
+{
+    int ia = __float_as_int(a), ib = __float_as_int(b);
+    return __int_as_float(ia < ib ? ia : ib);
+}
+template <int CTRL>
+static __device__ __forceinline__ int dpp_min_i32(int v)
+{
+    const int o = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, 0xF, 0xF, false);
+    return o < v ? o : v;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256, 3)
+k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
+              const float* __restrict__ ptx, const float* __restrict__ pty,
+              const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
+{
+    constexpr int NT = 256, NLI = 16;
+    constexpr int RP = R / 2;
+    constexpr bool ODD = (R & 1) != 0;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lj = tid & 15, li = tid >> 4;
+
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const WorkItem w = work[wi];
+        const PairDesc pd = pairs[w.pair];
+        const int na = pd.n_ref, nb = pd.n_tgt;
+        const int nbp = (nb + 15) & ~15;
+        const int ncg = nbp >> 4;
+
+        float4* s_b = reinterpret_cast<float4*>(smem);            // (bx, by, |b|^2, 0)
+        float2* s_tgt = reinterpret_cast<float2*>(s_b + nbp);
+        int* s_colmin = reinterpret_cast<int*>(s_tgt + nbp);
+        int* s_red = s_colmin + nbp;
+
+        __syncthreads();
+        for (int j = tid; j < nbp; j += NT) {
+            float2 t;
+            const int jc = j < nb ? j : nb - 1;   // padding columns duplicate the last point: they
+            t.x = ptx[pd.tgt_off + jc];            // cannot change a row minimum, and their own
+            t.y = pty[pd.tgt_off + jc];            // column minimum is never read
+            s_tgt[j] = t;
+        }
+        // rows: (-2ax, -2ay) and |a|^2; padding rows duplicate the last reference point, so they
+        // repeat its row minimum (max unchanged) and cannot lower any column minimum
+        v2f m2x[RP + 1], m2y[RP + 1], a2[RP + 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = r * NLI + li;
+            const int rc = row < na ? row : na - 1;
+            const float vx = ptx[pd.ref_off + rc], vy = pty[pd.ref_off + rc];
+            const float n2 = __builtin_fmaf(vx, vx, vy * vy);
+            if (r & 1) { m2x[r >> 1].y = -2.0f * vx; m2y[r >> 1].y = -2.0f * vy; a2[r >> 1].y = n2; }
+            else       { m2x[r >> 1].x = -2.0f * vx; m2y[r >> 1].x = -2.0f * vy; a2[r >> 1].x = n2; }
+        }
+
+        for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
+            const float c = cosv[pd.tab_off + a], s = sinv[pd.tab_off + a];
+            __syncthreads();  // S0
+            for (int j = tid; j < nbp; j += NT) {
+                const float2 t = s_tgt[j];
+                float4 b;
+                b.x = __builtin_fmaf(t.x, c, -(t.y * s));
+                b.y = __builtin_fmaf(t.x, s, t.y * c);
+                b.z = __builtin_fmaf(b.x, b.x, b.y * b.y);
+                b.w = 0.0f;
+                s_b[j] = b;
+                s_colmin[j] = 0x7f800000;
+            }
+            if (tid == 0) s_red[0] = 0;
+            __syncthreads();  // S1
+
+            float rmin[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) rmin[r] = __int_as_float(0x7f800000);
+
+            auto tile2 = [&](const float4 b0, const float4 b1, float& cm0, float& cm1) {
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                    const v2f t0 = __builtin_elementwise_fma(m2y[q], (v2f)(b0.y), (v2f)(b0.z));
+                    const v2f t1 = __builtin_elementwise_fma(m2y[q], (v2f)(b1.y), (v2f)(b1.z));
+                    const v2f e0 = __builtin_elementwise_fma(m2x[q], (v2f)(b0.x), t0);
+                    const v2f e1 = __builtin_elementwise_fma(m2x[q], (v2f)(b1.x), t1);
+                    const v2f d0 = e0 + a2[q];
+                    const v2f d1 = e1 + a2[q];
+                    rmin[2 * q]     = imin3f(rmin[2 * q], d0.x, d1.x);
+                    rmin[2 * q + 1] = imin3f(rmin[2 * q + 1], d0.y, d1.y);
+                    cm0 = imin3f(cm0, d0.x, d0.y);
+                    cm1 = imin3f(cm1, d1.x, d1.y);
+                }
+                if constexpr (ODD) {
+                    const float d0 = __builtin_fmaf(m2x[RP].x, b0.x, __builtin_fmaf(m2y[RP].x, b0.y, b0.z)) + a2[RP].x;
+                    const float d1 = __builtin_fmaf(m2x[RP].x, b1.x, __builtin_fmaf(m2y[RP].x, b1.y, b1.z)) + a2[RP].x;
+                    rmin[R - 1] = imin3f(rmin[R - 1], d0, d1);
+                    cm0 = imin2f(cm0, d0);
+                    cm1 = imin2f(cm1, d1);
+                }
+            };
+
+            int k = 0;
+            for (; k + 1 < ncg; k += 2) {
+                const float4 b0 = s_b[k * 16 + lj];
+                const float4 b1 = s_b[(k + 1) * 16 + lj];
+                float cm0 = __int_as_float(0x7f800000), cm1 = cm0;
+                tile2(b0, b1, cm0, cm1);
+                atomicMin(&s_colmin[k * 16 + lj], __float_as_int(cm0));
+                atomicMin(&s_colmin[(k + 1) * 16 + lj], __float_as_int(cm1));
+            }
+            if (k < ncg) {  // odd tail: the column group paired with itself
+                const float4 b0 = s_b[k * 16 + lj];
+                float cm0 = __int_as_float(0x7f800000), cmd = cm0;
+                tile2(b0, b0, cm0, cmd);
+                atomicMin(&s_colmin[k * 16 + lj], __float_as_int(cm0));
+            }
+
+            // rows: min over the 16 column lanes, then max over valid rows (floor 0)
+            int rowmax = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int v = __float_as_int(rmin[r]);
+                v = dpp_min_i32<0xB1>(v); v = dpp_min_i32<0x4E>(v); v = dpp_min_i32<0x141>(v); v = dpp_min_i32<0x140>(v);
+                rowmax = v > rowmax ? v : rowmax;
+            }
+            __syncthreads();  // S2
+            int m = rowmax;
+            for (int j = tid; j < nb; j += NT) { const int v = s_colmin[j]; m = v > m ? v : m; }
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
+            if ((tid & 63) == 0) atomicMax(&s_red[0], m);
+            __syncthreads();  // S3
+            if (tid == 0) out_sq[pd.out_off + a] = __int_as_float(s_red[0]);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // Shortlist: per pair, minimum screened cost and every candidate within 2*delta of it.
 // One 256-thread workgroup per pair.
 // -------------------------------------------------------------------------------------
@@ -346,11 +502,14 @@ k_shortlist(const PairDesc* __restrict__ pairs, const float* __restrict__ sq32,
     }
     atomicMin(&s_min, m);
     __syncthreads();
-    const double hmin = sqrt((double)__uint_as_float(s_min));
-    const double thr = hmin + 2.0 * pd.delta;
+    // A candidate stays if its smallest possible exact cost does not exceed the smallest
+    // upper bound: the screened squared value S is within e2 of the f32-exact one (e2 = 0 for
+    // the direct-form kernel) and the f32 representation costs at most delta on the distance.
+    const double smin = (double)__uint_as_float(s_min);
+    const double thr = sqrt(smin + pd.e2) + 2.0 * pd.delta;
     for (int a = tid; a < pd.n_ang; a += 256) {
-        const double h = sqrt((double)sq32[pd.out_off + a]);
-        const bool keep = h <= thr;
+        const double sv = (double)sq32[pd.out_off + a] - pd.e2;
+        const bool keep = sqrt(sv > 0.0 ? sv : 0.0) <= thr;
         flag[pd.out_off + a] = keep ? 1 : 0;
         if (keep) {
             const int slot = atomicAdd(n_items, 1);
@@ -483,6 +642,35 @@ hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStre
     if (max_na <= 16 * 33) return MM_F32(33, false);
     return MM_F32(32, true);
 #undef MM_F32
+}
+
+size_t lds_bytes_fast(int nbp) { return (size_t)nbp * (16 + 8 + 4) + 16; }
+int max_rows_fast() { return 16 * 33; }
+int max_target_points_fast() { return ((LDS_CAP - 16) / 28) & ~15; }
+
+template <int Rv>
+static hipError_t launch_fast_one(const BatchDev& b, size_t lds, hipStream_t s)
+{
+    auto kern = k_screen_fast<Rv>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y,
+                       b.cos32, b.sin32, b.sq32);
+    return hipGetLastError();
+}
+
+hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
+{
+    if (b.n_work <= 0) return hipSuccess;
+    const size_t lds = lds_bytes_fast(max_nbp);
+    if (max_na <= 16 * 8) return launch_fast_one<8>(b, lds, s);
+    if (max_na <= 16 * 14) return launch_fast_one<14>(b, lds, s);
+    if (max_na <= 16 * 20) return launch_fast_one<20>(b, lds, s);
+    if (max_na <= 16 * 26) return launch_fast_one<26>(b, lds, s);
+    return launch_fast_one<33>(b, lds, s);
 }
 
 template <bool FROM_QUEUE>

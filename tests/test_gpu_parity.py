@@ -383,3 +383,57 @@ def test_hausdorff_batch_large_and_swapped_sets(engine, oracle):
     assert np.array_equal(costs, ref) and first == int(np.argmin(ref))
     with pytest.raises(RuntimeError, match="LDS budget"):
         engine.hausdorff_batch([(rng.normal(size=(5000, 2)), rng.normal(size=(5000, 2)))])
+
+
+# ---------------------------------------------------------------------------------------
+# MM_PRECISION_F32_FAST: expanded-form screening kernel, same exactness contract
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,step,rng_deg", [(6, 1.0, 30.0), (100, 1.0, 180.0), (208, 0.5, 90.0), (320, 1.0, 180.0),
+                                            (416, 2.0, 180.0), (521, 0.5, 180.0), (528, 1.0, 90.0), (600, 2.0, 90.0)])
+def test_fast_screen_winner_bit_exact_and_interval(engine, oracle, mm, n, step, rng_deg):
+    rng = np.random.default_rng(3000 + n)
+    ref = blob(rng, n)
+    tgt = blob(rng, n) + rng.normal(0, 0.02, (n, 2))
+    c = ref.mean(axis=0)
+    centre = (float(c[0]), float(c[1]))
+    angles, _, _ = mm.search_angles(step, rng_deg)
+    bi, ba, bc, costs = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True,
+                                             precision=mm.MM_PRECISION_F32_FAST, return_costs=True)
+    ocosts = oracle.costs_over_angles(ref, tgt, angles, centre[0], centre[1])
+    obi = int(np.argmin(ocosts))
+    assert bi == obi and ba == angles[obi] and bc == ocosts[obi]
+    rho = np.hypot(*(ref - c).T).max() + np.hypot(*(tgt - c).T).max()
+    delta = 24 * U24 * rho
+    e2 = (8 * U24 * rho * rho) if n <= 528 else 0.0          # > 528 rows: the direct-form kernel is used
+    s = costs ** 2
+    lo = np.sqrt(np.maximum(s - e2, 0.0)) - delta
+    hi = np.sqrt(s + e2) + delta
+    assert np.all(lo <= ocosts * (1 + 1e-12)) and np.all(ocosts <= hi * (1 + 1e-12))   # stated tolerance of the fast screen
+    assert np.abs(costs - ocosts).max() < 5e-3
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", [(True, 1.0, 180.0, 501), (False, 0.05, 45.0, 200), (True, 0.5, 180.0, 500)])
+def test_fast_precision_chain_bit_identical(engine, oracle, mm, mode, bruteforce, step, rng_deg, ss):
+    geoms = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((8, 6, 7, 5))]
+    ogeoms = [to_oracle(oracle, g) for g in geoms]
+    logs, _ = mm.align_within(engine, geoms, step, rng_deg, bruteforce, ss, precision=mm.MM_PRECISION_F32_FAST, mode=mode)
+    for g, og, lg in zip(geoms, ogeoms, logs):
+        assert lg == oracle.align_within_chain(og, step, rng_deg, bruteforce, ss, n_threads=8)
+        assert geoms_equal(g, og)
+
+
+def test_fast_precision_ties_and_identical_sets(engine, oracle, mm):
+    """Cost ~ 0 (identical sets) is where the expanded form is least accurate: d^2 of order 1e-5 can
+    round below zero.  Winners must still be the reference's."""
+    t = np.arange(360) * (2 * math.pi / 360)
+    ref = np.stack([4.5 + 2 * np.cos(t) * (1 + 0.2 * np.cos(3 * t)), 4.5 + 2 * np.sin(t)], 1)
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    for tgt in (ref.copy(), np.roll(ref, 7, axis=0)):
+        oc = oracle.costs_over_angles(ref, tgt, angles, 4.5, 4.5)
+        out = engine.best_rotation(ref, tgt, angles, (4.5, 4.5), precision=mm.MM_PRECISION_F32_FAST)
+        assert out[0] == int(np.argmin(oc)) and out[2] == oc.min()
+    circ = np.stack([4.5 + 2 * np.cos(t), 4.5 + 2 * np.sin(t)], 1)
+    oc = oracle.costs_over_angles(circ, circ, angles, 4.5, 4.5)
+    out = engine.best_rotation(circ, circ, angles, (4.5, 4.5), precision=mm.MM_PRECISION_F32_FAST)
+    assert out[0] == int(np.argmin(oc)) and out[2] == oc.min()
