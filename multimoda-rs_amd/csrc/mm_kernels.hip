@@ -41,7 +41,6 @@ template <> struct Tr<float> {
     using T2 = float2;
     static __device__ __forceinline__ U bits(float v) { return __float_as_uint(v); }
     static __device__ __forceinline__ float from(U u) { return __uint_as_float(u); }
-    static __device__ __forceinline__ float big() { return 1.0e18f; }
     static __device__ __forceinline__ float inf() { return __uint_as_float(0x7f800000u); }
     static constexpr U INF_BITS = 0x7f800000u;
 };
@@ -50,7 +49,6 @@ template <> struct Tr<double> {
     using T2 = double2;
     static __device__ __forceinline__ U bits(double v) { return (U)__double_as_longlong(v); }
     static __device__ __forceinline__ double from(U u) { return __longlong_as_double((long long)u); }
-    static __device__ __forceinline__ double big() { return 1.0e150; }
     static __device__ __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000ll); }
     static constexpr U INF_BITS = 0x7ff0000000000000ull;
 };
@@ -172,23 +170,25 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
 
         __syncthreads();  // previous work item is done with LDS
         for (int j = tid; j < nbp; j += NT) {
+            // padding columns duplicate the last target point: a duplicate cannot change a row
+            // minimum, and its own column minimum is never read
+            const int jc = j < nb ? j : nb - 1;
             T2 t;
-            if (j < nb) { t.x = ptx[pd.tgt_off + j]; t.y = pty[pd.tgt_off + j]; }
-            else        { t.x = -TT::big();           t.y = -TT::big(); }
+            t.x = ptx[pd.tgt_off + jc]; t.y = pty[pd.tgt_off + jc];
             s_tgt[j] = t;
         }
 
-        // reference rows -> registers (row = rb*ROWS_PER_BLOCK + r*NLI + li); branch-free:
-        // out-of-range rows read a clamped address and are replaced by a far-away point.
+        // reference rows -> registers (row = rb*ROWS_PER_BLOCK + r*NLI + li); padding rows
+        // duplicate the last reference point: they repeat its row minimum (the max is unchanged)
+        // and cannot lower a column minimum -- no far-away sentinels, no validity tests.
         T ax[R], ay[R];
         auto load_rows = [&](int rb) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int row = rb * ROWS_PER_BLOCK + r * NLI + li;
                 const int rc = row < na ? row : na - 1;
-                const T vx = ptx[pd.ref_off + rc], vy = pty[pd.ref_off + rc];
-                ax[r] = row < na ? vx : TT::big();
-                ay[r] = row < na ? vy : TT::big();
+                ax[r] = ptx[pd.ref_off + rc];
+                ay[r] = pty[pd.ref_off + rc];
             }
         };
         if constexpr (!MULTI_RB) load_rows(0);
@@ -204,23 +204,19 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
             for (int j = tid; j < nbp; j += NT) {
                 const T2 t = s_tgt[j];
                 T2 b;
-                if (j < nb) {
-                    if constexpr (EXACT) {
-                        // contour_point.rs:39-52 / align_between.rs:194-206
-                        if (skip_zero && s == (T)0) {  // angle == 0.0  <=>  sin(angle) == 0 for f64
-                            b = t;
-                        } else {
-                            const T x = t.x - cx;
-                            const T y = t.y - cy;
-                            b.x = (x * c - y * s) + cx;
-                            b.y = (x * s + y * c) + cy;
-                        }
+                if constexpr (EXACT) {
+                    // contour_point.rs:39-52 / align_between.rs:194-206
+                    if (skip_zero && s == (T)0) {  // angle == 0.0  <=>  sin(angle) == 0 for f64
+                        b = t;
                     } else {
-                        b.x = __builtin_fmaf(t.x, c, -(t.y * s));
-                        b.y = __builtin_fmaf(t.x, s, t.y * c);
+                        const T x = t.x - cx;
+                        const T y = t.y - cy;
+                        b.x = (x * c - y * s) + cx;
+                        b.y = (x * s + y * c) + cy;
                     }
                 } else {
-                    b = t;  // padding stays far away
+                    b.x = __builtin_fmaf(t.x, c, -(t.y * s));
+                    b.y = __builtin_fmaf(t.x, s, t.y * c);
                 }
                 s_b[j] = b;
                 s_colmin[j] = TT::INF_BITS;
@@ -305,8 +301,7 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const T v = lane_min16(rmin[r]);
-                    const int row = rb * ROWS_PER_BLOCK + r * NLI + li;
-                    if (row < na && v > rowmax) rowmax = v;
+                    rowmax = v > rowmax ? v : rowmax;
                 }
             }
             __syncthreads();  // S2: all column minima are in LDS
