@@ -68,6 +68,28 @@ def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     return logs, rot, evals + e2, unresolved
 
 
+def committed_traffic(workload, precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/, tools/gpu_pmc.sh): FETCH_SIZE + WRITE_SIZE in KiB, raw (on gfx950 FETCH_SIZE can
+    under-report wide streaming reads by up to 2x; these are dword loads, uncalibrated).  bench.py
+    cannot run the profiler itself, so this is null unless a matching profile is committed."""
+    name = {("config3", "fast"): "r1_config3_fast_pmc_summary.csv", ("config3", "f32"): "r1_config3_pmc_summary.csv"}.get(
+        (workload, precision))
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
+        return None
+    import csv
+    tot, grid = {}, 0
+    for r in csv.DictReader(open(path)):
+        if r["kernel"].startswith(("k_screen_fast", "k_search<float")) and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            g = int(r["grid_threads"])
+            if g >= grid:
+                if g > grid:
+                    tot, grid = {}, g
+                tot[r["counter"]] = float(r["mean_value"]) * 1024.0
+    return sum(tot.values()) if len(tot) == 2 else None
+
+
 def cpu_baseline(cfg, geoms, threads, budget_s=10.0):
     """The CPU oracle (a port of the reference algorithm) timed on this box's host cores on a
     bounded sample of the same workload: the first frame pairs of pullback 0, all candidates,
@@ -245,12 +267,15 @@ def main():
                        "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU"},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                "traffic": committed_traffic(args.workload, args.precision),
                 "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33>",
                            "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "note": "point-set min/max metric: bounded by fp32 VALU issue (SURVEY 8(d)), not HBM/MFMA; "
-                        "achieved = pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every launch)",
+                        "achieved = pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every "
+                        "launch); traffic = HBM bytes per launch of the big launch (FETCH_SIZE+WRITE_SIZE, committed "
+                        "rocprofv3 --pmc passes in profiles/)",
                 "hbm": {"bound": "hbm", "achieved": algo_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_gbs / HBM_PEAK_GBS,
                         "note": "algorithmic no-reuse bytes ((Na+Nb)*8+8 per pose-eval) / kernel time"},
