@@ -288,12 +288,27 @@ def main():
                 avail = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(cfg, base, args.cpu_threads or min(avail, 16))
         if args.check:
+            # full-size parity: the whole 4-phase alignment of this workload through the CPU oracle
+            # (sequential chain, all candidates in f64), compared bit for bit with the last step
             from oracle import oracle as orc
-            from tests.helpers import to_oracle  # type: ignore
-            og = to_oracle(orc, base[0])
-            ol = orc.align_within_chain(og, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                                        n_threads=os.cpu_count() or 1)
-            out["check"] = {"pullback0_logs_identical": bool(res[0][0] == ol)}
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import to_oracle  # type: ignore
+            threads = args.cpu_threads or 16
+            t0c = time.perf_counter()
+            og = [to_oracle(orc, g) for g in base]
+            ologs = [orc.align_within_chain(o, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                            n_threads=threads) for o in og]
+            orot = [orc.align_between(og[i], og[j], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], n_threads=threads)
+                    for i, j in ((0, 1), (2, 3), (0, 2), (1, 3))]
+            last = cases[n_total - 1]
+            out["check"] = {
+                "within_logs_identical": bool(list(res[0]) == ologs),
+                "between_rotations_identical": bool(list(res[1]) == orot),
+                "all_coordinates_identical": bool(all(np.array_equal(g.lumen, o.lumen) and np.array_equal(g.cath, o.cath)
+                                                      and np.array_equal(g.centroids, o.centroids)
+                                                      for g, o in zip(last, og))),
+                "oracle_seconds": time.perf_counter() - t0c, "oracle_threads": threads,
+            }
         print(json.dumps(out))
     if world > 1:
         # every rank must have produced the same alignment (merged winners -> identical host walk)

@@ -27,6 +27,7 @@ import numpy as np
 
 from . import _native as N
 from . import geometry as G
+from ._libm import sincos
 from .io import EXTRA_KINDS, InputData, build_geometry_from_inputdata, sort_contour_points
 
 AlignLog = List[Tuple[int, int, float, float, float, float, float]]
@@ -140,7 +141,7 @@ def _angle_ref_point_to_right(g: G.FlatGeometry, ref_idx: int, anomalous: bool) 
 
     def rotate2(pt, center, angle):
         ddx, ddy = pt[0] - center[0], pt[1] - center[1]
-        c, s = math.cos(angle), math.sin(angle)
+        s, c = sincos(angle)
         return (ddx * c - ddy * s + center[0], ddx * s + ddy * c + center[1])
 
     center = (p1[0], p1[1])

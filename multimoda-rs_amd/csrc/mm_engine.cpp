@@ -263,7 +263,8 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     float *c32 = (float*)(h + o_c32), *s32 = (float*)(h + o_s32);
     double *c64 = (double*)(h + o_c64), *s64 = (double*)(h + o_s64);
     for (int64_t t = 0; t < T; ++t) {
-        const double co = std::cos(host_tables[(size_t)t]), si = std::sin(host_tables[(size_t)t]);
+        double co, si;
+        ::sincos(host_tables[(size_t)t], &si, &co);   // one glibc sincos, like the reference's per-point cos()/sin() pair
         c64[t] = co; s64[t] = si; c32[t] = (float)co; s32[t] = (float)si;
     }
     if (P) std::memcpy(h + o_pairs, host_pairs.data(), (size_t)P * sizeof(PairDesc));

@@ -32,6 +32,11 @@ struct TraceTimer {
     }
 };
 
+// cos and sin of the same angle: the reference computes both in one function, which LLVM on
+// x86_64-linux-gnu lowers to one glibc `sincos` call; sincos is not bit-identical to separate
+// sin()/cos() for every argument, so the pair is requested explicitly ("sincos").
+static inline void sin_cos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+
 static constexpr double kPi = 3.14159265358979323846264338327950288;
 
 static inline double deg2rad(double d) { return d * (kPi / 180.0); }  // f64::to_radians
@@ -103,7 +108,8 @@ static inline void rotate_xy(double& x, double& y, double angle, double cx, doub
     // contour_point.rs:38-52
     if (angle == 0.0) return;
     const double rx = x - cx, ry = y - cy;
-    const double co = std::cos(angle), si = std::sin(angle);
+    double co, si;
+    sin_cos(angle, si, co);
     x = rx * co - ry * si + cx;
     y = rx * si + ry * co + cy;
 }
@@ -118,7 +124,8 @@ static void span_rotate(double* p, int64_t lo, int64_t hi, double angle, double 
     // contour_point.rs:38-52 applied to a span; the reference evaluates cos/sin per point, with
     // the same argument every time -- hoisted here (identical values, ~40 ns saved per point)
     if (angle == 0.0) return;
-    const double co = std::cos(angle), si = std::sin(angle);
+    double co, si;
+    sin_cos(angle, si, co);
     for (int64_t k = lo; k < hi; ++k) {
         const double rx = p[3 * k] - cx, ry = p[3 * k + 1] - cy;
         p[3 * k] = rx * co - ry * si + cx;
@@ -617,7 +624,8 @@ void mm_frame_rotate(mm_geometry* g, int32_t i, double angle, double cx, double 
     if (g->extra_off) span_rotate(g->extra, g->extra_off[i], g->extra_off[i + 1], angle, cx, cy);
     if (g->has_ref && g->has_ref[i]) rotate_xy(g->ref[3 * i], g->ref[3 * i + 1], angle, cx, cy);
     const double x = g->centroid[3 * i] - cx, y = g->centroid[3 * i + 1] - cy;
-    const double co = std::cos(angle), si = std::sin(angle);
+    double co, si;
+    sin_cos(angle, si, co);
     g->centroid[3 * i] = x * co - y * si + cx;
     g->centroid[3 * i + 1] = x * si + y * co + cy;
 }
@@ -897,7 +905,8 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
         mm_geometry *A = a[p], *B = b[p];
         const double best = jobs[p].result;
         // :95-145 rotate the whole of B about A's reference-frame centroid (no shortcut)
-        const double co = std::cos(best), si = std::sin(best);
+        double co, si;
+        sin_cos(best, si, co);
         const double cx = a_ref[p][0], cy = a_ref[p][1];
         auto rot = [&](double& x, double& y) {
             const double tx = x - cx, ty = y - cy;

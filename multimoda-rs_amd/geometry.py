@@ -16,6 +16,8 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
+from ._libm import sincos
+
 from . import _native as N
 
 
@@ -44,8 +46,9 @@ def catheter_points(z: float, image_center=(4.5, 4.5), radius=0.5, n_points=20) 
     out = np.empty((n_points, 3), dtype=np.float64)
     for i in range(n_points):
         angle = 2.0 * math.pi * float(i) / float(n_points)
-        out[i, 0] = image_center[0] + radius * math.cos(angle)
-        out[i, 1] = image_center[1] + radius * math.sin(angle)
+        si, co = sincos(angle)                      # frame.rs:192-193: cos and sin of one value
+        out[i, 0] = image_center[0] + radius * co
+        out[i, 1] = image_center[1] + radius * si
         out[i, 2] = z
     return out
 

@@ -17,6 +17,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from ._libm import sincos
+
 from .geometry import FlatGeometry, contour_centroid
 
 RECORD_FILE_NAME = "combined_sorted_manual.csv"          # input.rs:12
@@ -186,8 +188,9 @@ def create_catheter_points(frame_z: Dict[int, float], image_center, radius: floa
         pts = np.empty((n_points, 3), dtype=np.float64)
         for i in range(n_points):
             angle = 2.0 * math.pi * float(i) / float(n_points)
-            pts[i, 0] = image_center[0] + radius * math.cos(angle)
-            pts[i, 1] = image_center[1] + radius * math.sin(angle)
+            si, co = sincos(angle)                  # frame.rs:192-193: cos and sin of one value
+            pts[i, 0] = image_center[0] + radius * co
+            pts[i, 1] = image_center[1] + radius * si
             pts[i, 2] = z
         out[frame] = pts
     return out

@@ -4,6 +4,7 @@
  * reference lines it follows (paths relative to the reference checkout).
  * Build: gcc -O2 -ffp-contract=off -fopenmp -fPIC -shared (see oracle/Makefile).
  */
+#define _GNU_SOURCE /* sincos */
 #include "mm_oracle.h"
 
 #include <math.h>
@@ -19,6 +20,14 @@
 /* f64::to_radians / to_degrees: one multiply by a pre-folded constant. */
 static double to_radians(double deg) { return deg * (ORC_PI / 180.0); }
 static double to_degrees(double rad) { return rad * (180.0 / ORC_PI); }
+
+/* Wherever the reference evaluates `angle.cos()` and `angle.sin()` of the same value in one
+ * function (contour_point.rs:45-46, frame.rs:58-59, align_between.rs:96-97,197-198), LLVM on
+ * x86_64-unknown-linux-gnu lowers the pair to ONE `sincos` libcall.  glibc's sincos is not
+ * bit-identical to separate sin()/cos() for every argument (1 ulp apart for some |x| > 2.4, seen
+ * at x = -23.17, -32.35, -67.66 ...), so the pair is requested explicitly here instead of being
+ * left to whatever this compiler's optimiser does with two calls. */
+static void sin_cos(double x, double* s, double* c) { sincos(x, s, c); }
 
 /* f64::rem_euclid */
 static double rem_euclid(double a, double m)
@@ -144,8 +153,8 @@ orc_point orc_rotate_point(orc_point p, double angle, double cx, double cy)
     if (angle == 0.0) return p;                               /* :39-41 */
     double x = p.x - cx;                                      /* :43 */
     double y = p.y - cy;                                      /* :44 */
-    double cos_a = cos(angle);
-    double sin_a = sin(angle);
+    double cos_a, sin_a;
+    sin_cos(angle, &sin_a, &cos_a);                           /* :45-46 */
     orc_point r = p;
     r.x = x * cos_a - y * sin_a + cx;                         /* :48 */
     r.y = x * sin_a + y * cos_a + cy;                         /* :49 */
@@ -183,8 +192,8 @@ double orc_cost_between(const orc_point* ref, size_t nr, const orc_point* tgt, s
                         double angle, double cx, double cy)
 {
     orc_point* rot = (orc_point*)malloc((nt + 1) * sizeof(orc_point));
-    double cos_angle = cos(angle);
-    double sin_angle = sin(angle);
+    double cos_angle, sin_angle;
+    sin_cos(angle, &sin_angle, &cos_angle);                   /* :197-198 */
     for (size_t i = 0; i < nt; ++i) {
         double translated_x = tgt[i].x - cx;                  /* :194 */
         double translated_y = tgt[i].y - cy;                  /* :195 */
@@ -305,8 +314,8 @@ void orc_frame_rotate(orc_geometry* g, int32_t i, double angle, double cx, doubl
     if (g->has_ref && g->has_ref[i]) g->ref[i] = orc_rotate_point(g->ref[i], angle, cx, cy); /* :53 */
     double x = g->centroid[3 * i + 0] - cx;                                         /* :56-57 */
     double y = g->centroid[3 * i + 1] - cy;
-    double cos_a = cos(angle);
-    double sin_a = sin(angle);
+    double cos_a, sin_a;
+    sin_cos(angle, &sin_a, &cos_a);                                                 /* :58-59 */
     g->centroid[3 * i + 0] = x * cos_a - y * sin_a + cx;                            /* :60 */
     g->centroid[3 * i + 1] = x * sin_a + y * cos_a + cy;                            /* :61 */
 }
@@ -434,8 +443,8 @@ size_t orc_extract_between_points(const orc_geometry* g, size_t sample_size,
 /* align_between.rs:95-145 rotate_geometry_around_point */
 static void rotate_geometry_around_point(orc_geometry* g, double angle_rad, double cx, double cy)
 {
-    double cos_angle = cos(angle_rad);
-    double sin_angle = sin(angle_rad);
+    double cos_angle, sin_angle;
+    sin_cos(angle_rad, &sin_angle, &cos_angle);               /* :96-97 */
 #define ROT_PT(X, Y) do { \
         double tx_ = (X) - cx, ty_ = (Y) - cy; \
         double rx_ = tx_ * cos_angle - ty_ * sin_angle; \

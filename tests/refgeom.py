@@ -6,7 +6,19 @@ from __future__ import annotations
 
 import math
 
+import ctypes
+
 import numpy as np
+
+_libm = ctypes.CDLL("libm.so.6")
+_libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+
+
+def sincos(x):
+    """one glibc sincos call (what the reference's cos()/sin() pair compiles to on linux-gnu)"""
+    s, c = ctypes.c_double(), ctypes.c_double()
+    _libm.sincos(float(x), ctypes.byref(s), ctypes.byref(c))
+    return s.value, c.value
 
 BASE6 = [(1.0, 3.0), (0.0, 2.0), (0.0, 0.0), (1.0, 0.0), (2.0, 0.0), (2.0, 2.0)]  # test_utils.rs:28-77
 
@@ -25,7 +37,7 @@ def rotate_pt(p, angle, c):
         return list(p)
     x = p[0] - c[0]
     y = p[1] - c[1]
-    ca, sa = math.cos(angle), math.sin(angle)
+    sa, ca = sincos(angle)
     return [x * ca - y * sa + c[0], x * sa + y * ca + c[1], p[2]]
 
 
@@ -62,7 +74,7 @@ class Fr:
             self.ref = rotate_pt(self.ref, angle, c)
         x = self.centroid[0] - c[0]
         y = self.centroid[1] - c[1]
-        ca, sa = math.cos(angle), math.sin(angle)
+        sa, ca = sincos(angle)
         self.centroid = [x * ca - y * sa + c[0], x * sa + y * ca + c[1], self.centroid[2]]
 
     def sort_points(self):  # contour.rs:368-405

@@ -108,3 +108,34 @@ def test_refine_helpers_match_oracle(built, mm, oracle):
     for nf, m, f in [(0, 501, 20), (1, 501, 20), (3000, 501, 20), (10020, 501, 20), (50000, 501, 20), (777, 200, 11)]:
         assert mm.refine_downsample_count(nf, m, f) == oracle.refine_downsample_count(nf, m, f)
     assert mm.refine_downsample_count(50000, 501, 20) == 501 and mm.refine_downsample_count(0, 501, 20) == 1
+
+
+def test_rotation_uses_one_sincos_call(built, mm, oracle):
+    """The reference's `angle.cos()` / `angle.sin()` pair compiles to ONE glibc `sincos` call on
+    x86_64-linux-gnu, and sincos differs from separate sin()/cos() by 1 ulp for some arguments
+    (found at config3 scale: cumulative chain rotations of -23.17, -32.35, -67.66, -85.02 rad).
+    Host C++ and oracle must both follow sincos, at exactly those arguments."""
+    import math
+    from multimoda_rs_amd._libm import sincos
+    args = [-23.169245820224717, -32.349677685714894, -67.65768845356021, -85.02371451090376, -142.50613342533705]
+    assert any((math.sin(a), math.cos(a)) != sincos(a) for a in args)      # the trap is real on this libm
+    g = mm.synthetic_pullback(len(args) + 1, 64, pullback_id=3)
+    og = to_oracle(oracle, g)
+    s = g.c_struct()
+    L = mm._native.lib()
+    for i, a in enumerate(args):
+        cx, cy = float(g.centroids[i + 1, 0]) + 0.3, float(g.centroids[i + 1, 1]) - 0.2
+        L.mm_frame_rotate(C.byref(s), i + 1, a, cx, cy)
+        oracle.frame_rotate(og, i + 1, a, cx, cy)
+        si, co = sincos(a)
+        x, y = g.frame_lumen(0)[0, 0], g.frame_lumen(0)[0, 1]
+    for arr, oarr in ((g.lumen, og.lumen), (g.cath, og.cath), (g.centroids, og.centroids)):
+        assert np.array_equal(arr, oarr)
+    # and the result is the sincos one, not the sin()/cos() one
+    base = mm.synthetic_pullback(len(args) + 1, 64, pullback_id=3)
+    for i, a in enumerate(args):
+        cx, cy = float(base.centroids[i + 1, 0]) + 0.3, float(base.centroids[i + 1, 1]) - 0.2
+        si, co = sincos(a)
+        p = base.frame_lumen(i + 1)
+        ex = (p[:, 0] - cx) * co - (p[:, 1] - cy) * si + cx
+        assert np.array_equal(g.frame_lumen(i + 1)[:, 0], ex)
