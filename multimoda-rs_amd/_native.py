@@ -5,6 +5,7 @@ when an :class:`Engine` is created, this module raises.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import weakref
@@ -68,6 +69,20 @@ class MMAlignLog(C.Structure):
 
 
 _lib = None
+_engines = weakref.WeakSet()
+
+
+def _close_all_engines():
+    """Interpreter shutdown: release plans and engines while the HIP runtime is still alive
+    (destructors running after its teardown abort the process)."""
+    for e in list(_engines):
+        try:
+            e.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all_engines)
 
 
 def lib():
@@ -289,6 +304,7 @@ class Engine:
         self._h = C.c_void_p()
         check(lib().mm_engine_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)),
               "mm_engine_create")
+        _engines.add(self)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
