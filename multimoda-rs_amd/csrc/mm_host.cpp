@@ -869,18 +869,25 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
         if (ia >= (size_t)A->n_frames || ib >= (size_t)B->n_frames)
             return set_error(MM_ERR_REF_INDEX, "reference frame index out of range");
     }
-    // the pairs are independent (the reference runs them in a crossbeam scope, entry.rs:206-277)
+    // The pairs are independent (the reference runs them in a crossbeam scope, entry.rs:206-277).
+    // The reference makes three passes over B: translate (:40), rotate (:50), translate (:68).
+    // Per coordinate these are the same roundings in the same order whether done as three passes
+    // or one, so the search sets are built from the original frames plus the first translation
+    // (the only thing the search needs) and the three steps are fused into ONE pass afterwards,
+    // split over a few threads per pair.
+    std::vector<std::array<double, 3>> t1(n_pairs);
     auto prep = [&](int p) {
         mm_geometry *A = a[p], *B = b[p];
         const size_t ia = ref_or_proximal(A), ib = ref_or_proximal(B);
         a_ref[p] = {A->centroid[3 * ia], A->centroid[3 * ia + 1], A->centroid[3 * ia + 2]};
-        const double dx = a_ref[p][0] - B->centroid[3 * ib], dy = a_ref[p][1] - B->centroid[3 * ib + 1],
-                     dz = a_ref[p][2] - B->centroid[3 * ib + 2];                    // :33-37
-        for (int32_t i = 0; i < B->n_frames; ++i) mm_frame_translate(B, i, dx, dy, dz);  // :40
+        t1[p] = {a_ref[p][0] - B->centroid[3 * ib], a_ref[p][1] - B->centroid[3 * ib + 1],
+                 a_ref[p][2] - B->centroid[3 * ib + 2]};                             // :33-37
         const int64_t s = std::max<int64_t>(sample_size, 500);                      // :43-44
         SearchJob& job = jobs[p];
         between_points(A, s, job.rx, job.ry);
         between_points(B, s, job.tx, job.ty);
+        for (double& v : job.tx) v += t1[p][0];                                      // :40 on the sampled points
+        for (double& v : job.ty) v += t1[p][1];
         // :260-271 centroid of the reference sample
         double sx = 0.0, sy = 0.0;
         for (double v : job.rx) sx += v;
@@ -888,12 +895,7 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
         if (!job.rx.empty()) { job.cx = sx / (double)job.rx.size(); job.cy = sy / (double)job.rx.size(); }
         job.flags = 0;  // no angle==0 shortcut in this closure (:194-209)
     };
-    {
-        std::vector<std::thread> th;
-        for (int p = 1; p < n_pairs; ++p) th.emplace_back(prep, p);
-        prep(0);
-        for (std::thread& t : th) t.join();
-    }
+    for (int p = 0; p < n_pairs; ++p) prep(p);
     int rc;
     {
         TraceTimer t("between: searches");
@@ -901,35 +903,55 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
     }
     if (rc) return rc;
     TraceTimer t2("between: apply");
-    auto apply = [&](int p) {
+    struct Motion { double dx, dy, dz, co, si, cx, cy, fx, fy, fz; };
+    std::vector<Motion> mo(n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
         mm_geometry *A = a[p], *B = b[p];
-        const double best = jobs[p].result;
-        // :95-145 rotate the whole of B about A's reference-frame centroid (no shortcut)
-        double co, si;
-        sin_cos(best, si, co);
-        const double cx = a_ref[p][0], cy = a_ref[p][1];
-        auto rot = [&](double& x, double& y) {
-            const double tx = x - cx, ty = y - cy;
-            const double rx = tx * co - ty * si, ry = tx * si + ty * co;
-            x = rx + cx; y = ry + cy;
-        };
-        for (int32_t i = 0; i < B->n_frames; ++i) {
-            for (int64_t k = B->lumen_off[i]; k < B->lumen_off[i + 1]; ++k) rot(B->lumen[3 * k], B->lumen[3 * k + 1]);
-            rot(B->centroid[3 * i], B->centroid[3 * i + 1]);
-            if (B->cath_off) for (int64_t k = B->cath_off[i]; k < B->cath_off[i + 1]; ++k) rot(B->cath[3 * k], B->cath[3 * k + 1]);
-            if (B->extra_off) for (int64_t k = B->extra_off[i]; k < B->extra_off[i + 1]; ++k) rot(B->extra[3 * k], B->extra[3 * k + 1]);
-            if (B->has_ref && B->has_ref[i]) rot(B->ref[3 * i], B->ref[3 * i + 1]);
+        Motion& m = mo[p];
+        m.dx = t1[p][0]; m.dy = t1[p][1]; m.dz = t1[p][2];
+        sin_cos(jobs[p].result, m.si, m.co);                                         // :96-97
+        m.cx = a_ref[p][0]; m.cy = a_ref[p][1];
+        // the final translation needs B's reference-frame centroid after translate + rotate (:53-66)
+        const size_t ia = ref_or_proximal(A), ib = ref_or_proximal(B);
+        double bx = B->centroid[3 * ib] + m.dx, by = B->centroid[3 * ib + 1] + m.dy, bz = B->centroid[3 * ib + 2] + m.dz;
+        {
+            const double tx = bx - m.cx, ty = by - m.cy;
+            const double rx = tx * m.co - ty * m.si, ry = tx * m.si + ty * m.co;
+            bx = rx + m.cx; by = ry + m.cy;
         }
-        const size_t ia = ref_or_proximal(A), ib = ref_or_proximal(B);  // :53-58
-        const double fx = A->centroid[3 * ia] - B->centroid[3 * ib], fy = A->centroid[3 * ia + 1] - B->centroid[3 * ib + 1],
-                     fz = A->centroid[3 * ia + 2] - B->centroid[3 * ib + 2];  // :60-66
-        for (int32_t i = 0; i < B->n_frames; ++i) mm_frame_translate(B, i, fx, fy, fz);  // :68
-        if (best_rotation) best_rotation[p] = best;
+        m.fx = A->centroid[3 * ia] - bx; m.fy = A->centroid[3 * ia + 1] - by; m.fz = A->centroid[3 * ia + 2] - bz;
+        if (best_rotation) best_rotation[p] = jobs[p].result;
+    }
+    auto move_frames = [&](int p, int32_t f0, int32_t f1) {
+        mm_geometry* B = b[p];
+        const Motion m = mo[p];
+        auto mv = [&](double* q) {
+            double x = q[0] + m.dx, y = q[1] + m.dy, z = q[2] + m.dz;                // :40   Frame::translate
+            const double tx = x - m.cx, ty = y - m.cy;                               // :100-107 rotate_point
+            const double rx = tx * m.co - ty * m.si, ry = tx * m.si + ty * m.co;
+            x = rx + m.cx; y = ry + m.cy;
+            q[0] = x + m.fx; q[1] = y + m.fy; q[2] = z + m.fz;                       // :68   Frame::translate
+        };
+        for (int32_t i = f0; i < f1; ++i) {
+            for (int64_t k = B->lumen_off[i]; k < B->lumen_off[i + 1]; ++k) mv(B->lumen + 3 * k);
+            mv(B->centroid + 3 * i);
+            if (B->cath_off) for (int64_t k = B->cath_off[i]; k < B->cath_off[i + 1]; ++k) mv(B->cath + 3 * k);
+            if (B->extra_off) for (int64_t k = B->extra_off[i]; k < B->extra_off[i + 1]; ++k) mv(B->extra + 3 * k);
+            if (B->has_ref && B->has_ref[i]) mv(B->ref + 3 * i);
+        }
     };
     {
+        // a few threads per pair; small geometries stay on the calling thread
         std::vector<std::thread> th;
-        for (int p = 1; p < n_pairs; ++p) th.emplace_back(apply, p);
-        apply(0);
+        for (int p = 0; p < n_pairs; ++p) {
+            const int32_t F = b[p]->n_frames;
+            const int parts = F >= 64 ? 4 : 1;
+            for (int q = 0; q < parts; ++q) {
+                const int32_t f0 = (int32_t)((int64_t)F * q / parts), f1 = (int32_t)((int64_t)F * (q + 1) / parts);
+                if (p == n_pairs - 1 && q == parts - 1) move_frames(p, f0, f1);
+                else th.emplace_back(move_frames, p, f0, f1);
+            }
+        }
         for (std::thread& t : th) t.join();
     }
     return MM_OK;
