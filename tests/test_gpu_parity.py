@@ -437,3 +437,32 @@ def test_fast_precision_ties_and_identical_sets(engine, oracle, mm):
     oc = oracle.costs_over_angles(circ, circ, angles, 4.5, 4.5)
     out = engine.best_rotation(circ, circ, angles, (4.5, 4.5), precision=mm.MM_PRECISION_F32_FAST)
     assert out[0] == int(np.argmin(oc)) and out[2] == oc.min()
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_near_ties_between_neighbouring_candidates(engine, oracle, mm, precision):
+    """Adversarial for the screen-then-exact scheme: the true rotation sits (almost) exactly between
+    two grid candidates, so their costs differ by ~1e-9 .. 1e-5 -- far below the f32 screening error.
+    Every precision mode must return the oracle's first minimum and its exact cost."""
+    rng = np.random.default_rng(77)
+    angles, _, _ = mm.search_angles(0.5, 180.0)
+    refs, tgts, cs = [], [], []
+    for p in range(48):
+        ref = blob(rng, 300 + 7 * p)
+        k = int(rng.integers(5, 700))
+        eps = [0.0, 1e-9, -1e-9, 1e-6, -1e-6, 1e-4][p % 6]
+        th = -(0.5 * (angles[k] + angles[k + 1]) + eps)
+        c, s_ = math.cos(th), math.sin(th)
+        rel = ref - 4.5
+        tgt = np.stack([rel[:, 0] * c - rel[:, 1] * s_, rel[:, 0] * s_ + rel[:, 1] * c], 1) + 4.5
+        refs.append(ref); tgts.append(tgt); cs.append((4.5, 4.5))
+    batch = mm.Batch(refs, tgts, [angles] * len(refs), cs, [1] * len(refs))
+    out = engine.best_rotation_batch(batch, precision=precision)
+    n_close = 0
+    for p, (r, t) in enumerate(zip(refs, tgts)):
+        oc = oracle.costs_over_angles(r, t, angles, 4.5, 4.5)
+        k = int(np.argmin(oc))
+        assert out["best_idx"][p] == k and out["best_cost"][p] == oc[k]
+        srt = np.sort(oc)
+        n_close += int(srt[1] - srt[0] < 1e-6)
+    assert n_close >= 8     # the scenario really produces near-ties
