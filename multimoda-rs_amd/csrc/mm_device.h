@@ -64,6 +64,12 @@ hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStre
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 int        max_rows_fast();
 int        max_target_points_fast();
+// large-set Hausdorff (no LDS limit on the set sizes); pairs/work are device arrays of the kernel's
+// LargePair {a_off, na, b_off, nb, col_off, pad} / LargeWork {pair, row0} records
+hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pairs, int n_work, const double* px,
+                                  const double* py, void* colmin, long long n_col, void* rowmax, double* out,
+                                  hipStream_t s);
+int        large_rows_per_block();
 hipError_t launch_exact_all(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_shortlist(const BatchDev& b, hipStream_t s);
 hipError_t launch_rescore(const BatchDev& b, int max_na, int max_nbp, int total_candidates, hipStream_t s);

@@ -422,6 +422,59 @@ static void scatter_costs(const Plan& plan, const double* plan_costs, const int6
     }
 }
 
+// Pairs whose sets both exceed the search kernel's LDS budget: streaming kernel, sets uploaded
+// as given (f64), row blocks of one pair spread over the device.
+struct LargePairH { int32_t a_off, na, b_off, nb, col_off, pad; };
+struct LargeWorkH { int32_t pair, row0; };
+
+int hausdorff_large(Engine* e, const std::vector<int>& idx, const int64_t* a_off, const double* ax, const double* ay,
+                    const int64_t* b_off, const double* bx, const double* by, double* out)
+{
+    const int P = (int)idx.size();
+    std::vector<LargePairH> hp(P);
+    std::vector<LargeWorkH> hw;
+    int64_t npts = 0, ncol = 0;
+    const int rpb = large_rows_per_block();
+    for (int k = 0; k < P; ++k) {
+        const int p = idx[k];
+        const int64_t na = a_off[p + 1] - a_off[p], nb = b_off[p + 1] - b_off[p];
+        hp[k] = LargePairH{(int32_t)npts, (int32_t)na, (int32_t)(npts + na), (int32_t)nb, (int32_t)ncol, 0};
+        npts += na + nb; ncol += nb;
+        if (npts > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
+        for (int64_t r0 = 0; r0 < na; r0 += rpb) hw.push_back(LargeWorkH{k, (int32_t)r0});
+    }
+    const size_t o_px = 0, o_py = align_up((size_t)npts * 8), o_pairs = align_up(o_py + (size_t)npts * 8);
+    const size_t o_work = align_up(o_pairs + (size_t)P * sizeof(LargePairH));
+    const size_t in_bytes = align_up(o_work + hw.size() * sizeof(LargeWorkH));
+    const size_t o_col = in_bytes, o_row = align_up(o_col + (size_t)ncol * 8), o_out = align_up(o_row + (size_t)P * 8);
+    const size_t total = align_up(o_out + (size_t)P * 8);
+    int rc = e->ensure(e->host_pts, in_bytes, true);
+    if (rc) return rc;
+    if ((rc = e->ensure(e->dev_pts, total, false))) return rc;
+    unsigned char* h = (unsigned char*)e->host_pts.p;
+    double *hx = (double*)(h + o_px), *hy = (double*)(h + o_py);
+    for (int k = 0; k < P; ++k) {
+        const int p = idx[k];
+        std::memcpy(hx + hp[k].a_off, ax + a_off[p], (size_t)hp[k].na * 8);
+        std::memcpy(hy + hp[k].a_off, ay + a_off[p], (size_t)hp[k].na * 8);
+        std::memcpy(hx + hp[k].b_off, bx + b_off[p], (size_t)hp[k].nb * 8);
+        std::memcpy(hy + hp[k].b_off, by + b_off[p], (size_t)hp[k].nb * 8);
+    }
+    std::memcpy(h + o_pairs, hp.data(), (size_t)P * sizeof(LargePairH));
+    std::memcpy(h + o_work, hw.data(), hw.size() * sizeof(LargeWorkH));
+    unsigned char* d = (unsigned char*)e->dev_pts.p;
+    MM_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, e->stream));
+    hipError_t he = launch_hausdorff_large(d + o_pairs, d + o_work, P, (int)hw.size(), (const double*)(d + o_px),
+                                           (const double*)(d + o_py), d + o_col, ncol, d + o_row, (double*)(d + o_out),
+                                           e->stream);
+    if (he != hipSuccess) return hip_error(he, "large-set hausdorff launch");
+    std::vector<double> res(P);
+    MM_HIP(hipMemcpyAsync(res.data(), d + o_out, (size_t)P * 8, hipMemcpyDeviceToHost, e->stream));
+    MM_HIP(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < P; ++k) out[idx[k]] = res[k];
+    return MM_OK;
+}
+
 }  // namespace mm
 
 // =====================================================================================
@@ -577,6 +630,9 @@ int mm_best_rotation(mm_engine* h, const double* rx, const double* ry, int nr,
     return MM_OK;
 }
 
+int mm_hausdorff_batch(mm_engine* h, int n_pairs, const int64_t* a_off, const double* ax, const double* ay,
+                       const int64_t* b_off, const double* bx, const double* by, double* out, int32_t* first_min);
+
 int mm_hausdorff_2d(mm_engine* h, const double* ax, const double* ay, int na,
                     const double* bx, const double* by, int nb, double* out)
 {
@@ -584,14 +640,8 @@ int mm_hausdorff_2d(mm_engine* h, const double* ax, const double* ay, int na,
     if (!h) return set_error(MM_ERR_INVALID, "engine == NULL");
     if (na < 0 || nb < 0) return set_error(MM_ERR_INVALID, "negative set size");
     if (na == 0 || nb == 0) { *out = 0.0; return MM_OK; }  // process_utils.rs:86-88
-    const double zero = 0.0;
-    double cost = NAN;
-    // angle 0 with the rotate() shortcut leaves the target untouched -> plain hausdorff_distance
-    int rc = mm_best_rotation(h, ax, ay, na, bx, by, nb, 0.0, 0.0, &zero, 1, MM_SEARCH_SKIP_ZERO,
-                              MM_PRECISION_F64, nullptr, &cost, nullptr, nullptr);
-    if (rc) return rc;
-    *out = cost;
-    return MM_OK;
+    const int64_t ao[2] = {0, na}, bo[2] = {0, nb};
+    return mm_hausdorff_batch(h, 1, ao, ax, ay, bo, bx, by, out, nullptr);
 }
 
 int mm_hausdorff_batch(mm_engine* h, int n_pairs, const int64_t* a_off, const double* ax, const double* ay,
@@ -605,10 +655,12 @@ int mm_hausdorff_batch(mm_engine* h, int n_pairs, const int64_t* a_off, const do
     MM_HIP(hipSetDevice(e->device));
     static const double zero = 0.0;
     std::vector<SetRef> sets; std::vector<PairSpec> pairs;
+    std::vector<int> small_idx, large_idx;
     const int cap = max_target_points_f64();
     for (int p = 0; p < n_pairs; ++p) {
         const int64_t na = a_off[p + 1] - a_off[p], nb = b_off[p + 1] - b_off[p];
         if (na < 0 || nb < 0 || na > INT32_MAX || nb > INT32_MAX) return set_error(MM_ERR_INVALID, "bad set extent");
+        if (na > cap && nb > cap) { large_idx.push_back(p); continue; }   // neither side fits LDS: streaming kernel
         SetRef A{ax + a_off[p], ay + a_off[p], (int32_t)na, 0.0, 0.0}, B{bx + b_off[p], by + b_off[p], (int32_t)nb, 0.0, 0.0};
         // hausdorff_distance is symmetric bit for bit (max of the two directed terms over the same
         // squared distances): put the smaller set on the LDS-staged (target) side if the other one
@@ -619,16 +671,22 @@ int mm_hausdorff_batch(mm_engine* h, int n_pairs, const int64_t* a_off, const do
         sets.push_back(swap ? A : B);
         // angle 0 with the rotate() shortcut leaves the target untouched
         pairs.push_back(PairSpec{sid, sid + 1, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, &zero, 1, 0.0, 0.0});
+        small_idx.push_back(p);
     }
-    BatchResult res;
-    int rc = run_batch(e, sets, pairs, MM_PRECISION_F64, res);
-    if (rc) return rc;
+    if (!pairs.empty()) {
+        BatchResult res;
+        int rc = run_batch(e, sets, pairs, MM_PRECISION_F64, res);
+        if (rc) return rc;
+        for (size_t k = 0; k < small_idx.size(); ++k) out[small_idx[k]] = res.best_cost[k];
+    }
+    if (!large_idx.empty()) {
+        int rc = hausdorff_large(e, large_idx, a_off, ax, ay, b_off, bx, by, out);
+        if (rc) return rc;
+    }
     int32_t best = -1;
     double best_cost = INFINITY;   // f64::MAX in the reference; costs are finite
-    for (int p = 0; p < n_pairs; ++p) {
-        out[p] = res.best_cost[p];
+    for (int p = 0; p < n_pairs; ++p)
         if (out[p] < best_cost) { best_cost = out[p]; best = p; }
-    }
     if (first_min) *first_min = best;
     return MM_OK;
 }

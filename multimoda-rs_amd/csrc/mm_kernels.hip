@@ -593,6 +593,124 @@ k_finalize(const PairDesc* __restrict__ pairs, const double* __restrict__ sq64,
 }
 
 // -------------------------------------------------------------------------------------
+// Large-set Hausdorff (f64, exact, no rotation): for point sets whose target side does not
+// fit the search kernel's LDS budget (e.g. the 10^3..10^4-point CCTA clouds of
+// refine_alignment_hausdorff, align_algorithms.rs:400-431).  One workgroup = (pair, block of
+// 16*R reference rows); the target columns stream through LDS in chunks, so any Nb works, and
+// the row blocks of ONE pair spread over many CUs.  Row minima are complete inside a workgroup
+// (it sees every column); column minima are combined across row blocks with 64-bit integer
+// atomics in global memory (squared distances are >= +0: integer order == f64 order).
+// -------------------------------------------------------------------------------------
+struct LargePair {
+    int32_t a_off, na, b_off, nb;   // into the f64 point pool
+    int32_t col_off;                // into the global column-minimum array
+    int32_t pad;
+};
+struct LargeWork { int32_t pair, row0; };
+
+__global__ void __launch_bounds__(256)
+k_large_init(unsigned long long* __restrict__ colmin, long long n_col, unsigned long long* __restrict__ rowmax, int n_pairs)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_col) colmin[i] = 0x7ff0000000000000ull;
+    if (i < n_pairs) rowmax[i] = 0ull;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restrict__ work,
+                  const double* __restrict__ px, const double* __restrict__ py,
+                  unsigned long long* __restrict__ g_colmin, unsigned long long* __restrict__ g_rowmax)
+{
+    constexpr int NT = 256, NLI = 16, CH = 1024;
+    __shared__ double2 s_b[CH];
+    __shared__ unsigned long long s_colmin[CH];
+    __shared__ unsigned long long s_red;
+    const int tid = threadIdx.x, lj = tid & 15, li = tid >> 4;
+    const LargeWork w = work[blockIdx.x];
+    const LargePair pd = pairs[w.pair];
+    const int na = pd.na, nb = pd.nb;
+
+    double ax[R], ay[R], rmin[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {   // padding rows duplicate the last point (see k_search)
+        const int row = w.row0 + r * NLI + li;
+        const int rc = row < na ? row : na - 1;
+        ax[r] = px[pd.a_off + rc]; ay[r] = py[pd.a_off + rc];
+        rmin[r] = __longlong_as_double(0x7ff0000000000000ll);
+    }
+    if (tid == 0) s_red = 0ull;
+
+    for (int c0 = 0; c0 < nb; c0 += CH) {
+        const int n = nb - c0 < CH ? nb - c0 : CH;
+        const int np = (n + 15) & ~15;
+        __syncthreads();
+        for (int j = tid; j < np; j += NT) {
+            const int jc = j < n ? j : n - 1;
+            s_b[j] = make_double2(px[pd.b_off + c0 + jc], py[pd.b_off + c0 + jc]);
+            s_colmin[j] = 0x7ff0000000000000ull;
+        }
+        __syncthreads();
+        for (int k = 0; k < (np >> 4); ++k) {
+            const double2 b0 = s_b[k * 16 + lj];
+            double cm = __longlong_as_double(0x7ff0000000000000ll);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double dx = ax[r] - b0.x, dy = ay[r] - b0.y;   // process_utils.rs:105-107
+                const double d = dx * dx + dy * dy;
+                rmin[r] = dmin2(rmin[r], d);
+                cm = dmin2(cm, d);
+            }
+            atomicMin(&s_colmin[k * 16 + lj], (unsigned long long)__double_as_longlong(cm));
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) atomicMin(&g_colmin[pd.col_off + c0 + j], s_colmin[j]);
+    }
+    double rowmax = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double v = lane_min16(rmin[r]);
+        rowmax = v > rowmax ? v : rowmax;
+    }
+    rowmax = wave_max(rowmax);
+    if ((tid & 63) == 0) atomicMax(&s_red, (unsigned long long)__double_as_longlong(rowmax));
+    __syncthreads();
+    if (tid == 0) atomicMax(&g_rowmax[w.pair], s_red);
+}
+
+__global__ void __launch_bounds__(256)
+k_large_finish(const LargePair* __restrict__ pairs, const unsigned long long* __restrict__ g_colmin,
+               const unsigned long long* __restrict__ g_rowmax, double* __restrict__ out)
+{
+    __shared__ unsigned long long s_red;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const LargePair pd = pairs[p];
+    if (tid == 0) s_red = g_rowmax[p];
+    __syncthreads();
+    unsigned long long m = 0ull;
+    for (int j = tid; j < pd.nb; j += 256) { const unsigned long long v = g_colmin[pd.col_off + j]; m = v > m ? v : m; }
+    atomicMax(&s_red, m);
+    __syncthreads();
+    if (tid == 0) out[p] = sqrt(__longlong_as_double((long long)s_red));   // process_utils.rs:120, :81
+}
+
+hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pairs, int n_work, const double* px,
+                                  const double* py, void* colmin, long long n_col, void* rowmax, double* out,
+                                  hipStream_t s)
+{
+    const long long n_init = n_col > n_pairs ? n_col : n_pairs;
+    hipLaunchKernelGGL(k_large_init, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s,
+                       (unsigned long long*)colmin, n_col, (unsigned long long*)rowmax, n_pairs);
+    if (n_work > 0)
+        hipLaunchKernelGGL(k_hausdorff_large<8>, dim3(n_work), dim3(256), 0, s, (const LargePair*)pairs,
+                           (const LargeWork*)work, px, py, (unsigned long long*)colmin, (unsigned long long*)rowmax);
+    hipLaunchKernelGGL(k_large_finish, dim3(n_pairs), dim3(256), 0, s, (const LargePair*)pairs,
+                       (const unsigned long long*)colmin, (const unsigned long long*)rowmax, out);
+    return hipGetLastError();
+}
+int large_rows_per_block() { return 16 * 8; }
+
+// -------------------------------------------------------------------------------------
 // launch helpers
 // -------------------------------------------------------------------------------------
 static constexpr int LDS_CAP = 160 * 1024 - 256;

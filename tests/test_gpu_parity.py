@@ -47,11 +47,13 @@ def test_hausdorff_random_bit_exact(engine, oracle, na, nb):
     assert engine.hausdorff(b, a) == oracle.hausdorff(b, a)
 
 
-def test_hausdorff_too_large_is_an_error(engine):
+def test_search_target_set_beyond_lds_budget_is_an_error(engine, mm):
+    """A rotation SEARCH stages the rotated target in LDS (f64 re-score: 4080 points); beyond that
+    it fails loudly.  The plain metric has no such limit (streaming kernel, next tests)."""
     a = np.zeros((8, 2))
-    b = np.zeros((5000, 2))
+    b = np.zeros((9000, 2))
     with pytest.raises(RuntimeError, match="LDS budget"):
-        engine.hausdorff(a, b)
+        engine.best_rotation(a, b, np.array([0.0, 0.1]), (0.0, 0.0))
 
 
 # ---------------------------------------------------------------------------------------
@@ -381,8 +383,19 @@ def test_hausdorff_batch_large_and_swapped_sets(engine, oracle):
     costs, first = engine.hausdorff_batch(pairs)
     ref = np.array([oracle.hausdorff(a, b) for a, b in pairs])
     assert np.array_equal(costs, ref) and first == int(np.argmin(ref))
-    with pytest.raises(RuntimeError, match="LDS budget"):
-        engine.hausdorff_batch([(rng.normal(size=(5000, 2)), rng.normal(size=(5000, 2)))])
+
+
+def test_hausdorff_both_sets_beyond_lds_budget_streaming_kernel(engine, oracle):
+    """Both sets larger than the LDS budget (CCTA-cloud sized, align_algorithms.rs:400-431): the
+    streaming kernel splits the rows of one pair over many workgroups and chunks the columns."""
+    rng = np.random.default_rng(12)
+    pairs = [(rng.normal(4.5, 2.0, size=(5000, 2)), rng.normal(4.6, 2.1, size=(4100, 2))),
+             (rng.normal(size=(12345, 2)), rng.normal(size=(10001, 2)) * 1.1),
+             (rng.normal(size=(40, 2)), rng.normal(size=(33, 2)))]
+    costs, first = engine.hausdorff_batch(pairs)
+    ref = np.array([oracle.hausdorff(a, b) for a, b in pairs])
+    assert np.array_equal(costs, ref) and first == int(np.argmin(ref))
+    assert engine.hausdorff(pairs[1][1], pairs[1][0]) == ref[1]
 
 
 # ---------------------------------------------------------------------------------------
