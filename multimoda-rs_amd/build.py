@@ -32,6 +32,20 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
+    # several ranks may import at once (torch.distributed.run): one builds, the others wait
+    import fcntl
+    os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"

@@ -28,7 +28,13 @@ def build(force: bool = False) -> str:
         os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
     )
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "libmm_oracle.so"], stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:   # ranks of one node build once
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "libmm_oracle.so"], stdout=subprocess.DEVNULL)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
