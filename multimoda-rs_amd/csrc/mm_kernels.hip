@@ -762,9 +762,10 @@ int max_rows_fast() { return 16 * 33; }
 int max_target_points_fast() { return ((LDS_CAP - 16) / 28) & ~15; }
 
 template <int Rv>
-static hipError_t launch_fast_one(const BatchDev& b, size_t lds, hipStream_t s)
+static hipError_t launch_fast_r(const BatchDev& b, int max_nbp, hipStream_t s)
 {
     auto kern = k_screen_fast<Rv>;
+    const size_t lds = lds_bytes_fast(max_nbp);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -778,12 +779,11 @@ static hipError_t launch_fast_one(const BatchDev& b, size_t lds, hipStream_t s)
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
 {
     if (b.n_work <= 0) return hipSuccess;
-    const size_t lds = lds_bytes_fast(max_nbp);
-    if (max_na <= 16 * 8) return launch_fast_one<8>(b, lds, s);
-    if (max_na <= 16 * 14) return launch_fast_one<14>(b, lds, s);
-    if (max_na <= 16 * 20) return launch_fast_one<20>(b, lds, s);
-    if (max_na <= 16 * 26) return launch_fast_one<26>(b, lds, s);
-    return launch_fast_one<33>(b, lds, s);
+    if (max_na <= 16 * 8) return launch_fast_r<8>(b, max_nbp, s);
+    if (max_na <= 16 * 14) return launch_fast_r<14>(b, max_nbp, s);
+    if (max_na <= 16 * 20) return launch_fast_r<20>(b, max_nbp, s);
+    if (max_na <= 16 * 26) return launch_fast_r<26>(b, max_nbp, s);
+    return launch_fast_r<33>(b, max_nbp, s);
 }
 
 template <bool FROM_QUEUE>
