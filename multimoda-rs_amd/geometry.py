@@ -53,6 +53,38 @@ def catheter_points(z: float, image_center=(4.5, 4.5), radius=0.5, n_points=20) 
     return out
 
 
+class AlignLogs(Sequence):
+    """The AlignLog records of one pullback (align_within.rs:14-22) as the reference returns them to
+    Python: a sequence of 7-tuples ``(id, matched_to, rot_deg, tx, ty, cx, cy)``
+    (binding/functions.rs:26-40).  The tuples are materialised on first access; the C buffer the
+    host code wrote is kept as is until then."""
+
+    def __init__(self, buf, n: int):
+        self._buf, self._n, self._list = buf, n, None
+
+    def tolist(self):
+        if self._list is None:
+            b = self._buf
+            self._list = [(b[i].contour_id, b[i].matched_to, b[i].rot_deg, b[i].tx, b[i].ty, b[i].cx, b[i].cy)
+                          for i in range(self._n)]
+        return self._list
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return self.tolist()[i]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __eq__(self, other):
+        return self.tolist() == (other.tolist() if isinstance(other, AlignLogs) else list(other))
+
+    def __repr__(self):
+        return repr(self.tolist())
+
+
 @dataclass
 class FlatGeometry:
     ids: np.ndarray                      # (F,) u32  Frame.id
@@ -181,8 +213,7 @@ def align_within(engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: floa
     N.check(N.lib().mm_align_within(engine.handle, G, C.cast(gptrs, C.c_void_p), float(step_deg), float(range_deg),
                                     int(bool(bruteforce)), int(sample_size), int(precision), int(mode),
                                     C.cast(lptrs, C.c_void_p), C.byref(pe)), "mm_align_within")
-    logs = [[(l.contour_id, l.matched_to, l.rot_deg, l.tx, l.ty, l.cx, l.cy) for l in b[: g.n_frames - 1]]
-            for b, g in zip(log_bufs, geoms)]
+    logs = [AlignLogs(b, g.n_frames - 1) for b, g in zip(log_bufs, geoms)]
     return logs, int(pe.value)
 
 
@@ -212,8 +243,7 @@ class WithinPlan:
         pe, nu = C.c_int64(0), C.c_int64(0)
         N.check(N.lib().mm_within_plan_run(self._h, C.cast(lptrs, C.c_void_p), C.byref(pe), C.byref(nu)),
                 "mm_within_plan_run")
-        logs = [[(l.contour_id, l.matched_to, l.rot_deg, l.tx, l.ty, l.cx, l.cy) for l in b[: g.n_frames - 1]]
-                for b, g in zip(log_bufs, self.geoms)]
+        logs = [AlignLogs(b, g.n_frames - 1) for b, g in zip(log_bufs, self.geoms)]
         return logs, int(pe.value), int(nu.value)
 
     # -- candidate axis sharded over ranks (one process per GPU) ---------------------------
@@ -249,8 +279,7 @@ class WithinPlan:
         pe, nu = C.c_int64(0), C.c_int64(0)
         N.check(N.lib().mm_within_plan_walk(self._h, C.cast(lptrs, C.c_void_p), C.byref(pe), C.byref(nu)),
                 "mm_within_plan_walk")
-        logs = [[(l.contour_id, l.matched_to, l.rot_deg, l.tx, l.ty, l.cx, l.cy) for l in b[: g.n_frames - 1]]
-                for b, g in zip(log_bufs, self.geoms)]
+        logs = [AlignLogs(b, g.n_frames - 1) for b, g in zip(log_bufs, self.geoms)]
         return logs, int(pe.value), int(nu.value)
 
     def run_sharded(self, group=None):
