@@ -200,10 +200,6 @@ def _f64(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def _i64(a) -> np.ndarray:
-    return np.ascontiguousarray(a, dtype=np.int64)
-
-
 def _xy(a) -> np.ndarray:
     """array-like of points -> (n, >=2) f64 array ((0, 2) when empty)."""
     a = np.asarray(a, dtype=np.float64)

@@ -59,7 +59,6 @@ struct BatchDev {
 };
 
 // Launchers (mm_kernels.hip).  All asynchronous on `s`.
-struct KernelConfig { int r; int nli; size_t lds; };
 hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 int        max_rows_fast();
@@ -78,6 +77,5 @@ size_t     lds_bytes_f32(int nbp);
 size_t     lds_bytes_f64(int nbp);
 int        max_target_points_f32();
 int        max_target_points_f64();
-const char* screen_kernel_name();
 
 }  // namespace mm

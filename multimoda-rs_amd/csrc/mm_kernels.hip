@@ -719,7 +719,6 @@ size_t lds_bytes_f32(int nbp) { return (size_t)nbp * (8 + 8 + 4) + 16; }
 size_t lds_bytes_f64(int nbp) { return (size_t)nbp * (16 + 16 + 8) + 16; }
 int max_target_points_f32() { return ((LDS_CAP - 16) / 20) & ~15; }
 int max_target_points_f64() { return ((LDS_CAP - 16) / 40) & ~15; }
-const char* screen_kernel_name() { return "k_search<float"; }
 
 template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB>
 static hipError_t launch_one(const BatchDev& b, const WorkItem* work, int n_work, const int* n_work_dev,
