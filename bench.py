@@ -34,6 +34,9 @@ WORKLOADS = {
     "config2": dict(frames=128, points=501, step_deg=1.0, range_deg=180.0, sample_size=501),
     "config3": dict(frames=512, points=501, step_deg=0.5, range_deg=180.0, sample_size=501),
     "tiny": dict(frames=12, points=501, step_deg=2.0, range_deg=180.0, sample_size=501),
+    # EXTENSION axis (absent from the reference's 4-phase path): every frame against a
+    # window of 100 neighbouring frames x 721 rotations; reported separately, never as the headline
+    "config3ext": dict(frames=512, points=501, step_deg=0.5, range_deg=180.0, sample_size=501, shift=(-50, 49)),
 }
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (vector)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md, HBM3E peak
@@ -181,7 +184,15 @@ def main():
     n_total = args.warmup + args.steps
     t_stage0 = time.perf_counter()
     cases, plans = [], []
-    for _ in range(n_total):
+    ext = cfg.get("shift")
+    if ext is not None:
+        if world > 1:
+            raise SystemExit("config3ext is a single-GPU workload")
+        for _ in range(n_total):
+            plans.append(mm.ShiftRotationSearch(eng, base, ext[0], ext[1], cfg["step_deg"], cfg["range_deg"],
+                                                cfg["sample_size"], precision=PREC))
+            cases.append(base)
+    for _ in range(0 if ext is not None else n_total):
         geoms = [g.copy() for g in base]
         cases.append(geoms)
         plan = None
@@ -197,6 +208,9 @@ def main():
     def one_step():
         k = next(it)
         geoms = cases[k]
+        if ext is not None:
+            r = plans[k].run()
+            return r["winners"], None, plans[k].pose_evals, 0
         if world == 1:
             return full_alignment(mm, eng, geoms, cfg, plans[k], PREC)
         logs, evals, unres = plans[k].run_sharded()
@@ -259,7 +273,10 @@ def main():
             "dtype": {"f32": "f32 screen (direct form) + f64 exact re-score", "fast": "f32 screen (expanded form) + f64 exact re-score",
                       "f64": "f64"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: full 4-phase alignment, 4 pullbacks x {cfg['frames']} frames x "
+            "config": {"workload": (f"{args.workload}: EXTENSION (not in the reference's 4-phase path) rotation x frame-shift "
+                                    f"grid, 4 pullbacks x {cfg['frames']} frames x {cfg['points']} pts, shifts {ext[0]}..{ext[1]} x "
+                                    f"{cfg['step_deg']} deg x +-{cfg['range_deg']} deg") if ext is not None else
+                                   f"{args.workload}: full 4-phase alignment, 4 pullbacks x {cfg['frames']} frames x "
                                    f"{cfg['points']} pts (N={na} pts/set), {cfg['step_deg']} deg x +-{cfg['range_deg']} deg "
                                    f"bruteforce grid", "mode": args.mode, "pose_evals_per_step": evals // max(args.steps, 1),
                        "chain_steps_researched_on_chain_state": unresolved,

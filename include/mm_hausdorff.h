@@ -160,6 +160,19 @@ int  mm_plan_create(mm_engine* e, int n_pairs,
                     const double* cx, const double* cy, const int32_t* flags,
                     int precision, int32_t angle_begin, int32_t angle_end,
                     mm_plan** out);
+/* The same with the point sets given once and referenced by index: pair p searches reference
+ * set ref_set[p] against target set tgt_set[p] (a set may serve any number of pairs, e.g. every
+ * frame of a pullback against a window of neighbouring frames).  Set s is x/y[set_off[s] ..
+ * set_off[s+1]); its f32 copy is taken relative to (set_cx[s], set_cy[s]), which must equal the
+ * rotation centre of every pair that uses it.  shared_angles != 0: every pair uses the one
+ * candidate list angles[0 .. ang_off[1]) (ang_off has 2 entries).  want_costs != 0 keeps the
+ * per-candidate costs for mm_plan_fetch(all_costs). */
+int  mm_plan_create_indexed(mm_engine* e, int n_sets, const int64_t* set_off, const double* x,
+                            const double* y, const double* set_cx, const double* set_cy,
+                            int n_pairs, const int32_t* ref_set, const int32_t* tgt_set,
+                            const int64_t* ang_off, const double* angles, int shared_angles,
+                            const double* cx, const double* cy, const int32_t* flags,
+                            int precision, int want_costs, mm_plan** out);
 void mm_plan_destroy(mm_plan* p);
 /* Enqueue the whole search (screen -> shortlist -> exact re-score -> argmin) on the
  * engine's stream; asynchronous. */

@@ -10,7 +10,8 @@ package directory name contains a hyphen.
 from __future__ import annotations
 
 from . import _native
-from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_FAST, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine, Plan,
+from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_FAST, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine,
+                      IndexedBatch, Plan,
                       device_count, filter_points_in_region, refine_angles, refine_downsample_count, search_angles)
 from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
                        contour_centroid, search_set)
@@ -18,6 +19,7 @@ from .io import InputData, Record, build_geometry_from_inputdata, numpy_to_input
 from .api import (GeometryPair, align_frames_in_geometries, from_array_doublepair, from_array_full,
                   from_array_single, from_array_singlepair, from_file_doublepair, from_file_full,
                   from_file_single, from_file_singlepair)
+from .extension import ShiftRotationSearch
 from .synth import synthetic_case, synthetic_pullback
 
 __version__ = "0.1.0"
@@ -30,6 +32,7 @@ __all__ = [
     "from_array_full", "from_array_doublepair", "from_array_singlepair", "from_array_single",
     "InputData", "Record", "numpy_to_inputdata", "build_geometry_from_inputdata", "process_directory",
     "GeometryPair", "align_frames_in_geometries",
+    "ShiftRotationSearch",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F32_FAST", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

@@ -27,7 +27,7 @@ EXPORTS = [
     "mm_engine_profile", "mm_engine_profile_read",
     "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
     "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
-    "mm_plan_create", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
+    "mm_plan_create", "mm_plan_create_indexed", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
     "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy",
     "mm_within_plan_set_shard", "mm_within_plan_dims", "mm_within_plan_level_local", "mm_within_plan_level_commit",
@@ -133,6 +133,8 @@ def lib():
     L.mm_best_rotation_batch.argtypes = batch_args + [P, P, P, P, P]
     L.mm_plan_create.restype = I
     L.mm_plan_create.argtypes = batch_args + [I32, I32, C.POINTER(P)]
+    L.mm_plan_create_indexed.restype = I
+    L.mm_plan_create_indexed.argtypes = [P, I, P, P, P, P, P, I, P, P, P, P, I, P, P, P, I, I, C.POINTER(P)]
     L.mm_plan_destroy.restype = None
     L.mm_plan_destroy.argtypes = [P]
     L.mm_plan_run.restype = I
@@ -413,14 +415,48 @@ class Engine:
         return Plan(self, batch, precision, angle_begin, angle_end)
 
 
+class IndexedBatch:
+    """Point sets given once, pairs referencing them by index, one shared candidate list
+    (``mm_plan_create_indexed``)."""
+
+    def __init__(self, sets: Sequence[np.ndarray], set_centres, ref_set, tgt_set, angles, flags=None):
+        arrs = [_xy(s) for s in sets]
+        self.n_sets = len(arrs)
+        self.set_off = np.zeros(self.n_sets + 1, dtype=np.int64)
+        self.set_off[1:] = np.cumsum([a.shape[0] for a in arrs])
+        self.x = _f64(np.concatenate([a[:, 0] for a in arrs])) if arrs else np.zeros(0)
+        self.y = _f64(np.concatenate([a[:, 1] for a in arrs])) if arrs else np.zeros(0)
+        c = np.asarray(set_centres, dtype=np.float64).reshape(self.n_sets, 2)
+        self.set_cx, self.set_cy = _f64(c[:, 0]), _f64(c[:, 1])
+        self.ref_set = np.ascontiguousarray(ref_set, dtype=np.int32)
+        self.tgt_set = np.ascontiguousarray(tgt_set, dtype=np.int32)
+        self.n_pairs = int(self.ref_set.shape[0])
+        self.angles = _f64(angles)
+        self.ang_off = np.array([0, len(self.angles)], dtype=np.int64)
+        self.cx = _f64(self.set_cx[self.tgt_set])       # pair centre = centre of its sets
+        self.cy = _f64(self.set_cy[self.tgt_set])
+        self.flags = np.ascontiguousarray(np.zeros(self.n_pairs, dtype=np.int32) if flags is None
+                                          else np.asarray(flags, dtype=np.int32))
+
+
 class Plan:
     """Device-resident batch (``mm_plan``): upload once, run many times."""
 
-    def __init__(self, engine: Engine, batch: Batch, precision, angle_begin, angle_end):
+    def __init__(self, engine: Engine, batch, precision, angle_begin=0, angle_end=2**31 - 1, want_costs=True):
         self.engine = engine
         self.batch = batch
         self._h = C.c_void_p()
         engine._children.add(self)
+        if isinstance(batch, IndexedBatch):
+            b = batch
+            check(lib().mm_plan_create_indexed(engine.handle, b.n_sets, _ptr(b.set_off), _ptr(b.x), _ptr(b.y),
+                                               _ptr(b.set_cx), _ptr(b.set_cy), b.n_pairs, _ptr(b.ref_set),
+                                               _ptr(b.tgt_set), _ptr(b.ang_off), _ptr(b.angles), 1, _ptr(b.cx),
+                                               _ptr(b.cy), _ptr(b.flags), precision, int(bool(want_costs)),
+                                               C.byref(self._h)), "mm_plan_create_indexed")
+            self._n_costs = b.n_pairs * len(b.angles)
+            return
+        self._n_costs = int(batch.ang_off[-1])
         check(lib().mm_plan_create(engine.handle, *batch._args(), precision, int(angle_begin), int(angle_end),
                                    C.byref(self._h)), "mm_plan_create")
 
@@ -445,7 +481,7 @@ class Plan:
         bang = np.zeros(n, dtype=np.float64)
         bcost = np.zeros(n, dtype=np.float64)
         nres = np.zeros(n, dtype=np.int32)
-        costs = np.full(int(self.batch.ang_off[-1]), np.nan, dtype=np.float64) if return_costs else None
+        costs = np.full(self._n_costs, np.nan, dtype=np.float64) if return_costs else None
         check(lib().mm_plan_fetch(self._h, _ptr(bidx), _ptr(bang), _ptr(bcost), _ptr(nres), _ptr(costs)),
               "mm_plan_fetch")
         out = {"best_idx": bidx, "best_angle": bang, "best_cost": bcost, "n_rescored": nres}

@@ -721,6 +721,45 @@ int mm_plan_create(mm_engine* h, int n_pairs,
     return MM_OK;
 }
 
+int mm_plan_create_indexed(mm_engine* h, int n_sets, const int64_t* set_off, const double* x, const double* y,
+                           const double* set_cx, const double* set_cy, int n_pairs, const int32_t* ref_set,
+                           const int32_t* tgt_set, const int64_t* ang_off, const double* angles, int shared_angles,
+                           const double* cx, const double* cy, const int32_t* flags, int precision, int want_costs,
+                           mm_plan** out)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e || !out) return set_error(MM_ERR_INVALID, "engine/out == NULL");
+    *out = nullptr;
+    if (n_sets < 0 || n_pairs < 0) return set_error(MM_ERR_INVALID, "negative counts");
+    MM_HIP(hipSetDevice(e->device));
+    std::vector<SetRef> sets((size_t)n_sets);
+    for (int s = 0; s < n_sets; ++s) {
+        const int64_t n = set_off[s + 1] - set_off[s];
+        if (n < 0 || n > INT32_MAX) return set_error(MM_ERR_INVALID, "bad set extent");
+        sets[s] = SetRef{x + set_off[s], y + set_off[s], (int32_t)n, set_cx[s], set_cy[s]};
+    }
+    std::vector<PairSpec> pairs((size_t)n_pairs);
+    PlanHandle* ph = new PlanHandle();
+    ph->ang_off.resize((size_t)n_pairs + 1);
+    for (int p = 0; p < n_pairs; ++p) {
+        const int64_t a0 = shared_angles ? ang_off[0] : ang_off[p], a1 = shared_angles ? ang_off[1] : ang_off[p + 1];
+        if (a1 < a0 || a1 - a0 > INT32_MAX) { delete ph; return set_error(MM_ERR_INVALID, "bad candidate extent"); }
+        pairs[p] = PairSpec{ref_set[p], tgt_set[p], cx[p], cy[p], flags ? flags[p] : 0, angles + a0, (int32_t)(a1 - a0), 0.0, 0.0};
+        ph->ang_off[p] = shared_angles ? (int64_t)p * (a1 - a0) : a0;   // all_costs layout: pair-major
+    }
+    if (n_pairs > 0) {
+        const int64_t a0 = shared_angles ? ang_off[0] : ang_off[n_pairs - 1], a1 = shared_angles ? ang_off[1] : ang_off[n_pairs];
+        ph->ang_off[n_pairs] = shared_angles ? (int64_t)n_pairs * (a1 - a0) : a1;
+    }
+    int rc;
+    if ((rc = ph->plan.stage_sets(e, sets, false)) || (rc = ph->plan.stage_level(pairs, precision, 0, INT32_MAX, want_costs != 0))) {
+        delete ph;
+        return rc;
+    }
+    *out = reinterpret_cast<mm_plan*>(ph);
+    return MM_OK;
+}
+
 void mm_plan_destroy(mm_plan* h)
 {
     PlanHandle* p = reinterpret_cast<PlanHandle*>(h);

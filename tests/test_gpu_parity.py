@@ -479,3 +479,34 @@ def test_near_ties_between_neighbouring_candidates(engine, oracle, mm, precision
         srt = np.sort(oc)
         n_close += int(srt[1] - srt[0] < 1e-6)
     assert n_close >= 8     # the scenario really produces near-ties
+
+
+# ---------------------------------------------------------------------------------------
+# EXTENSION (not in the reference's 4-phase path): rotation x frame-shift grid
+# ---------------------------------------------------------------------------------------
+def test_shift_rotation_extension_vs_oracle(engine, oracle, mm):
+    geoms = [mm.synthetic_pullback(9, 501, pullback_id=i) for i in range(2)]
+    srs = mm.ShiftRotationSearch(engine, geoms, -2, 3, 2.0, 180.0, 501, want_costs=True)
+    res = srs.run()
+    angles = srs.angles
+    assert srs.pose_evals == len(srs.meta) * len(angles)
+    best = {}
+    for p, (gi, i, sh, j) in enumerate(srs.meta):
+        g = geoms[gi]
+        ref = mm.search_set(g, int(j), 501) - g.centroids[j, :2]
+        tgt = mm.search_set(g, int(i), 501) - g.centroids[i, :2]
+        oc = oracle.costs_over_angles(ref, tgt, angles, 0.0, 0.0)
+        k = int(np.argmin(oc))
+        assert res["best_idx"][p] == k and res["best_cost"][p] == oc[k] and res["best_angle"][p] == angles[k]
+        cur = best.get((gi, i))
+        if cur is None or oc[k] < cur[2]:
+            best[(gi, i)] = (int(sh), float(angles[k]), float(oc[k]))
+    assert len(res["winners"]) == len(best)
+    for (gi, i, sh, ang, c) in res["winners"]:
+        assert best[(gi, i)] == (sh, ang, c)
+    # at shift 0 the pair is the reference's chain step (decoupled): same winner as the chain's first step
+    og = to_oracle(oracle, geoms[0])
+    logs = oracle.align_within_chain(og, 2.0, 180.0, True, 501)
+    p0 = [p for p, (gi, i, sh, j) in enumerate(srs.meta) if gi == 0 and i == 1 and sh == 0][0]
+    assert math.degrees(res["best_angle"][p0]) == logs[0][2]
+    srs.close()
