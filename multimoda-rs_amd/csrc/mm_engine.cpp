@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -231,7 +232,11 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
 
     // ---- work decomposition: one workgroup = `apb` consecutive candidates of one pair ----
     const int64_t target_wgs = 256 * 24;
-    const int apb = (int)std::min<int64_t>(64, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
+    // at most 8 candidates per workgroup: measured on config3 (apb 2/4/8/16/64/128: 140.6/145.0/146.3/
+    // 144.6/138.2/122.3 TFLOP/s) -- many short workgroups keep the co-resident ones out of phase
+    // (rotation / epilogue of one overlaps the micro-tile loop of the others) and balance the tail
+    int apb = (int)std::min<int64_t>(8, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
+    if (const char* env = std::getenv("MM_APB")) apb = std::max(1, std::atoi(env));   // tuning knob
     host_work.clear();
     for (int p = 0; p < P; ++p) {
         const PairDesc& d = host_pairs[p];

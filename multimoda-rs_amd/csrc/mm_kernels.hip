@@ -26,6 +26,8 @@
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mm_device.h"
@@ -770,7 +772,9 @@ static hipError_t launch_fast_r(const BatchDev& b, int max_nbp, hipStream_t s)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y,
+    int grid = b.n_work;
+    if (const char* env = std::getenv("MM_GRID")) grid = std::min(grid, std::max(1, std::atoi(env)));   // tuning knob
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y,
                        b.cos32, b.sin32, b.sq32);
     return hipGetLastError();
 }
