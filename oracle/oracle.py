@@ -22,10 +22,10 @@ _LIB_PATH = os.path.join(_HERE, "libmm_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile ``libmm_oracle.so`` with gcc (building the checker is not using it)."""
-    src = os.path.join(_HERE, "mm_oracle.c")
-    hdr = os.path.join(_HERE, "mm_oracle.h")
+    deps = [os.path.join(_HERE, f) for f in ("mm_oracle.c", "mm_oracle.h", "mm_oracle_cl.c", "mm_oracle_cl.h",
+                                             "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in deps
     )
     if force or stale:
         import fcntl
@@ -243,6 +243,11 @@ class OracleGeometry:
     ref: Optional[np.ndarray] = None       # (F,3) f64
     label: str = ""
     _keep: list = field(default_factory=list, repr=False)
+    # centerline placement only (orc_clgeom): the lumen contour's own centroid and the extras layout
+    has_lumen_centroid: Optional[np.ndarray] = None   # (F,) u8
+    lumen_centroids: Optional[np.ndarray] = None      # (F,3) f64
+    n_extra_kinds: int = 0
+    extra_kind_off: Optional[np.ndarray] = None       # (F*K+1,) i64
 
     @property
     def n_frames(self) -> int:
@@ -292,9 +297,12 @@ class OracleGeometry:
 
     def copy(self) -> "OracleGeometry":
         cp = lambda a: None if a is None else a.copy()
-        return OracleGeometry(cp(self.ids), cp(self.lumen_ids), cp(self.orig_frames), cp(self.centroids),
-                              cp(self.lumen_off), cp(self.lumen), cp(self.cath_off), cp(self.cath),
-                              cp(self.extra_off), cp(self.extra), cp(self.has_ref), cp(self.ref), self.label)
+        g = OracleGeometry(cp(self.ids), cp(self.lumen_ids), cp(self.orig_frames), cp(self.centroids),
+                           cp(self.lumen_off), cp(self.lumen), cp(self.cath_off), cp(self.cath),
+                           cp(self.extra_off), cp(self.extra), cp(self.has_ref), cp(self.ref), self.label)
+        g.has_lumen_centroid, g.lumen_centroids = cp(self.has_lumen_centroid), cp(self.lumen_centroids)
+        g.n_extra_kinds, g.extra_kind_off = self.n_extra_kinds, cp(self.extra_kind_off)
+        return g
 
     def frame_lumen(self, i) -> np.ndarray:
         return self.lumen[self.lumen_off[i]:self.lumen_off[i + 1]]
