@@ -19,6 +19,9 @@ from .io import InputData, Record, build_geometry_from_inputdata, numpy_to_input
 from .api import (GeometryPair, align_frames_in_geometries, from_array_doublepair, from_array_full,
                   from_array_single, from_array_singlepair, from_file_doublepair, from_file_full,
                   from_file_single, from_file_singlepair)
+from .centerline import (Centerline, align_combined, align_manual, align_three_point, numpy_to_centerline,
+                         preprocess_centerline)
+from . import centerline
 from .extension import ShiftRotationSearch
 from .synth import synthetic_case, synthetic_pullback
 
@@ -33,6 +36,8 @@ __all__ = [
     "InputData", "Record", "numpy_to_inputdata", "build_geometry_from_inputdata", "process_directory",
     "GeometryPair", "align_frames_in_geometries",
     "ShiftRotationSearch",
+    "Centerline", "numpy_to_centerline", "preprocess_centerline", "align_three_point", "align_manual",
+    "align_combined", "centerline",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F32_FAST", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

@@ -34,6 +34,12 @@ EXPORTS = [
     "mm_within_plan_walk", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
     "mm_frame_translate", "mm_frame_rotate",
 ]
+# include/mm_centerline.h
+EXPORTS_CENTERLINE = [
+    "mm_centerline_from_points", "mm_centerline_find_ref_idx", "mm_centerline_preprocess",
+    "mm_sort_contour_points", "mm_rotate_geometry", "mm_apply_transformations", "mm_best_rotation_three_point",
+    "mm_refine_alignment_hausdorff", "mm_align_three_point", "mm_align_manual", "mm_align_combined",
+]
 
 
 class MMGeometry(C.Structure):
@@ -53,6 +59,17 @@ class MMGeometry(C.Structure):
         ("extra", C.c_void_p),
         ("has_ref", C.c_void_p),
         ("ref", C.c_void_p),
+    ]
+
+
+class MMClGeometry(C.Structure):
+    """``mm_cl_geometry`` (include/mm_centerline.h)."""
+    _fields_ = [
+        ("g", C.POINTER(MMGeometry)),
+        ("has_lumen_centroid", C.c_void_p),
+        ("lumen_centroid", C.c_void_p),
+        ("n_extra_kinds", C.c_int32),
+        ("extra_kind_off", C.c_void_p),
     ]
 
 
@@ -179,6 +196,32 @@ def lib():
     L.mm_frame_translate.argtypes = [C.POINTER(MMGeometry), I32, D, D, D]
     L.mm_frame_rotate.restype = None
     L.mm_frame_rotate.argtypes = [C.POINTER(MMGeometry), I32, D, D, D]
+    # include/mm_centerline.h
+    U32 = C.c_uint32
+    L.mm_centerline_from_points.restype = I
+    L.mm_centerline_from_points.argtypes = [P, I64, P]
+    L.mm_centerline_find_ref_idx.restype = I64
+    L.mm_centerline_find_ref_idx.argtypes = [P, I64, P]
+    L.mm_centerline_preprocess.restype = I64
+    L.mm_centerline_preprocess.argtypes = [P, I64, C.POINTER(MMGeometry), P, I64, C.POINTER(D)]
+    L.mm_sort_contour_points.restype = I
+    L.mm_sort_contour_points.argtypes = [P, I64]
+    L.mm_rotate_geometry.restype = I
+    L.mm_rotate_geometry.argtypes = [C.POINTER(MMClGeometry), D]
+    L.mm_apply_transformations.restype = I64
+    L.mm_apply_transformations.argtypes = [P, I, P, I64, P]
+    L.mm_best_rotation_three_point.restype = I
+    L.mm_best_rotation_three_point.argtypes = [P, I64, I, P, U32, P, P, P, D, P, C.POINTER(D)]
+    L.mm_refine_alignment_hausdorff.restype = I
+    L.mm_refine_alignment_hausdorff.argtypes = [P, P, I, P, I64, I64, D, P, I64, D, D, I64, C.POINTER(D),
+                                                C.POINTER(I64), C.POINTER(D), P, I64, C.POINTER(I64)]
+    L.mm_align_three_point.restype = I
+    L.mm_align_three_point.argtypes = [P, I64, P, I, U32, P, P, P, D, I, C.POINTER(D), C.POINTER(D)]
+    L.mm_align_manual.restype = I
+    L.mm_align_manual.argtypes = [P, I64, P, I, D, P, I, C.POINTER(D), C.POINTER(D)]
+    L.mm_align_combined.restype = I
+    L.mm_align_combined.argtypes = [P, P, I64, P, I, U32, P, P, P, P, I64, D, D, I64, I, C.POINTER(D), C.POINTER(D),
+                                    C.POINTER(I64), C.POINTER(I64)]
     _lib = L
     return L
 

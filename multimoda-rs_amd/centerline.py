@@ -1,0 +1,294 @@
+"""Centerline placement path, mirroring the reference's Python entry points
+``align_three_point`` / ``align_manual`` / ``align_combined`` (multimodars/_processing.py:1010-1300,
+binding src/intravascular/binding/align.rs:83-460, implementation
+src/intravascular/centerline_align/{align.rs, align_algorithms.rs, preprocessing.rs}).
+
+Same argument names, meaning, defaults and error behaviour; geometries are ``FlatGeometry`` /
+``GeometryPair`` containers instead of the PyO3 value classes and are returned as transformed
+copies (the reference clones at the boundary too).  The three-point sweep and the frame placement
+are host f64 (csrc/mm_centerline.cpp); every Hausdorff evaluation of ``align_combined``'s
+refinement grid runs on the GPU.  ``write=True`` (OBJ export, to_object/*) and
+``align_wall_anomalous=True`` (align.rs:381-595) are outside this path and raise
+NotImplementedError instead of silently skipping work.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _native as N
+from . import geometry as G
+from .io import EXTRA_KINDS
+
+# mm_clpoint (include/mm_centerline.h)
+CL_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("tx", "<f8"), ("ty", "<f8"), ("tz", "<f8"),
+                     ("radius", "<f8"), ("branch_id", "<u4"), ("pad_", "<u4")])
+assert CL_DTYPE.itemsize == 64
+
+
+class Centerline:
+    """types/native/centerline.rs ``Centerline``: points with unit tangents, radius and branch id."""
+
+    def __init__(self, points: np.ndarray):
+        points = np.ascontiguousarray(points)
+        if points.dtype != CL_DTYPE or points.ndim != 1:
+            raise TypeError("Centerline expects a 1-d array of CL_DTYPE records")
+        self.points = points
+
+    def __len__(self) -> int:
+        return int(self.points.shape[0])
+
+    @staticmethod
+    def from_contour_points(xyz) -> "Centerline":
+        """Centerline::from_contour_points (centerline.rs:14-42): forward-difference unit tangents."""
+        a = np.ascontiguousarray(np.asarray(xyz, dtype=np.float64).reshape(-1, 3))
+        out = np.zeros(a.shape[0], dtype=CL_DTYPE)
+        N.check(N.lib().mm_centerline_from_points(N._ptr(a), a.shape[0], N._ptr(out)), "from_contour_points")
+        return Centerline(out)
+
+    @staticmethod
+    def from_arrays(xyz, tangents, radius=None, branch_id=None) -> "Centerline":
+        a = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+        t = np.asarray(tangents, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(a.shape[0], dtype=CL_DTYPE)
+        out["x"], out["y"], out["z"] = a[:, 0], a[:, 1], a[:, 2]
+        out["tx"], out["ty"], out["tz"] = t[:, 0], t[:, 1], t[:, 2]
+        if radius is not None:
+            out["radius"] = radius
+        if branch_id is not None:
+            out["branch_id"] = branch_id
+        return Centerline(out)
+
+    def xyz(self) -> np.ndarray:
+        return np.stack([self.points["x"], self.points["y"], self.points["z"]], axis=1)
+
+    def find_reference_cl_point_idx(self, reference_point) -> int:
+        r = np.ascontiguousarray(np.asarray(reference_point, dtype=np.float64).reshape(3))
+        return int(N.lib().mm_centerline_find_ref_idx(N._ptr(self.points), len(self), N._ptr(r)))
+
+
+def numpy_to_centerline(arr) -> Centerline:
+    """multimodars/_converters.py:605-686: (N,3) array -> centerline; NaNs are interpolated along the
+    index axis, an all-NaN column or fewer than two points raise ValueError."""
+    arr = np.asarray(arr, dtype=float)
+    if arr.ndim != 2 or arr.shape[1] != 3:
+        raise ValueError("Input must be a (N,3) array")
+    n = arr.shape[0]
+    if n == 0:
+        raise ValueError("Input array must contain at least one point")
+    if np.isnan(arr).any():
+        idx = np.arange(n)
+        fixed = arr.copy()
+        for col in range(3):
+            ok = ~np.isnan(arr[:, col])
+            if ok.sum() == 0:
+                raise ValueError(f"All values are NaN for coordinate column {col}; cannot build centerline.")
+            if ok.sum() < n:
+                fixed[:, col] = np.interp(idx, idx[ok], arr[ok, col])
+        arr = fixed
+    if arr.shape[0] < 2:
+        raise ValueError("Centerline must contain at least two points after cleaning/interpolation.")
+    return Centerline.from_contour_points(arr)
+
+
+def preprocess_centerline(centerline: Centerline, ref_mesh: G.FlatGeometry) -> Tuple[Centerline, float]:
+    """preprocessing.rs:16-108 -> (resampled centerline, spacing in mm)."""
+    cg = ref_mesh.c_struct()
+    sp = C.c_double(0.0)
+    L = N.lib()
+    n = L.mm_centerline_preprocess(N._ptr(centerline.points), len(centerline), C.byref(cg), None, 0, C.byref(sp))
+    if n < 0:
+        N.check(int(n), "preprocess_centerline")
+    out = np.zeros(int(n), dtype=CL_DTYPE)
+    L.mm_centerline_preprocess(N._ptr(centerline.points), len(centerline), C.byref(cg), N._ptr(out), int(n), C.byref(sp))
+    return Centerline(out), sp.value
+
+
+def with_lumen_centroids(g: G.FlatGeometry) -> G.FlatGeometry:
+    """Contour::compute_centroid (contour.rs:213-224) for every lumen: what a PyContour carries."""
+    F = g.n_frames
+    lc = np.zeros((F, 3), dtype=np.float64)
+    for i in range(F):
+        lc[i] = G.contour_centroid(g.frame_lumen(i))
+    g.has_lumen_centroid = np.ones(F, dtype=np.uint8)
+    g.lumen_centroids = lc
+    return g
+
+
+class _ClPack:
+    """ctypes views (mm_cl_geometry) of one or two FlatGeometry objects, kept alive for one call."""
+
+    def __init__(self, geoms: Sequence[G.FlatGeometry]):
+        self.keep = []
+        self.gs = [g.c_struct() for g in geoms]
+        self.cls = []
+        for g, cg in zip(geoms, self.gs):
+            c = N.MMClGeometry()
+            c.g = C.pointer(cg)
+            if g.lumen_centroids is not None:
+                hl = g.has_lumen_centroid if g.has_lumen_centroid is not None else np.ones(g.n_frames, dtype=np.uint8)
+                if hl.dtype != np.uint8 or hl.shape != (g.n_frames,) or g.lumen_centroids.shape != (g.n_frames, 3) \
+                        or g.lumen_centroids.dtype != np.float64 or not g.lumen_centroids.flags.c_contiguous:
+                    raise ValueError("FlatGeometry.lumen_centroids: expected C-contiguous float64 (F,3) + uint8 (F,)")
+                self.keep.append(hl)
+                c.has_lumen_centroid = N._ptr(hl)
+                c.lumen_centroid = N._ptr(g.lumen_centroids)
+            counts = g.meta.get("extra_counts")
+            if g.extra_off is not None and counts:
+                kinds = [k for k in EXTRA_KINDS if k in counts]
+                per = np.stack([np.asarray(counts[k], dtype=np.int64) for k in kinds], axis=1)   # (F, K)
+                ko = np.zeros(per.size + 1, dtype=np.int64)
+                ko[1:] = np.cumsum(per.reshape(-1))
+                if int(ko[-1]) != int(g.extra_off[-1]):
+                    raise ValueError("meta['extra_counts'] does not match the extras blob")
+                self.keep.append(ko)
+                c.n_extra_kinds = len(kinds)
+                c.extra_kind_off = N._ptr(ko)
+            self.cls.append(c)
+        self.arr = (C.POINTER(N.MMClGeometry) * len(geoms))(*[C.pointer(c) for c in self.cls])
+
+    @property
+    def ptr(self):
+        return C.cast(self.arr, C.c_void_p)
+
+
+def _v3(p) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(3))
+
+
+def _unpack(geometry):
+    from .api import GeometryPair
+    if isinstance(geometry, GeometryPair):
+        a, b = geometry.geom_a.copy(), geometry.geom_b.copy()
+        return [a, b], lambda: GeometryPair(a, b, geometry.label)
+    if isinstance(geometry, G.FlatGeometry):
+        a = geometry.copy()
+        return [a], lambda: a
+    raise TypeError("geometry must be a FlatGeometry or a GeometryPair")     # binding/align.rs:151
+
+
+def _unsupported(write: bool, align_wall_anomalous: bool):
+    if write:
+        raise NotImplementedError("write=True (OBJ export, to_object/*) is outside the accelerated path")
+    if align_wall_anomalous:
+        raise NotImplementedError("align_wall_anomalous=True (align.rs:381-595) is not built yet")
+
+
+def _ref_point_index(g: G.FlatGeometry) -> int:
+    return int(g.meta.get("ref_point_index", 0))      # Frame.reference_point.point_index (0 from file, build.rs:406)
+
+
+# ---- building blocks ---------------------------------------------------------------------
+def rotate_geometry(g: G.FlatGeometry, angle_rad: float) -> None:
+    """Geometry::rotate_geometry (geometry.rs:241-250), in place."""
+    pk = _ClPack([g])
+    N.check(N.lib().mm_rotate_geometry(C.byref(pk.cls[0]), float(angle_rad)), "rotate_geometry")
+
+
+def apply_transformations(geoms: Sequence[G.FlatGeometry], centerline: Centerline, ref_pt) -> int:
+    """apply_transformations (align_algorithms.rs:511-535), in place; returns the frames placed."""
+    pk = _ClPack(geoms)
+    r = _v3(ref_pt)
+    n = N.lib().mm_apply_transformations(pk.ptr, len(geoms), N._ptr(centerline.points), len(centerline), N._ptr(r))
+    if n < 0:
+        N.check(int(n), "apply_transformations")
+    return int(n)
+
+
+def best_rotation_three_point(lumen_xyz, centroid, index_reference: int, main_ref_pt, counterclockwise_ref_pt,
+                              clockwise_ref_pt, angle_step: float, centerline_point) -> float:
+    """best_rotation_three_point (align_algorithms.rs:263-336); angles in radians."""
+    p = np.ascontiguousarray(np.asarray(lumen_xyz, dtype=np.float64).reshape(-1, 3))
+    c = None if centroid is None else _v3(centroid)
+    clp = np.ascontiguousarray(np.asarray(centerline_point, dtype=CL_DTYPE).reshape(1))
+    a, b, d = _v3(main_ref_pt), _v3(counterclockwise_ref_pt), _v3(clockwise_ref_pt)
+    out = C.c_double(0.0)
+    N.check(N.lib().mm_best_rotation_three_point(N._ptr(p), p.shape[0], 0 if c is None else 1, N._ptr(c),
+                                                 int(index_reference), N._ptr(a), N._ptr(b), N._ptr(d),
+                                                 float(angle_step), N._ptr(clp), C.byref(out)),
+            "best_rotation_three_point")
+    return out.value
+
+
+def refine_alignment_hausdorff(engine: N.Engine, geoms: Sequence[G.FlatGeometry], centerline: Centerline,
+                               initial_cl_ref_idx: int, initial_rotation: float, points, angle_search_range: float,
+                               angle_step: float, index_search_range: int):
+    """refine_alignment_hausdorff (align_algorithms.rs:339-451) with the grid scored on the GPU.
+    Returns (best_angle, best_cl_ref_idx, min_hausdorff, costs of every evaluated candidate)."""
+    pk = _ClPack(geoms)
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+    n_ang = int(math.floor(2.0 * angle_search_range / angle_step)) + 3 if angle_step > 0 else 1
+    cap = (2 * int(index_search_range) + 1) * n_ang
+    costs = np.zeros(cap, dtype=np.float64)
+    ba, mh, bi, ne = C.c_double(0.0), C.c_double(0.0), C.c_int64(0), C.c_int64(0)
+    N.check(N.lib().mm_refine_alignment_hausdorff(engine.handle, pk.ptr, len(geoms), N._ptr(centerline.points),
+                                                  len(centerline), int(initial_cl_ref_idx), float(initial_rotation),
+                                                  N._ptr(pts), pts.shape[0], float(angle_search_range),
+                                                  float(angle_step), int(index_search_range), C.byref(ba),
+                                                  C.byref(bi), C.byref(mh), N._ptr(costs), cap, C.byref(ne)),
+            "refine_alignment_hausdorff")
+    return ba.value, int(bi.value), mh.value, costs[: min(int(ne.value), cap)].copy()
+
+
+# ---- the reference's entry points ----------------------------------------------------------
+def align_three_point(centerline: Centerline, geometry, main_ref_pt, counterclockwise_ref_pt, clockwise_ref_pt,
+                      angle_step_deg: float = 1.0, write: bool = False, watertight: bool = True,
+                      interpolation_steps: int = 0, output_dir: str = "output/aligned", contour_types=None,
+                      case_name: str = "None", align_wall_anomalous: bool = False):
+    """multimodars/_processing.py:1010-1103 -> (geometry, spacing_mm, total_rotation_deg)."""
+    _unsupported(write, align_wall_anomalous)
+    geoms, rebuild = _unpack(geometry)
+    pk = _ClPack(geoms)
+    a, b, d = _v3(main_ref_pt), _v3(counterclockwise_ref_pt), _v3(clockwise_ref_pt)
+    sp, rot = C.c_double(0.0), C.c_double(0.0)
+    N.check(N.lib().mm_align_three_point(N._ptr(centerline.points), len(centerline), pk.ptr, len(geoms),
+                                         _ref_point_index(geoms[0]), N._ptr(a), N._ptr(b), N._ptr(d),
+                                         math.radians(angle_step_deg), 0, C.byref(sp), C.byref(rot)),
+            "align_three_point")
+    return rebuild(), sp.value, rot.value * (180.0 / math.pi)
+
+
+def align_manual(centerline: Centerline, geometry, rotation_angle_deg: float, ref_point, write: bool = False,
+                 watertight: bool = True, interpolation_steps: int = 0, output_dir: str = "output/aligned",
+                 contour_types=None, case_name: str = "None", align_wall_anomalous: bool = False):
+    """multimodars/_processing.py:1106-1188 -> (geometry, spacing_mm, total_rotation_deg)."""
+    _unsupported(write, align_wall_anomalous)
+    geoms, rebuild = _unpack(geometry)
+    pk = _ClPack(geoms)
+    r = _v3(ref_point)
+    sp, rot = C.c_double(0.0), C.c_double(0.0)
+    N.check(N.lib().mm_align_manual(N._ptr(centerline.points), len(centerline), pk.ptr, len(geoms),
+                                    float(rotation_angle_deg), N._ptr(r), 0, C.byref(sp), C.byref(rot)),
+            "align_manual")
+    return rebuild(), sp.value, rot.value * (180.0 / math.pi)
+
+
+def align_combined(centerline: Centerline, geometry, main_ref_pt, counterclockwise_ref_pt, clockwise_ref_pt, points,
+                   angle_step_deg: float = 1.0, angle_range_deg: float = 15.0, index_range: int = 2,
+                   write: bool = False, watertight: bool = True, interpolation_steps: int = 0,
+                   output_dir: str = "output/aligned", contour_types=None, case_name: str = "None",
+                   align_wall_anomalous: bool = False, engine: Optional[N.Engine] = None):
+    """multimodars/_processing.py:1191-1300 -> (geometry, spacing_mm, total_rotation_deg).  The
+    Hausdorff refinement grid ((2*index_range+1) x angles) is scored on the GPU."""
+    _unsupported(write, align_wall_anomalous)
+    if engine is None:
+        from .api import default_engine
+        engine = default_engine()
+    geoms, rebuild = _unpack(geometry)
+    pk = _ClPack(geoms)
+    a, b, d = _v3(main_ref_pt), _v3(counterclockwise_ref_pt), _v3(clockwise_ref_pt)
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+    sp, rot, ri, ne = C.c_double(0.0), C.c_double(0.0), C.c_int64(0), C.c_int64(0)
+    N.check(N.lib().mm_align_combined(engine.handle, N._ptr(centerline.points), len(centerline), pk.ptr, len(geoms),
+                                      _ref_point_index(geoms[0]), N._ptr(a), N._ptr(b), N._ptr(d), N._ptr(pts),
+                                      pts.shape[0], math.radians(angle_step_deg), math.radians(angle_range_deg),
+                                      int(index_range), 0, C.byref(sp), C.byref(rot), C.byref(ri), C.byref(ne)),
+            "align_combined")
+    out = rebuild()
+    first = out.geom_a if hasattr(out, "geom_a") else out
+    first.meta["refined_cl_ref_idx"] = int(ri.value)
+    first.meta["refine_evals"] = int(ne.value)
+    return out, sp.value, rot.value * (180.0 / math.pi)

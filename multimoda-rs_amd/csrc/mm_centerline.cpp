@@ -1,0 +1,752 @@
+// mm_centerline.cpp -- centerline placement path (include/mm_centerline.h): three-point initial
+// rotation, per-frame placement on the resampled centerline, and the Hausdorff refinement grid.
+// Geometry transforms are exact f64 host arithmetic in the reference's operation order (compiled
+// with -ffp-contract=off); the grid's Hausdorff evaluations run on the device (hausdorff_sets).
+// Reference lines are cited per function (paths relative to the reference checkout).
+//
+// Small-vector arithmetic follows nalgebra 0.35 (the reference's Cargo.lock): dot = (x0 y0 + x1 y1)
+// + x2 y2, norm = sqrt(dot), Matrix::angle = acos(clamp(dot / (|a||b|))), from_axis_angle as in
+// geometry/rotation_specialization.rs, matrix * vector accumulated column by column (blas gemv).
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "../../include/mm_centerline.h"
+#include "mm_engine.h"
+
+namespace mm {
+namespace {
+
+constexpr double kTau = 6.283185307179586476925286766559;
+constexpr double kPiCl = 3.14159265358979323846264338327950288;
+
+inline void sin_cos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+
+struct Vec3 {
+    double v[3];
+    double& operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+};
+inline double dot(const Vec3& a, const Vec3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double norm(const Vec3& a) { return std::sqrt(dot(a, a)); }
+inline Vec3 cross(const Vec3& a, const Vec3& b)
+{
+    return Vec3{{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}};
+}
+inline double angle_between(const Vec3& a, const Vec3& b)
+{
+    const double prod = dot(a, b), n1 = norm(a), n2 = norm(b);
+    if (n1 == 0.0 || n2 == 0.0) return 0.0;
+    double c = prod / (n1 * n2);
+    c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
+    return std::acos(c);
+}
+
+struct Mat3 {
+    double m[9];  // row-major
+    static Mat3 identity() { return Mat3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+    // Rotation3::from_axis_angle(&Unit::new_normalize(axis), angle)
+    static Mat3 axis_angle(const Vec3& axis, double angle)
+    {
+        if (angle == 0.0) return identity();
+        const double n = norm(axis);
+        const double ux = axis[0] / n, uy = axis[1] / n, uz = axis[2] / n;
+        const double sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
+        double s, c;
+        sin_cos(angle, s, c);
+        const double omc = 1.0 - c;
+        return Mat3{{sqx + (1.0 - sqx) * c, ux * uy * omc - uz * s, ux * uz * omc + uy * s,
+                     ux * uy * omc + uz * s, sqy + (1.0 - sqy) * c, uy * uz * omc - ux * s,
+                     ux * uz * omc - uy * s, uy * uz * omc + ux * s, sqz + (1.0 - sqz) * c}};
+    }
+    Vec3 operator*(const Vec3& x) const
+    {
+        Vec3 o;
+        for (int i = 0; i < 3; ++i) {
+            double y = m[3 * i] * x[0];
+            y = m[3 * i + 1] * x[1] + y;
+            y = m[3 * i + 2] * x[2] + y;
+            o[i] = y;
+        }
+        return o;
+    }
+};
+
+// FrameTransformation (align_algorithms.rs:65-94)
+struct FrameTf {
+    Vec3 t; Mat3 r; Vec3 pivot;
+    inline void apply(double* p) const
+    {
+        const Vec3 rel{{(p[0] + t[0]) - pivot[0], (p[1] + t[1]) - pivot[1], (p[2] + t[2]) - pivot[2]}};
+        const Vec3 rot = r * rel;
+        p[0] = pivot[0] + rot[0]; p[1] = pivot[1] + rot[1]; p[2] = pivot[2] + rot[2];
+    }
+    void apply_span(double* xyz, int64_t lo, int64_t hi) const
+    {
+        for (int64_t i = lo; i < hi; ++i) apply(xyz + 3 * i);
+    }
+};
+
+Vec3 mean_of(const double* xyz, int64_t n)
+{
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int64_t i = 0; i < n; ++i) sx += xyz[3 * i];
+    for (int64_t i = 0; i < n; ++i) sy += xyz[3 * i + 1];
+    for (int64_t i = 0; i < n; ++i) sz += xyz[3 * i + 2];
+    return Vec3{{sx / (double)n, sy / (double)n, sz / (double)n}};
+}
+
+// calculate_normal (align_algorithms.rs:206-235): Newell's method about `c`
+Vec3 newell_normal(const double* xyz, int64_t n, const Vec3& c)
+{
+    if (n < 3) return Vec3{{0.0, 0.0, 1.0}};
+    Vec3 acc{{0.0, 0.0, 0.0}};
+    for (int64_t i = 0; i < n; ++i) {
+        const double* cur = xyz + 3 * i;
+        const double* nxt = xyz + 3 * ((i + 1) % n);
+        acc[0] += (cur[1] - c[1]) * (nxt[2] - c[2]) - (cur[2] - c[2]) * (nxt[1] - c[1]);
+        acc[1] += (cur[2] - c[2]) * (nxt[0] - c[0]) - (cur[0] - c[0]) * (nxt[2] - c[2]);
+        acc[2] += (cur[0] - c[0]) * (nxt[1] - c[1]) - (cur[1] - c[1]) * (nxt[0] - c[0]);
+    }
+    const double nn = norm(acc);
+    if (nn > 1e-12) return Vec3{{acc[0] / nn, acc[1] / nn, acc[2] / nn}};
+    return Vec3{{0.0, 0.0, 1.0}};
+}
+
+// align_frame (align_algorithms.rs:128-173)
+FrameTf align_frame(const double* xyz, int64_t n, bool has_c, const double* c_in, const mm_clpoint& clp)
+{
+    const Vec3 c = has_c ? Vec3{{c_in[0], c_in[1], c_in[2]}} : mean_of(xyz, n);
+    FrameTf tf;
+    tf.t = Vec3{{clp.x - c[0], clp.y - c[1], clp.z - c[2]}};
+    const Vec3 cur = newell_normal(xyz, n, c), des{{clp.tx, clp.ty, clp.tz}};
+    const double ang = angle_between(cur, des);
+    tf.r = Mat3::identity();
+    if (!(std::fabs(ang) < 1e-6)) {
+        const Vec3 axis = cross(cur, des);
+        if (!(norm(axis) < 1e-6)) tf.r = Mat3::axis_angle(axis, ang);
+    }
+    tf.pivot = Vec3{{clp.x, clp.y, clp.z}};
+    return tf;
+}
+
+// Contour::sort_contour_points (contour.rs:368-405).  `key`/`perm`/`tmp` are caller scratch.
+struct SortScratch { std::vector<double> key, tmp; std::vector<int32_t> perm; };
+void sort_contour(double* xyz, int64_t n, SortScratch& sc)
+{
+    if (n == 0) return;
+    double sx = 0.0, sy = 0.0;
+    for (int64_t i = 0; i < n; ++i) { sx += xyz[3 * i]; sy += xyz[3 * i + 1]; }
+    const double cx = sx / (double)n, cy = sy / (double)n;
+    sc.key.resize((size_t)n); sc.perm.resize((size_t)n); sc.tmp.resize((size_t)n * 3);
+    for (int64_t i = 0; i < n; ++i) sc.key[i] = std::atan2(xyz[3 * i + 1] - cy, xyz[3 * i] - cx);
+    std::iota(sc.perm.begin(), sc.perm.end(), 0);
+    const double* key = sc.key.data();
+    std::stable_sort(sc.perm.begin(), sc.perm.end(), [key](int32_t a, int32_t b) { return key[a] < key[b]; });
+    // highest y moves to the front; Iterator::max_by keeps the last of equal maxima
+    int64_t start = 0;
+    for (int64_t i = 1; i < n; ++i)
+        if (!(xyz[3 * sc.perm[i] + 1] < xyz[3 * sc.perm[start] + 1])) start = i;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t src = sc.perm[(size_t)((i + start) % n)];
+        sc.tmp[3 * i] = xyz[3 * src]; sc.tmp[3 * i + 1] = xyz[3 * src + 1]; sc.tmp[3 * i + 2] = xyz[3 * src + 2];
+    }
+    std::memcpy(xyz, sc.tmp.data(), (size_t)n * 24);
+}
+
+// ContourPoint::rotate (contour_point.rs:38-52) with the sin/cos pair hoisted out of the loop
+inline void rotate_xy_span(double* xyz, int64_t lo, int64_t hi, double s, double c, double cx, double cy)
+{
+    for (int64_t i = lo; i < hi; ++i) {
+        const double x = xyz[3 * i] - cx, y = xyz[3 * i + 1] - cy;
+        xyz[3 * i] = x * c - y * s + cx;
+        xyz[3 * i + 1] = x * s + y * c + cy;
+    }
+}
+
+int64_t find_ref_idx(const mm_clpoint* cl, int64_t n, const double ref[3])
+{
+    int64_t best = 0;
+    double best_d = INFINITY;
+    for (int64_t i = 0; i < n; ++i) {
+        const double dx = cl[i].x - ref[0], dy = cl[i].y - ref[1], dz = cl[i].z - ref[2];
+        const double d = std::sqrt(dx * dx + dy * dy + dz * dz);
+        if (d < best_d) { best_d = d; best = i; }
+    }
+    return best;
+}
+
+// preprocessing.rs:162-242
+mm_clpoint interpolate_at(const std::vector<mm_clpoint>& cl, const std::vector<double>& cum, double target)
+{
+    const size_t n = cl.size();
+    // binary_search_by: Ok(i) -> i, Err(0) -> 0, Err(pos) -> pos - 1
+    const size_t ub = (size_t)(std::upper_bound(cum.begin(), cum.end(), target) - cum.begin());
+    const size_t idx = ub == 0 ? 0 : ub - 1;
+    if (idx >= n - 1) { mm_clpoint o = cl[n - 1]; o.branch_id = 0; return o; }
+    const mm_clpoint &p0 = cl[idx], &p1 = cl[idx + 1];
+    const double s0 = cum[idx], s1 = cum[idx + 1], denom = s1 - s0;
+    const double t = std::fabs(denom) < 1e-12 ? 0.0 : (target - s0) / denom;
+    mm_clpoint o{};
+    o.x = p0.x + t * (p1.x - p0.x);
+    o.y = p0.y + t * (p1.y - p0.y);
+    o.z = p0.z + t * (p1.z - p0.z);
+    const Vec3 t0{{p0.tx, p0.ty, p0.tz}}, t1{{p1.tx, p1.ty, p1.tz}};
+    Vec3 tg{{0.0, 0.0, 0.0}};
+    if (norm(t0) > 0.0 || norm(t1) > 0.0) {
+        for (int k = 0; k < 3; ++k) tg[k] = t0[k] * (1.0 - t) + t1[k] * t;
+        const double tn = norm(tg);
+        if (tn > 1e-12) { tg[0] /= tn; tg[1] /= tn; tg[2] /= tn; }
+        else tg = Vec3{{0.0, 0.0, 0.0}};
+    }
+    o.tx = tg[0]; o.ty = tg[1]; o.tz = tg[2];
+    o.radius = p0.radius * (1.0 - t) + p1.radius * t;
+    o.branch_id = 0;
+    return o;
+}
+
+int preprocess(const mm_clpoint* cl_in, int64_t n_in, const mm_geometry* mesh, std::vector<mm_clpoint>& out,
+               double& spacing)
+{
+    std::vector<mm_clpoint> cl;
+    cl.reserve((size_t)std::max<int64_t>(n_in, 0));
+    for (int64_t i = 0; i < n_in; ++i) if (cl_in[i].branch_id == 0) cl.push_back(cl_in[i]);  // :23-27
+    if (cl.empty()) return set_error(MM_ERR_INVALID, "Couldn't resample the centerline: Centerline has no branch-0 points");
+    if (cl.front().z < cl.back().z) std::reverse(cl.begin(), cl.end());                        // :39-47
+    if (!mesh || mesh->n_frames <= 0)
+        return set_error(MM_ERR_NO_FRAMES, "Couldn't resample the centerline: Reference mesh has no frames");
+    bool has_mean = false;
+    double mean = 0.0;
+    if (mesh->n_frames >= 2) {                                                                 // :244-280
+        double sum = 0.0;
+        for (int32_t i = 0; i + 1 < mesh->n_frames; ++i) {
+            const double* a = mesh->centroid + 3 * i;
+            const double* b = a + 3;
+            const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+            sum += std::sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        mean = sum / (double)(mesh->n_frames - 1);
+        has_mean = std::isfinite(mean) && mean > 1e-12;
+    }
+    std::vector<double> cum(cl.size());                                                        // :110-126
+    cum[0] = 0.0;
+    for (size_t i = 1; i < cl.size(); ++i) {
+        const double dx = cl[i].x - cl[i - 1].x, dy = cl[i].y - cl[i - 1].y, dz = cl[i].z - cl[i - 1].z;
+        cum[i] = cum[i - 1] + std::sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    const double total = cum.back();
+    bool ok = false;                                                                           // :128-143
+    if (has_mean) { spacing = mean; ok = true; }
+    else if (cl.size() >= 2) {
+        const double fb = total / (double)(cl.size() - 1);
+        if (std::isfinite(fb) && fb > 1e-12) { spacing = fb; ok = true; }
+    }
+    if (!ok) { out = cl; spacing = 0.0; return MM_OK; }                                        // :70-73
+    std::vector<double> s_new;                                                                 // :145-160
+    for (double s = 0.0; s <= total + 1e-9; s += spacing) s_new.push_back(s);
+    if (!s_new.empty() && s_new.back() > total + 1e-6) s_new.back() = total;
+    out.clear(); out.reserve(s_new.size());
+    for (double s : s_new) out.push_back(interpolate_at(cl, cum, s));
+    return MM_OK;
+}
+
+inline bool lumen_centroid_of(const mm_cl_geometry* cg, int32_t i, const double*& c)
+{
+    if (cg->has_lumen_centroid && cg->lumen_centroid && cg->has_lumen_centroid[i]) { c = cg->lumen_centroid + 3 * i; return true; }
+    c = nullptr;
+    return false;
+}
+
+int check_geoms(mm_cl_geometry** geoms, int n_geoms)
+{
+    if (!geoms || n_geoms < 1 || n_geoms > 2) return set_error(MM_ERR_INVALID, "expected one geometry or a geometry pair");
+    for (int g = 0; g < n_geoms; ++g) {
+        if (!geoms[g] || !geoms[g]->g) return set_error(MM_ERR_INVALID, "geometry == NULL");
+        const mm_geometry* G = geoms[g]->g;
+        if (G->n_frames < 0 || !G->lumen_off || !G->centroid) return set_error(MM_ERR_INVALID, "malformed geometry");
+        if (geoms[g]->extra_kind_off && geoms[g]->n_extra_kinds <= 0)
+            return set_error(MM_ERR_INVALID, "extra_kind_off given with n_extra_kinds <= 0");
+    }
+    return MM_OK;
+}
+
+// get_transformations (align_algorithms.rs:96-126)
+void frame_transforms(const mm_cl_geometry* prim, const mm_clpoint* cl, int64_t ncl, const double ref_pt[3],
+                      std::vector<FrameTf>& tfs)
+{
+    const mm_geometry* g = prim->g;
+    const int64_t ref_idx = find_ref_idx(cl, ncl, ref_pt);
+    tfs.clear();
+    for (int32_t i = 0; i < g->n_frames; ++i) {
+        const int64_t k = ref_idx + i;
+        if (k >= ncl) continue;  // "Centerline index out of bounds": the frame keeps its place
+        const double* c;
+        const bool hc = lumen_centroid_of(prim, i, c);
+        tfs.push_back(align_frame(g->lumen + 3 * g->lumen_off[i], g->lumen_off[i + 1] - g->lumen_off[i], hc, c, cl[k]));
+    }
+}
+
+// apply_transforms_to_geometry (align_algorithms.rs:521-535)
+void apply_transforms(mm_cl_geometry* cg, const std::vector<FrameTf>& tfs)
+{
+    mm_geometry* g = cg->g;
+    for (int32_t i = 0; i < g->n_frames && (size_t)i < tfs.size(); ++i) {
+        const FrameTf& tf = tfs[(size_t)i];
+        tf.apply_span(g->lumen, g->lumen_off[i], g->lumen_off[i + 1]);
+        const double* c;
+        const bool hc = lumen_centroid_of(cg, i, c);
+        if (hc) tf.apply(cg->lumen_centroid + 3 * i);                                          // :186-201
+        if (g->cath_off) tf.apply_span(g->cath, g->cath_off[i], g->cath_off[i + 1]);
+        if (g->extra_off) tf.apply_span(g->extra, g->extra_off[i], g->extra_off[i + 1]);
+        if (g->has_ref && g->has_ref[i]) tf.apply(g->ref + 3 * i);                             // :529-531
+        for (int k = 0; k < 3; ++k) g->centroid[3 * i + k] = hc ? cg->lumen_centroid[3 * i + k] : 0.0;  // :532
+    }
+}
+
+void rotate_geometry(mm_cl_geometry* cg, double angle)
+{
+    if (angle == 0.0) return;                                                                  // geometry.rs:242-244
+    mm_geometry* g = cg->g;
+    SortScratch sc;
+    for (int32_t i = 0; i < g->n_frames; ++i) {
+        mm_frame_rotate(g, i, angle, g->centroid[3 * i], g->centroid[3 * i + 1]);              // :246-247
+        sort_contour(g->lumen + 3 * g->lumen_off[i], g->lumen_off[i + 1] - g->lumen_off[i], sc);  // frame.rs:123-129
+        if (g->cath_off) sort_contour(g->cath + 3 * g->cath_off[i], g->cath_off[i + 1] - g->cath_off[i], sc);
+        if (g->extra_off) {
+            if (cg->extra_kind_off) {
+                const int32_t K = cg->n_extra_kinds;
+                for (int32_t k = 0; k < K; ++k) {
+                    const int64_t lo = cg->extra_kind_off[(int64_t)i * K + k], hi = cg->extra_kind_off[(int64_t)i * K + k + 1];
+                    sort_contour(g->extra + 3 * lo, hi - lo, sc);
+                }
+            } else {
+                sort_contour(g->extra + 3 * g->extra_off[i], g->extra_off[i + 1] - g->extra_off[i], sc);
+            }
+        }
+    }
+}
+
+// best_rotation_three_point (align_algorithms.rs:263-336)
+double three_point(const double* lumen, int64_t n, bool has_c, const double* c_in, uint32_t index_reference,
+                   const double pm[3], const double pc[3], const double pw[3], double step, const mm_clpoint& clp)
+{
+    double best_angle = 0.0, min_err = DBL_MAX;
+    std::vector<double> tmp((size_t)n * 3);
+    const int64_t i_cw = n / 2;
+    for (double angle = 0.0; angle < kTau; angle += step) {
+        std::memcpy(tmp.data(), lumen, (size_t)n * 24);
+        // rotate_contour_around_centroid (:238-259): about the contour's normal through its centroid
+        const Vec3 c = has_c ? Vec3{{c_in[0], c_in[1], c_in[2]}} : mean_of(tmp.data(), n);
+        const Mat3 r = Mat3::axis_angle(newell_normal(tmp.data(), n, c), angle);
+        for (int64_t i = 0; i < n; ++i) {
+            double* p = tmp.data() + 3 * i;
+            const Vec3 rot = r * Vec3{{p[0] - c[0], p[1] - c[1], p[2] - c[2]}};
+            p[0] = c[0] + rot[0]; p[1] = c[1] + rot[1]; p[2] = c[2] + rot[2];
+        }
+        const FrameTf tf = align_frame(tmp.data(), n, has_c, c_in, clp);                        // :294
+        // only the three landmark points are read afterwards (:301-311)
+        double q[3][3];
+        const int64_t pick[3] = {(int64_t)index_reference, 0, i_cw};
+        const double* tgt[3] = {pm, pc, pw};
+        double err = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            std::memcpy(q[k], tmp.data() + 3 * pick[k], 24);
+            tf.apply(q[k]);
+            const Vec3 d{{tgt[k][0] - q[k][0], tgt[k][1] - q[k][1], tgt[k][2] - q[k][2]}};
+            const double dist = norm(d);
+            err = k == 0 ? dist * dist : err + dist * dist;                                    // :326
+        }
+        if (err < min_err) { min_err = err; best_angle = angle; }
+    }
+    return best_angle;
+}
+
+// filter_points_in_region (align_algorithms.rs:454-505): x,y of the points inside the box
+void filter_region(const double* pts, int64_t n, const mm_clpoint& a, const mm_clpoint& b,
+                   std::vector<double>& fx, std::vector<double>& fy)
+{
+    const double margin = 5.0;
+    const double min_x = std::fmin(a.x, b.x) - margin, max_x = std::fmax(a.x, b.x) + margin;
+    const double min_y = std::fmin(a.y, b.y) - margin, max_y = std::fmax(a.y, b.y) + margin;
+    const double min_z = std::fmin(a.z, b.z) - margin, max_z = std::fmax(a.z, b.z) + margin;
+    fx.clear(); fy.clear();
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        if (x >= min_x && x <= max_x && y >= min_y && y <= max_y && z >= min_z && z <= max_z) { fx.push_back(x); fy.push_back(y); }
+    }
+}
+
+struct Candidate { int32_t group; double angle; int64_t cl_idx; int64_t off, n; };
+
+// refine_alignment_hausdorff (align_algorithms.rs:339-451)
+int refine(Engine* e, mm_cl_geometry** geoms, const mm_clpoint* cl, int64_t ncl, int64_t initial_idx,
+           double initial_rotation, const double* pts, int64_t n_pts, double ang_range, double ang_step,
+           int64_t idx_range, double& best_angle, int64_t& best_idx, double& min_h,
+           double* all_costs, int64_t cap, int64_t* n_evals)
+{
+    const mm_cl_geometry* prim = geoms[0];
+    const mm_geometry* g = prim->g;
+    const int64_t F = g->n_frames;
+    best_angle = initial_rotation; best_idx = initial_idx; min_h = DBL_MAX;
+    if (n_evals) *n_evals = 0;
+    if (F <= 0) return set_error(MM_ERR_NO_FRAMES, "refine_alignment_hausdorff: geometry has no frames");
+    if (!(ang_step > 0.0)) return set_error(MM_ERR_INVALID, "refine_alignment_hausdorff: angle_step must be > 0");
+    const int64_t m = g->lumen_off[1] - g->lumen_off[0];                                       // :412
+
+    // candidate list in the reference's evaluation order; only the primary geometry's lumen
+    // enters the cost (:411-431), so only that is rebuilt per candidate
+    struct Group { int64_t cl_idx; std::vector<double> fx, fy; int64_t n_down; };
+    std::vector<Group> groups;
+    std::vector<Candidate> cands;
+    const int64_t lo = idx_range == 0 ? 0 : -idx_range, hi = idx_range == 0 ? 0 : idx_range;  // :363-367
+    int64_t flat_total = 0;
+    for (int64_t d = lo; d <= hi; ++d) {
+        const int64_t cur = initial_idx + d;
+        if (cur < 0) continue;                                                                 // :371-373
+        if (cur + F >= ncl) continue;                                                          // :376-378
+        Group grp;
+        grp.cl_idx = cur;
+        filter_region(pts, n_pts, cl[cur], cl[cur + F - 1], grp.fx, grp.fy);                   // :400-404
+        if (grp.fx.empty()) continue;                                                          // :406-409 (every angle skipped)
+        const double ratio = (double)grp.fx.size() / ((double)m * (double)F);                  // :415-418
+        const double nd = std::ceil(ratio * (double)m);
+        int64_t n_down = nd <= 0.0 ? 0 : (int64_t)nd;
+        n_down = std::max<int64_t>(1, std::min<int64_t>(n_down, m));
+        grp.n_down = n_down;
+        int64_t per_cand = 0;
+        for (int64_t f = 0; f < F; ++f) {
+            const int64_t len = g->lumen_off[f + 1] - g->lumen_off[f];
+            per_cand += (n_down < m) ? std::min(len, n_down) : len;                            // :420-428, contour.rs:47-58
+        }
+        const int32_t gi = (int32_t)groups.size();
+        groups.push_back(std::move(grp));
+        for (double a = initial_rotation - ang_range; a <= initial_rotation + ang_range; a += ang_step) {  // :386-387, 439
+            cands.push_back(Candidate{gi, a, cur, flat_total, per_cand});
+            flat_total += per_cand;
+            if (cands.size() > (size_t)1 << 22) return set_error(MM_ERR_TOO_LARGE, "refine grid has more than 2^22 candidates");
+        }
+    }
+    if (cands.empty()) return MM_OK;
+    if (flat_total > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "refine grid exceeds 2^30 points");
+
+    // rebuild the placed frames of every candidate (host, candidates in parallel)
+    std::vector<double> flat_x((size_t)flat_total), flat_y((size_t)flat_total);
+    int64_t max_len = 0;
+    for (int64_t f = 0; f < F; ++f) max_len = std::max(max_len, g->lumen_off[f + 1] - g->lumen_off[f]);
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        std::vector<double> buf((size_t)max_len * 3);
+        SortScratch sc;
+        for (;;) {
+            const size_t ci = next.fetch_add(1);
+            if (ci >= cands.size()) break;
+            const Candidate& cd = cands[ci];
+            const Group& grp = groups[(size_t)cd.group];
+            double s = 0.0, c = 1.0;
+            if (cd.angle != 0.0) sin_cos(cd.angle, s, c);
+            int64_t w = cd.off;
+            for (int64_t f = 0; f < F; ++f) {
+                const int64_t len = g->lumen_off[f + 1] - g->lumen_off[f];
+                double* p = buf.data();
+                std::memcpy(p, g->lumen + 3 * g->lumen_off[f], (size_t)len * 24);
+                if (cd.angle != 0.0) {                                                        // rotate_by_best_rotation (:395), geometry.rs:241-250
+                    rotate_xy_span(p, 0, len, s, c, g->centroid[3 * f], g->centroid[3 * f + 1]);
+                    sort_contour(p, len, sc);
+                }
+                // cl_segment = points[cur .. cur+F), ref_pt = its first point (:381-392): frame f -> cl[cur + f]
+                const double* lc;
+                const bool hc = lumen_centroid_of(prim, (int32_t)f, lc);
+                const FrameTf tf = align_frame(p, len, hc, lc, cl[cd.cl_idx + f]);
+                auto emit = [&](int64_t src) {
+                    double q[3] = {p[3 * src], p[3 * src + 1], p[3 * src + 2]};
+                    tf.apply(q);
+                    flat_x[(size_t)w] = q[0]; flat_y[(size_t)w] = q[1]; ++w;
+                };
+                if (grp.n_down < m && len > grp.n_down) {                                     // downsample_contour_points
+                    const double stepf = (double)len / (double)grp.n_down;
+                    for (int64_t i = 0; i < grp.n_down; ++i) emit((int64_t)((double)i * stepf));
+                } else {
+                    for (int64_t i = 0; i < len; ++i) emit(i);
+                }
+            }
+        }
+    };
+    {
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned nt = (unsigned)std::min<size_t>(hw, cands.size());
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker);
+        worker();
+        for (std::thread& t : th) t.join();
+    }
+
+    // one device batch: hausdorff_distance(filtered points of the group, placed frames), x,y only (:431)
+    std::vector<SetRef> sets;
+    std::vector<std::array<int32_t, 2>> pr;
+    sets.reserve(groups.size() + cands.size());
+    for (const Group& grp : groups) sets.push_back(SetRef{grp.fx.data(), grp.fy.data(), (int32_t)grp.fx.size(), 0.0, 0.0});
+    for (const Candidate& cd : cands) {
+        pr.push_back({cd.group, (int32_t)sets.size()});
+        sets.push_back(SetRef{flat_x.data() + cd.off, flat_y.data() + cd.off, (int32_t)cd.n, 0.0, 0.0});
+    }
+    std::vector<double> cost(cands.size());
+    int rc = hausdorff_sets(e, sets, pr, cost.data());
+    if (rc) return rc;
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+        if (all_costs && (int64_t)ci < cap) all_costs[ci] = cost[ci];
+        if (cost[ci] < min_h) { min_h = cost[ci]; best_angle = cands[ci].angle; best_idx = cands[ci].cl_idx; }  // :433-437
+    }
+    if (n_evals) *n_evals = (int64_t)cands.size();
+    return MM_OK;
+}
+
+int find_ref_frame(const mm_geometry* g, int64_t& idx)
+{
+    for (int32_t i = 0; i < g->n_frames; ++i)
+        if (g->has_ref && g->has_ref[i]) {                                                     // geometry.rs:62-69
+            idx = (int64_t)g->id[i];
+            if (idx >= g->n_frames) return set_error(MM_ERR_REF_INDEX, "reference frame id used as index is out of range");
+            return MM_OK;
+        }
+    return set_error(MM_ERR_INVALID, "Couldn't find ref frame idx: No reference point found in any frame");
+}
+
+int three_point_initial(const std::vector<mm_clpoint>& rcl, mm_cl_geometry** geoms, uint32_t ref_point_index,
+                        const double pm[3], const double pc[3], const double pw[3], double step,
+                        int64_t& cl_ref_idx, double& rot)
+{
+    const mm_cl_geometry* prim = geoms[0];
+    const mm_geometry* g = prim->g;
+    int64_t ref_idx = 0;
+    int rc = find_ref_frame(g, ref_idx);                                                       // align.rs:82-85
+    if (rc) return rc;
+    if (!(g->has_ref && g->has_ref[ref_idx])) return set_error(MM_ERR_INVALID, "missing reference point");  // :86-89
+    const int64_t n = g->lumen_off[ref_idx + 1] - g->lumen_off[ref_idx];
+    if ((int64_t)ref_point_index >= n || n == 0)
+        return set_error(MM_ERR_INVALID, "reference point index is not a point of the reference frame's lumen");
+    if (!(step > 0.0)) return set_error(MM_ERR_INVALID, "angle_step must be > 0");
+    cl_ref_idx = find_ref_idx(rcl.data(), (int64_t)rcl.size(), pm);                            // :90
+    const double* lc;
+    const bool hc = lumen_centroid_of(prim, (int32_t)ref_idx, lc);
+    rot = three_point(g->lumen + 3 * g->lumen_off[ref_idx], n, hc, lc, ref_point_index, pm, pc, pw, step,
+                      rcl[(size_t)cl_ref_idx]);                                                // :92-100
+    return MM_OK;
+}
+
+}  // namespace
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" {
+
+int mm_centerline_from_points(const double* xyz, int64_t n, mm_clpoint* out)
+{
+    if (n < 0 || (n > 0 && (!xyz || !out))) return set_error(MM_ERR_INVALID, "mm_centerline_from_points: bad arguments");
+    if (n == 1) return set_error(MM_ERR_INVALID, "a centerline needs at least two points");
+    for (int64_t i = 0; i < n; ++i) {
+        mm_clpoint& o = out[i];
+        o.x = xyz[3 * i]; o.y = xyz[3 * i + 1]; o.z = xyz[3 * i + 2];
+        if (i + 1 < n) {                                                                       // centerline.rs:20-22
+            const Vec3 d{{xyz[3 * (i + 1)] - o.x, xyz[3 * (i + 1) + 1] - o.y, xyz[3 * (i + 1) + 2] - o.z}};
+            const double nn = norm(d);
+            o.tx = d[0] / nn; o.ty = d[1] / nn; o.tz = d[2] / nn;
+        } else { o.tx = out[i - 1].tx; o.ty = out[i - 1].ty; o.tz = out[i - 1].tz; }          // :23-24
+        o.radius = 0.0; o.branch_id = 0; o.pad_ = 0;
+    }
+    return MM_OK;
+}
+
+int64_t mm_centerline_find_ref_idx(const mm_clpoint* cl, int64_t n, const double ref[3])
+{
+    if (!cl || !ref || n <= 0) return 0;
+    return find_ref_idx(cl, n, ref);
+}
+
+int64_t mm_centerline_preprocess(const mm_clpoint* cl, int64_t n, const mm_geometry* ref_mesh, mm_clpoint* out,
+                                 int64_t cap, double* spacing)
+{
+    if (n < 0 || (n > 0 && !cl)) return set_error(MM_ERR_INVALID, "mm_centerline_preprocess: bad arguments");
+    std::vector<mm_clpoint> res;
+    double sp = 0.0;
+    int rc = preprocess(cl, n, ref_mesh, res, sp);
+    if (rc) return rc;
+    if (spacing) *spacing = sp;
+    if (out) for (int64_t i = 0; i < (int64_t)res.size() && i < cap; ++i) out[i] = res[(size_t)i];
+    return (int64_t)res.size();
+}
+
+int mm_sort_contour_points(double* xyz, int64_t n)
+{
+    if (n < 0 || (n > 0 && !xyz)) return set_error(MM_ERR_INVALID, "mm_sort_contour_points: bad arguments");
+    SortScratch sc;
+    sort_contour(xyz, n, sc);
+    return MM_OK;
+}
+
+int mm_rotate_geometry(mm_cl_geometry* g, double angle)
+{
+    mm_cl_geometry* arr[1] = {g};
+    int rc = check_geoms(arr, 1);
+    if (rc) return rc;
+    rotate_geometry(g, angle);
+    return MM_OK;
+}
+
+int64_t mm_apply_transformations(mm_cl_geometry** geoms, int n_geoms, const mm_clpoint* cl, int64_t ncl,
+                                 const double ref_pt[3])
+{
+    int rc = check_geoms(geoms, n_geoms);
+    if (rc) return rc;
+    if (!cl || ncl <= 0 || !ref_pt) return set_error(MM_ERR_INVALID, "mm_apply_transformations: empty centerline");
+    std::vector<FrameTf> tfs;
+    frame_transforms(geoms[0], cl, ncl, ref_pt, tfs);
+    for (int g = 0; g < n_geoms; ++g) apply_transforms(geoms[g], tfs);
+    return (int64_t)tfs.size();
+}
+
+int mm_best_rotation_three_point(const double* lumen_xyz, int64_t n, int has_centroid, const double centroid[3],
+                                 uint32_t index_reference, const double p_main[3], const double p_ccw[3],
+                                 const double p_cw[3], double angle_step, const mm_clpoint* clp, double* best_angle)
+{
+    if (!lumen_xyz || n <= 0 || !p_main || !p_ccw || !p_cw || !clp || !best_angle || (has_centroid && !centroid))
+        return set_error(MM_ERR_INVALID, "mm_best_rotation_three_point: bad arguments");
+    if ((int64_t)index_reference >= n) return set_error(MM_ERR_INVALID, "index_reference is not a point of the contour");
+    if (!(angle_step > 0.0)) return set_error(MM_ERR_INVALID, "angle_step must be > 0");
+    *best_angle = three_point(lumen_xyz, n, has_centroid != 0, centroid, index_reference, p_main, p_ccw, p_cw,
+                              angle_step, *clp);
+    return MM_OK;
+}
+
+int mm_refine_alignment_hausdorff(mm_engine* h, mm_cl_geometry** geoms, int n_geoms, const mm_clpoint* cl,
+                                  int64_t ncl, int64_t initial_cl_ref_idx, double initial_rotation,
+                                  const double* points_xyz, int64_t n_points, double angle_search_range,
+                                  double angle_step, int64_t index_search_range, double* best_angle,
+                                  int64_t* best_idx, double* min_hausdorff, double* all_costs, int64_t cap,
+                                  int64_t* n_evals)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    int rc = check_geoms(geoms, n_geoms);
+    if (rc) return rc;
+    if (!cl || ncl <= 0 || n_points < 0 || (n_points > 0 && !points_xyz) || index_search_range < 0 ||
+        initial_cl_ref_idx < 0 || !best_angle || !best_idx)
+        return set_error(MM_ERR_INVALID, "mm_refine_alignment_hausdorff: bad arguments");
+    { const hipError_t he = hipSetDevice(e->device); if (he != hipSuccess) return hip_error(he, "hipSetDevice"); }
+    double ba, mh; int64_t bi;
+    rc = refine(e, geoms, cl, ncl, initial_cl_ref_idx, initial_rotation, points_xyz, n_points, angle_search_range,
+                angle_step, index_search_range, ba, bi, mh, all_costs, cap, n_evals);
+    if (rc) return rc;
+    *best_angle = ba; *best_idx = bi;
+    if (min_hausdorff) *min_hausdorff = mh;
+    return MM_OK;
+}
+
+int mm_align_three_point(const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geoms, int n_geoms,
+                         uint32_t ref_point_index, const double p_main[3], const double p_ccw[3],
+                         const double p_cw[3], double angle_step, int align_wall_anomalous, double* spacing,
+                         double* total_rotation)
+{
+    int rc = check_geoms(geoms, n_geoms);
+    if (rc) return rc;
+    if (align_wall_anomalous) return set_error(MM_ERR_INVALID, "align_wall_anomalous is not supported yet");
+    if (!p_main || !p_ccw || !p_cw) return set_error(MM_ERR_INVALID, "mm_align_three_point: bad arguments");
+    std::vector<mm_clpoint> rcl;
+    double sp = 0.0;
+    if ((rc = preprocess(cl, ncl, geoms[0]->g, rcl, sp))) return rc;                           // align.rs:78-80
+    int64_t cl_ref_idx = 0; double rot = 0.0;
+    if ((rc = three_point_initial(rcl, geoms, ref_point_index, p_main, p_ccw, p_cw, angle_step, cl_ref_idx, rot))) return rc;
+    for (int g = 0; g < n_geoms; ++g) rotate_geometry(geoms[g], rot);                          // :102
+    std::vector<FrameTf> tfs;
+    frame_transforms(geoms[0], rcl.data(), (int64_t)rcl.size(), p_main, tfs);                  // :103
+    for (int g = 0; g < n_geoms; ++g) apply_transforms(geoms[g], tfs);
+    if (spacing) *spacing = sp;
+    if (total_rotation) *total_rotation = rot;
+    return MM_OK;
+}
+
+int mm_align_manual(const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geoms, int n_geoms, double rotation_angle_deg,
+                    const double ref_pt[3], int align_wall_anomalous, double* spacing, double* total_rotation)
+{
+    int rc = check_geoms(geoms, n_geoms);
+    if (rc) return rc;
+    if (align_wall_anomalous) return set_error(MM_ERR_INVALID, "align_wall_anomalous is not supported yet");
+    if (!ref_pt) return set_error(MM_ERR_INVALID, "mm_align_manual: bad arguments");
+    std::vector<mm_clpoint> rcl;
+    double sp = 0.0;
+    if ((rc = preprocess(cl, ncl, geoms[0]->g, rcl, sp))) return rc;                           // align.rs:139-141
+    const double rot = rotation_angle_deg * (kPiCl / 180.0);                                   // :143
+    for (int g = 0; g < n_geoms; ++g) rotate_geometry(geoms[g], rot);                          // :144
+    std::vector<FrameTf> tfs;
+    frame_transforms(geoms[0], rcl.data(), (int64_t)rcl.size(), ref_pt, tfs);                  // :145
+    for (int g = 0; g < n_geoms; ++g) apply_transforms(geoms[g], tfs);
+    if (spacing) *spacing = sp;
+    if (total_rotation) *total_rotation = rot;
+    return MM_OK;
+}
+
+int mm_align_combined(mm_engine* h, const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geoms, int n_geoms,
+                      uint32_t ref_point_index, const double p_main[3], const double p_ccw[3], const double p_cw[3],
+                      const double* points_xyz, int64_t n_points, double angle_step, double refine_angle_range,
+                      int64_t refine_index_range, int align_wall_anomalous, double* spacing, double* total_rotation,
+                      int64_t* refined_idx, int64_t* n_evals)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    int rc = check_geoms(geoms, n_geoms);
+    if (rc) return rc;
+    if (align_wall_anomalous) return set_error(MM_ERR_INVALID, "align_wall_anomalous is not supported yet");
+    if (!p_main || !p_ccw || !p_cw || n_points < 0 || (n_points > 0 && !points_xyz) || refine_index_range < 0)
+        return set_error(MM_ERR_INVALID, "mm_align_combined: bad arguments");
+    { const hipError_t he = hipSetDevice(e->device); if (he != hipSuccess) return hip_error(he, "hipSetDevice"); }
+    std::vector<mm_clpoint> rcl;
+    double sp = 0.0;
+    if ((rc = preprocess(cl, ncl, geoms[0]->g, rcl, sp))) return rc;                           // align.rs:191-195
+    int64_t initial_idx = 0; double initial_rotation = 0.0;
+    if ((rc = three_point_initial(rcl, geoms, ref_point_index, p_main, p_ccw, p_cw, angle_step, initial_idx,
+                                  initial_rotation))) return rc;                               // :197-217
+
+    // `aligned` = the primary geometry rotated by the initial rotation and placed (:219-223); only its
+    // lumen, frame centroids and lumen centroids are read by the refinement
+    const mm_geometry* G = geoms[0]->g;
+    const int64_t F = G->n_frames, NL = G->lumen_off[F];
+    std::vector<double> a_lumen(G->lumen, G->lumen + 3 * NL), a_centroid(G->centroid, G->centroid + 3 * F);
+    std::vector<double> a_lc;
+    std::vector<uint8_t> a_hlc;
+    mm_geometry ag = *G;
+    ag.lumen = a_lumen.data(); ag.centroid = a_centroid.data();
+    ag.has_catheter = 0; ag.cath_off = nullptr; ag.cath = nullptr; ag.extra_off = nullptr; ag.extra = nullptr;
+    ag.has_ref = nullptr; ag.ref = nullptr;
+    mm_cl_geometry acg{&ag, nullptr, nullptr, 0, nullptr};
+    if (geoms[0]->has_lumen_centroid && geoms[0]->lumen_centroid) {
+        a_hlc.assign(geoms[0]->has_lumen_centroid, geoms[0]->has_lumen_centroid + F);
+        a_lc.assign(geoms[0]->lumen_centroid, geoms[0]->lumen_centroid + 3 * F);
+        acg.has_lumen_centroid = a_hlc.data(); acg.lumen_centroid = a_lc.data();
+    }
+    rotate_geometry(&acg, initial_rotation);
+    std::vector<FrameTf> tfs;
+    frame_transforms(&acg, rcl.data(), (int64_t)rcl.size(), p_main, tfs);
+    apply_transforms(&acg, tfs);
+
+    mm_cl_geometry* ap[1] = {&acg};
+    double delta = 0.0, mh = 0.0; int64_t ridx = initial_idx;
+    if ((rc = refine(e, ap, rcl.data(), (int64_t)rcl.size(), initial_idx, 0.0, points_xyz, n_points, refine_angle_range,
+                     angle_step, refine_index_range, delta, ridx, mh, nullptr, 0, n_evals))) return rc;  // :228-237
+    const double total = initial_rotation + delta;                                             // :239
+    const double ref_pt[3] = {rcl[(size_t)ridx].x, rcl[(size_t)ridx].y, rcl[(size_t)ridx].z};  // :248-258
+    for (int g = 0; g < n_geoms; ++g) rotate_geometry(geoms[g], total);                        // :260-264
+    frame_transforms(geoms[0], rcl.data(), (int64_t)rcl.size(), ref_pt, tfs);
+    for (int g = 0; g < n_geoms; ++g) apply_transforms(geoms[g], tfs);
+    if (spacing) *spacing = sp;
+    if (total_rotation) *total_rotation = total;
+    if (refined_idx) *refined_idx = ridx;
+    return MM_OK;
+}
+
+}  // extern "C"

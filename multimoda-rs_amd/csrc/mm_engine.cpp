@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
 #include <vector>
 
 namespace mm {
@@ -432,20 +433,27 @@ static void scatter_costs(const Plan& plan, const double* plan_costs, const int6
 struct LargePairH { int32_t a_off, na, b_off, nb, col_off, pad; };
 struct LargeWorkH { int32_t pair, row0; };
 
-int hausdorff_large(Engine* e, const std::vector<int>& idx, const int64_t* a_off, const double* ax, const double* ay,
-                    const int64_t* b_off, const double* bx, const double* by, double* out)
+static int hausdorff_large(Engine* e, const std::vector<SetRef>& sets, const std::vector<std::array<int32_t, 2>>& pr,
+                           const std::vector<int>& idx, double* out)
 {
     const int P = (int)idx.size();
     std::vector<LargePairH> hp(P);
     std::vector<LargeWorkH> hw;
+    std::vector<int64_t> set_at(sets.size(), -1);   // every set is uploaded once, however many pairs share it
+    std::vector<int32_t> order;
     int64_t npts = 0, ncol = 0;
     const int rpb = large_rows_per_block();
+    auto place = [&](int32_t sidx) {
+        if (set_at[sidx] < 0) { set_at[sidx] = npts; npts += sets[sidx].n; order.push_back(sidx); }
+        return set_at[sidx];
+    };
     for (int k = 0; k < P; ++k) {
-        const int p = idx[k];
-        const int64_t na = a_off[p + 1] - a_off[p], nb = b_off[p + 1] - b_off[p];
-        hp[k] = LargePairH{(int32_t)npts, (int32_t)na, (int32_t)(npts + na), (int32_t)nb, (int32_t)ncol, 0};
-        npts += na + nb; ncol += nb;
-        if (npts > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
+        const int32_t ia = pr[idx[k]][0], ib = pr[idx[k]][1];
+        const int64_t na = sets[ia].n, nb = sets[ib].n;
+        const int64_t oa = place(ia), ob = place(ib);
+        if (npts > (int64_t)1 << 30 || ncol + nb > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
+        hp[k] = LargePairH{(int32_t)oa, (int32_t)na, (int32_t)ob, (int32_t)nb, (int32_t)ncol, 0};
+        ncol += nb;
         for (int64_t r0 = 0; r0 < na; r0 += rpb) hw.push_back(LargeWorkH{k, (int32_t)r0});
     }
     const size_t o_px = 0, o_py = align_up((size_t)npts * 8), o_pairs = align_up(o_py + (size_t)npts * 8);
@@ -458,12 +466,9 @@ int hausdorff_large(Engine* e, const std::vector<int>& idx, const int64_t* a_off
     if ((rc = e->ensure(e->dev_pts, total, false))) return rc;
     unsigned char* h = (unsigned char*)e->host_pts.p;
     double *hx = (double*)(h + o_px), *hy = (double*)(h + o_py);
-    for (int k = 0; k < P; ++k) {
-        const int p = idx[k];
-        std::memcpy(hx + hp[k].a_off, ax + a_off[p], (size_t)hp[k].na * 8);
-        std::memcpy(hy + hp[k].a_off, ay + a_off[p], (size_t)hp[k].na * 8);
-        std::memcpy(hx + hp[k].b_off, bx + b_off[p], (size_t)hp[k].nb * 8);
-        std::memcpy(hy + hp[k].b_off, by + b_off[p], (size_t)hp[k].nb * 8);
+    for (int32_t sidx : order) {
+        std::memcpy(hx + set_at[sidx], sets[sidx].x, (size_t)sets[sidx].n * 8);
+        std::memcpy(hy + set_at[sidx], sets[sidx].y, (size_t)sets[sidx].n * 8);
     }
     std::memcpy(h + o_pairs, hp.data(), (size_t)P * sizeof(LargePairH));
     std::memcpy(h + o_work, hw.data(), hw.size() * sizeof(LargeWorkH));
@@ -477,6 +482,49 @@ int hausdorff_large(Engine* e, const std::vector<int>& idx, const int64_t* a_off
     MM_HIP(hipMemcpyAsync(res.data(), d + o_out, (size_t)P * 8, hipMemcpyDeviceToHost, e->stream));
     MM_HIP(hipStreamSynchronize(e->stream));
     for (int k = 0; k < P; ++k) out[idx[k]] = res[k];
+    return MM_OK;
+}
+
+// hausdorff_distance (process_utils.rs:78-121) of set pairs, exact f64 on the device.  Pairs name
+// their sets by index, so a set shared by many pairs (the CCTA points of the refine grid) is
+// staged once.
+int hausdorff_sets(Engine* e, const std::vector<SetRef>& sets, const std::vector<std::array<int32_t, 2>>& pr, double* out)
+{
+    static const double zero = 0.0;
+    const int cap = max_target_points_f64();
+    std::vector<SetRef> ssets; std::vector<PairSpec> pairs;
+    std::vector<int32_t> remap(sets.size(), -1);
+    std::vector<int> small_idx, large_idx;
+    auto use = [&](int32_t sidx) {
+        if (remap[sidx] < 0) { remap[sidx] = (int32_t)ssets.size(); ssets.push_back(sets[sidx]); }
+        return remap[sidx];
+    };
+    for (size_t p = 0; p < pr.size(); ++p) {
+        const int32_t ia = pr[p][0], ib = pr[p][1];
+        if (ia < 0 || ib < 0 || (size_t)ia >= sets.size() || (size_t)ib >= sets.size())
+            return set_error(MM_ERR_INVALID, "hausdorff_sets: set index out of range");
+        const int32_t na = sets[ia].n, nb = sets[ib].n;
+        if (na == 0 || nb == 0) { out[p] = 0.0; continue; }               // process_utils.rs:86-88
+        if (na > cap && nb > cap) { large_idx.push_back((int)p); continue; }  // neither side fits LDS: streaming kernel
+        // hausdorff_distance is symmetric bit for bit (max of the two directed terms over the same
+        // squared distances): put the smaller set on the LDS-staged (target) side if the other one
+        // would not fit
+        const bool swap = nb > cap && na <= cap;
+        const int32_t ra = use(swap ? ib : ia), rb = use(swap ? ia : ib);
+        // angle 0 with the rotate() shortcut leaves the target untouched
+        pairs.push_back(PairSpec{ra, rb, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, &zero, 1, 0.0, 0.0});
+        small_idx.push_back((int)p);
+    }
+    if (!pairs.empty()) {
+        BatchResult res;
+        int rc = run_batch(e, ssets, pairs, MM_PRECISION_F64, res);
+        if (rc) return rc;
+        for (size_t k = 0; k < small_idx.size(); ++k) out[small_idx[k]] = res.best_cost[k];
+    }
+    if (!large_idx.empty()) {
+        int rc = hausdorff_large(e, sets, pr, large_idx, out);
+        if (rc) return rc;
+    }
     return MM_OK;
 }
 
@@ -658,36 +706,18 @@ int mm_hausdorff_batch(mm_engine* h, int n_pairs, const int64_t* a_off, const do
     if (first_min) *first_min = -1;
     if (n_pairs == 0) return MM_OK;
     MM_HIP(hipSetDevice(e->device));
-    static const double zero = 0.0;
-    std::vector<SetRef> sets; std::vector<PairSpec> pairs;
-    std::vector<int> small_idx, large_idx;
-    const int cap = max_target_points_f64();
+    std::vector<SetRef> sets;
+    std::vector<std::array<int32_t, 2>> pr;
+    sets.reserve(2 * (size_t)n_pairs); pr.reserve((size_t)n_pairs);
     for (int p = 0; p < n_pairs; ++p) {
         const int64_t na = a_off[p + 1] - a_off[p], nb = b_off[p + 1] - b_off[p];
         if (na < 0 || nb < 0 || na > INT32_MAX || nb > INT32_MAX) return set_error(MM_ERR_INVALID, "bad set extent");
-        if (na > cap && nb > cap) { large_idx.push_back(p); continue; }   // neither side fits LDS: streaming kernel
-        SetRef A{ax + a_off[p], ay + a_off[p], (int32_t)na, 0.0, 0.0}, B{bx + b_off[p], by + b_off[p], (int32_t)nb, 0.0, 0.0};
-        // hausdorff_distance is symmetric bit for bit (max of the two directed terms over the same
-        // squared distances): put the smaller set on the LDS-staged (target) side if the other one
-        // would not fit
-        const bool swap = nb > cap && na <= cap;
-        const int32_t sid = (int32_t)sets.size();
-        sets.push_back(swap ? B : A);
-        sets.push_back(swap ? A : B);
-        // angle 0 with the rotate() shortcut leaves the target untouched
-        pairs.push_back(PairSpec{sid, sid + 1, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, &zero, 1, 0.0, 0.0});
-        small_idx.push_back(p);
+        sets.push_back(SetRef{ax + a_off[p], ay + a_off[p], (int32_t)na, 0.0, 0.0});
+        sets.push_back(SetRef{bx + b_off[p], by + b_off[p], (int32_t)nb, 0.0, 0.0});
+        pr.push_back({2 * p, 2 * p + 1});
     }
-    if (!pairs.empty()) {
-        BatchResult res;
-        int rc = run_batch(e, sets, pairs, MM_PRECISION_F64, res);
-        if (rc) return rc;
-        for (size_t k = 0; k < small_idx.size(); ++k) out[small_idx[k]] = res.best_cost[k];
-    }
-    if (!large_idx.empty()) {
-        int rc = hausdorff_large(e, large_idx, a_off, ax, ay, b_off, bx, by, out);
-        if (rc) return rc;
-    }
+    int rc = hausdorff_sets(e, sets, pr, out);
+    if (rc) return rc;
     int32_t best = -1;
     double best_cost = INFINITY;   // f64::MAX in the reference; costs are finite
     for (int p = 0; p < n_pairs; ++p)

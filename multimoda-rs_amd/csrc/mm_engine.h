@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/mm_hausdorff.h"
@@ -100,5 +101,10 @@ struct Plan {
 // One-shot batch on the engine's transient buffers (build, run, fetch).
 int run_batch(Engine* e, const std::vector<SetRef>& sets, const std::vector<PairSpec>& pairs, int precision,
               BatchResult& out);
+
+// hausdorff_distance of set pairs (indices into `sets`), exact f64 on the device; shared sets are
+// staged once.  out[pairs.size()].
+int hausdorff_sets(Engine* e, const std::vector<SetRef>& sets, const std::vector<std::array<int32_t, 2>>& pairs,
+                   double* out);
 
 }  // namespace mm

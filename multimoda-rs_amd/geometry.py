@@ -101,6 +101,10 @@ class FlatGeometry:
     ref: Optional[np.ndarray] = None      # (F,3) f64
     label: str = ""
     meta: dict = field(default_factory=dict)   # host-only bookkeeping (extras layout, wall thickness records)
+    # Frame.lumen.centroid (Contour.centroid): read by the centerline placement only (centerline.py);
+    # None = every contour centroid is None and align_frame falls back to the mean of the points
+    has_lumen_centroid: Optional[np.ndarray] = None   # (F,) u8
+    lumen_centroids: Optional[np.ndarray] = None      # (F,3) f64
 
     # ------------------------------------------------------------------------------
     @property
@@ -150,7 +154,7 @@ class FlatGeometry:
         return FlatGeometry(cp(self.ids), cp(self.lumen_ids), cp(self.orig_frames), cp(self.centroids),
                             cp(self.lumen_off), cp(self.lumen), cp(self.cath_off), cp(self.cath),
                             cp(self.extra_off), cp(self.extra), cp(self.has_ref), cp(self.ref), self.label,
-                            dict(self.meta))
+                            dict(self.meta), cp(self.has_lumen_centroid), cp(self.lumen_centroids))
 
     def frame_lumen(self, i: int) -> np.ndarray:
         return self.lumen[self.lumen_off[i]:self.lumen_off[i + 1]]

@@ -67,3 +67,48 @@ def synthetic_pullback(n_frames: int, n_points: int = 501, pullback_id: int = 0,
 def synthetic_case(n_frames: int, n_points: int = 501, seed: int = 1234) -> List[FlatGeometry]:
     """The four pullbacks of one full (4-phase) alignment."""
     return [synthetic_pullback(n_frames, n_points, pullback_id=i, seed=seed) for i in range(4)]
+
+
+def synthetic_centerline_case(n_frames: int = 24, n_points: int = 200, n_ccta: int = 4000, seed: int = 7,
+                              true_rotation_deg: float = 37.0, true_index: int = 12, noise: float = 0.03):
+    """A centerline-placement problem with a known answer (BASELINE config 5 shape; generator is ours):
+    a curved vessel centerline, one pullback geometry, and a CCTA-like point cloud sampled from that
+    geometry placed on the centerline at index ``true_index`` after an in-plane rotation of
+    ``true_rotation_deg``, plus noise and off-vessel clutter.
+
+    Returns dict(centerline, geometry, main_ref_pt, ccw_ref_pt, cw_ref_pt, points, truth=...).
+    """
+    from . import centerline as CL
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = synthetic_pullback(n_frames, n_points, pullback_id=0, seed=seed, torsion_sigma_deg=0.5)
+    CL.with_lumen_centroids(g)
+    # vessel path: gentle 3-D curve, z descending, raw spacing 0.2 mm (resampled to ~0.5 mm by preprocess)
+    s = np.arange(0.0, 0.5 * n_frames + 30.0, 0.2)
+    path = np.stack([12.0 + 6.0 * np.sin(s / 17.0), -200.0 + 5.0 * np.cos(s / 23.0), 1750.0 - 0.93 * s], axis=1)
+    cl = CL.Centerline.from_contour_points(path)
+    rcl, _ = CL.preprocess_centerline(cl, g)
+    placed = g.copy()
+    CL.rotate_geometry(placed, math.radians(true_rotation_deg))
+    ref_pt = rcl.xyz()[true_index]
+    CL.apply_transformations([placed], rcl, ref_pt)
+    lum = placed.lumen
+    pick = rng.choice(lum.shape[0], size=min(n_ccta, lum.shape[0]), replace=False)
+    cloud = lum[np.sort(pick)] + rng.normal(0.0, noise, size=(pick.shape[0], 3))
+    clutter = ref_pt + rng.normal(0.0, 1.0, size=(max(n_ccta // 20, 1), 3)) * np.array([30.0, 30.0, 30.0])
+    points = np.concatenate([cloud, clutter], axis=0)
+    # landmarks: where the reference frame's points with point_index = ref, 0 and n/2 land; the
+    # three-point sweep rotates without re-sorting (align_algorithms.rs:286-311), so these come from
+    # the un-sorted rotation of frame 0
+    ref_index = int(np.argmin(np.linalg.norm(g.frame_lumen(0) - g.ref[0], axis=1)))
+    g.meta["ref_point_index"] = ref_index
+    tmp = g.copy()
+    f0 = tmp.frame_lumen(0)
+    c, s_ = math.cos(math.radians(true_rotation_deg)), math.sin(math.radians(true_rotation_deg))
+    dx, dy = f0[:, 0] - tmp.centroids[0, 0], f0[:, 1] - tmp.centroids[0, 1]
+    f0[:, 0], f0[:, 1] = dx * c - dy * s_ + tmp.centroids[0, 0], dx * s_ + dy * c + tmp.centroids[0, 1]
+    CL.apply_transformations([tmp], rcl, ref_pt)
+    f0 = tmp.frame_lumen(0)
+    return dict(centerline=cl, geometry=g, main_ref_pt=f0[ref_index] + rng.normal(0.0, noise, 3),
+                ccw_ref_pt=f0[0] + rng.normal(0.0, noise, 3), cw_ref_pt=f0[n_points // 2] + rng.normal(0.0, noise, 3),
+                points=points, truth=dict(rotation_deg=true_rotation_deg, cl_index=true_index, placed=placed))

@@ -556,6 +556,7 @@ static int three_point_initial(const orc_clpoint* rcl, size_t nrcl, orc_clgeom**
     const orc_clgeom* prim = geoms[0];
     size_t ref_idx;
     if (orc_find_ref_frame_idx(prim->g, &ref_idx) != 0) return -4;                   /* align.rs:82-85 */
+    if (ref_idx >= (size_t)prim->g->n_frames) return -4;  /* frames[ref_idx]: Frame.id used as an index, Rust would panic */
     if (!(prim->g->has_ref && prim->g->has_ref[ref_idx])) return -5;                 /* :86-89 */
     *cl_ref_idx = orc_cl_find_ref_idx(rcl, nrcl, p_main);                            /* :90 */
     int hc = prim->has_lumen_centroid && prim->has_lumen_centroid[ref_idx];

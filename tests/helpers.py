@@ -7,9 +7,22 @@ import numpy as np
 def to_oracle(orc, g):
     """FlatGeometry -> OracleGeometry (deep copy; same CSR layout)."""
     cp = lambda a: None if a is None else a.copy()
-    return orc.OracleGeometry(cp(g.ids), cp(g.lumen_ids), cp(g.orig_frames), cp(g.centroids), cp(g.lumen_off),
-                              cp(g.lumen), cp(g.cath_off), cp(g.cath), cp(g.extra_off), cp(g.extra),
-                              cp(g.has_ref), cp(g.ref), g.label)
+    og = orc.OracleGeometry(cp(g.ids), cp(g.lumen_ids), cp(g.orig_frames), cp(g.centroids), cp(g.lumen_off),
+                            cp(g.lumen), cp(g.cath_off), cp(g.cath), cp(g.extra_off), cp(g.extra),
+                            cp(g.has_ref), cp(g.ref), g.label)
+    # centerline placement extras (orc_clgeom)
+    if getattr(g, "lumen_centroids", None) is not None:
+        og.lumen_centroids = g.lumen_centroids.copy()
+        og.has_lumen_centroid = (g.has_lumen_centroid.copy() if g.has_lumen_centroid is not None
+                                 else np.ones(g.n_frames, dtype=np.uint8))
+    counts = g.meta.get("extra_counts") if hasattr(g, "meta") else None
+    if g.extra_off is not None and counts:
+        kinds = [k for k in ("eem", "calcification", "sidebranch") if k in counts]
+        per = np.stack([np.asarray(counts[k], dtype=np.int64) for k in kinds], axis=1)
+        ko = np.zeros(per.size + 1, dtype=np.int64)
+        ko[1:] = np.cumsum(per.reshape(-1))
+        og.n_extra_kinds, og.extra_kind_off = len(kinds), ko
+    return og
 
 
 def geoms_equal(g, og) -> bool:
@@ -21,7 +34,17 @@ def geoms_equal(g, og) -> bool:
         ok = ok and np.array_equal(g.extra, og.extra)
     if g.ref is not None:
         ok = ok and np.array_equal(g.ref, og.ref)
+    if getattr(g, "lumen_centroids", None) is not None and og.lumen_centroids is not None:
+        ok = ok and np.array_equal(g.lumen_centroids, og.lumen_centroids)
     return bool(ok)
+
+
+def to_oracle_cl(ocl, centerline):
+    """multimoda_rs_amd.Centerline -> oracle CL array (same 64-byte record layout)."""
+    a = np.zeros(len(centerline), dtype=ocl.CL_DTYPE)
+    for f in ocl.CL_DTYPE.names:
+        a[f] = centerline.points[f]
+    return a
 
 
 def blob(rng, n, radius=2.5, centre=(4.5, 4.5), noise=0.05):

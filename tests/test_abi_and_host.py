@@ -20,15 +20,21 @@ def built():
     ge.build()
 
 
-def test_header_symbols_exported(built, mm):
-    hdr = open(os.path.join(ROOT, "include", "mm_hausdorff.h")).read()
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 20
+    return set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_header_symbols_exported(built, mm):
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["mm_centerline.h", "mm_hausdorff.h"]
     L = mm._native.lib()
-    for n in sorted(names):
-        assert hasattr(L, n), f"{n} declared in include/mm_hausdorff.h but not exported"
-    assert names == set(mm._native.EXPORTS)
+    for header, exports in (("mm_hausdorff.h", mm._native.EXPORTS), ("mm_centerline.h", mm._native.EXPORTS_CENTERLINE)):
+        names = _declared(header)
+        assert len(names) >= 10
+        for n in sorted(names):
+            assert hasattr(L, n), f"{n} declared in include/{header} but not exported"
+        assert names == set(exports)
     assert b"gfx950" in L.mm_version()
 
 

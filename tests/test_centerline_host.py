@@ -1,0 +1,176 @@
+"""CPU-side tests of the centerline placement path: every host f64 stage of
+csrc/mm_centerline.cpp (through the C ABI, include/mm_centerline.h) is bit-identical to the oracle
+(oracle/mm_oracle_cl.c).  None of these entry points touches the GPU; the refinement grid, which
+does, is tested in test_gpu_centerline.py."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import geoms_equal, to_oracle, to_oracle_cl
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+
+
+@pytest.fixture(scope="module")
+def ocl(oracle):
+    from oracle import oracle_cl
+    oracle_cl.lib()
+    return oracle_cl
+
+
+@pytest.fixture(scope="module")
+def case(built, mm):
+    return mm.synth.synthetic_centerline_case(n_frames=14, n_points=96, n_ccta=1500, seed=11,
+                                              true_rotation_deg=-52.0, true_index=9)
+
+
+def _cl_equal(a, b):
+    return all(np.array_equal(a[f], b[f]) for f in ("x", "y", "z", "tx", "ty", "tz", "radius", "branch_id"))
+
+
+def test_centerline_from_points_and_ref_idx(built, mm, ocl):
+    rng = np.random.default_rng(0)
+    pts = np.cumsum(rng.normal(0, 1, size=(40, 3)), axis=0)
+    cl = mm.Centerline.from_contour_points(pts)
+    assert _cl_equal(cl.points, ocl.centerline_from_points(pts))
+    for q in rng.normal(0, 5, size=(20, 3)):
+        assert cl.find_reference_cl_point_idx(q) == ocl.find_ref_idx(to_oracle_cl(ocl, cl), q)
+    with pytest.raises(RuntimeError, match="at least two points"):
+        mm.Centerline.from_contour_points([[0.0, 0.0, 0.0]])
+
+
+def test_numpy_to_centerline_nan_handling(built, mm):          # multimodars/_converters.py:605-686
+    a = np.array([[0.0, 0, 0], [np.nan, 0, 1], [2.0, 0, 2]])
+    cl = mm.numpy_to_centerline(a)
+    assert cl.points["x"].tolist() == [0.0, 1.0, 2.0]
+    with pytest.raises(ValueError, match="All values are NaN"):
+        mm.numpy_to_centerline(np.array([[np.nan, 0, 0], [np.nan, 0, 1]]))
+    with pytest.raises(ValueError, match=r"\(N,3\)"):
+        mm.numpy_to_centerline(np.zeros((3, 2)))
+
+
+def test_preprocess_centerline_matches_oracle(built, mm, ocl, oracle, case):
+    g = case["geometry"]
+    cl = case["centerline"]
+    rcl, sp = mm.preprocess_centerline(cl, g)
+    ocl_cl, osp = ocl.preprocess_centerline(to_oracle_cl(ocl, cl), to_oracle(oracle, g))
+    assert sp == osp and len(rcl) == len(ocl_cl) and _cl_equal(rcl.points, ocl_cl)
+    # ascending z input is reversed, side branches are dropped, a one-frame mesh falls back to the mean segment
+    rev = mm.Centerline(cl.points[::-1].copy())
+    rev.points["branch_id"][::7] = 3
+    g1 = mm.FlatGeometry.from_frames([g.frame_lumen(0)])
+    r2, s2 = mm.preprocess_centerline(rev, g1)
+    o2, os2 = ocl.preprocess_centerline(to_oracle_cl(ocl, rev), to_oracle(oracle, g1))
+    assert s2 == os2 and _cl_equal(r2.points, o2)
+    only_side = mm.Centerline(cl.points.copy())
+    only_side.points["branch_id"] = 1
+    with pytest.raises(RuntimeError, match="no branch-0 points"):
+        mm.preprocess_centerline(only_side, g)
+
+
+def test_sort_contour_points_matches_oracle(built, mm, ocl):
+    rng = np.random.default_rng(3)
+    L = mm._native.lib()
+    for n in (1, 2, 3, 7, 64, 501):
+        p = rng.normal(0, 2, size=(n, 3))
+        if n >= 7:
+            p[3] = p[5]                       # duplicate point: equal keys keep their order (stable sort)
+            p[1, 1] = p[:, 1].max(); p[6, 1] = p[1, 1]   # two maxima of y: the later one starts the contour
+        q = np.ascontiguousarray(p.copy())
+        assert L.mm_sort_contour_points(mm._native._ptr(q), n) == 0
+        assert np.array_equal(q, ocl.sort_contour_points(p))
+
+
+def test_rotate_geometry_matches_oracle(built, mm, ocl, oracle):
+    g = mm.synthetic_pullback(6, 120, pullback_id=2)
+    mm.centerline.with_lumen_centroids(g)
+    og = to_oracle(oracle, g)
+    for ang in (0.3, -1.9, 0.0, math.pi):
+        mm.centerline.rotate_geometry(g, ang)
+        ocl.rotate_geometry(og, ang)
+        assert geoms_equal(g, og)
+
+
+def test_apply_transformations_matches_oracle(built, mm, ocl, oracle, case):
+    g = case["geometry"].copy()
+    h = mm.synthetic_pullback(g.n_frames, 80, pullback_id=1, seed=5)      # second geometry of a pair
+    mm.centerline.with_lumen_centroids(h)
+    rcl, _ = mm.preprocess_centerline(case["centerline"], g)
+    og, oh, orcl = to_oracle(oracle, g), to_oracle(oracle, h), to_oracle_cl(ocl, rcl)
+    ref = rcl.xyz()[5] + 0.01
+    n = mm.centerline.apply_transformations([g, h], rcl, ref)
+    assert n == ocl.apply_transformations([og, oh], orcl, ref) == g.n_frames
+    assert geoms_equal(g, og) and geoms_equal(h, oh)
+    # frames that run past the end of the centerline keep their place
+    g2 = case["geometry"].copy()
+    og2 = to_oracle(oracle, g2)
+    tail = rcl.xyz()[len(rcl) - 4]
+    n2 = mm.centerline.apply_transformations([g2], rcl, tail)
+    assert n2 == ocl.apply_transformations([og2], orcl, tail) == 4
+    assert geoms_equal(g2, og2)
+    assert np.array_equal(g2.lumen[g2.lumen_off[4]:], case["geometry"].lumen[g2.lumen_off[4]:])
+    # without contour centroids align_frame falls back to the mean and the frame centroid becomes 0 (:532)
+    g3 = case["geometry"].copy(); g3.lumen_centroids = None; g3.has_lumen_centroid = None
+    og3 = to_oracle(oracle, g3)
+    mm.centerline.apply_transformations([g3], rcl, ref)
+    ocl.apply_transformations([og3], orcl, ref)
+    assert geoms_equal(g3, og3) and not g3.centroids.any()
+
+
+def test_best_rotation_three_point_matches_oracle(built, mm, ocl, case):
+    g = case["geometry"]
+    rcl, _ = mm.preprocess_centerline(case["centerline"], g)
+    orcl = to_oracle_cl(ocl, rcl)
+    k = rcl.find_reference_cl_point_idx(case["main_ref_pt"])
+    for step_deg, cen in ((1.0, g.lumen_centroids[0]), (0.37, None), (22.5, g.lumen_centroids[0])):
+        a = mm.centerline.best_rotation_three_point(g.frame_lumen(0), cen, g.meta["ref_point_index"],
+                                                    case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"],
+                                                    math.radians(step_deg), rcl.points[k])
+        b = ocl.best_rotation_three_point(g.frame_lumen(0), cen, g.meta["ref_point_index"], case["main_ref_pt"],
+                                          case["ccw_ref_pt"], case["cw_ref_pt"], math.radians(step_deg), orcl[k])
+        assert a == b
+    assert abs(math.degrees(a) - (360.0 - 52.0)) <= 22.5 + 1e-9
+
+
+def test_align_three_point_and_manual_match_oracle(built, mm, ocl, oracle, case):
+    g = case["geometry"]
+    ocl_cl = to_oracle_cl(ocl, case["centerline"])
+    og = to_oracle(oracle, g)
+    out, sp, rot_deg = mm.align_three_point(case["centerline"], g, case["main_ref_pt"], case["ccw_ref_pt"],
+                                            case["cw_ref_pt"], angle_step_deg=1.0)
+    osp, orot = ocl.align_three_point(ocl_cl, [og], g.meta["ref_point_index"], case["main_ref_pt"],
+                                      case["ccw_ref_pt"], case["cw_ref_pt"], math.radians(1.0))
+    assert sp == osp and rot_deg == orot * (180.0 / math.pi)
+    assert geoms_equal(out, og)
+    assert np.array_equal(g.lumen, case["geometry"].lumen)              # the input is not modified
+    # the sweep lands within a step of the constructed twist and the placement reproduces the truth
+    assert abs(rot_deg - (360.0 - 52.0)) <= 1.0 + 1e-9
+    assert np.abs(out.lumen - case["truth"]["placed"].lumen).max() < 0.12
+
+    pair = mm.GeometryPair(g, mm.synthetic_pullback(g.n_frames, 96, pullback_id=1, seed=11), "a - b")
+    mm.centerline.with_lumen_centroids(pair.geom_b)
+    oa, ob = to_oracle(oracle, pair.geom_a), to_oracle(oracle, pair.geom_b)
+    ref = case["truth"]["placed"].centroids[0]
+    outp, sp2, rot2 = mm.align_manual(case["centerline"], pair, -52.0, ref)
+    osp2, orot2 = ocl.align_manual(ocl_cl, [oa, ob], -52.0, ref)
+    assert sp2 == osp2 and rot2 == orot2 * (180.0 / math.pi) == pytest.approx(-52.0, abs=1e-12)
+    assert geoms_equal(outp.geom_a, oa) and geoms_equal(outp.geom_b, ob)
+    assert np.abs(outp.geom_a.lumen - case["truth"]["placed"].lumen).max() < 1e-9
+
+
+def test_align_errors(built, mm, case):
+    g = case["geometry"].copy()
+    g.has_ref[:] = 0
+    with pytest.raises(RuntimeError, match="No reference point found"):
+        mm.align_three_point(case["centerline"], g, case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"])
+    with pytest.raises(NotImplementedError):
+        mm.align_manual(case["centerline"], case["geometry"], 10.0, (0, 0, 0), write=True)
+    with pytest.raises(NotImplementedError):
+        mm.align_manual(case["centerline"], case["geometry"], 10.0, (0, 0, 0), align_wall_anomalous=True)
+    with pytest.raises(TypeError):
+        mm.align_manual(case["centerline"], object(), 10.0, (0, 0, 0))

@@ -1,0 +1,96 @@
+"""GPU parity tests of the Hausdorff refinement grid (third call site of the search,
+align_algorithms.rs:339-451) and of align_combined (align.rs:169-285), through the C ABI
+(include/mm_centerline.h) against the oracle: bit-exact costs, winner and transformed geometry."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import geoms_equal, to_oracle, to_oracle_cl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ocl(oracle):
+    from oracle import oracle_cl
+    oracle_cl.lib()
+    return oracle_cl
+
+
+def _aligned(mm, case):
+    """`aligned` of align_combined_rs (:219-223): rotated by the three-point result and placed."""
+    g = case["geometry"]
+    out, _, rot_deg = mm.align_three_point(case["centerline"], g, case["main_ref_pt"], case["ccw_ref_pt"],
+                                           case["cw_ref_pt"], angle_step_deg=1.0)
+    rcl, _ = mm.preprocess_centerline(case["centerline"], g)
+    return out, rcl, rcl.find_reference_cl_point_idx(case["main_ref_pt"])
+
+
+@pytest.mark.parametrize("n_frames,n_points,n_ccta,idx_range", [
+    (10, 64, 600, 2),        # small sets: search kernel with a one-angle table
+    (16, 200, 3000, 1),      # downsampled frames (n_down < points per frame)
+    (24, 300, 9000, 2),      # both sets above the LDS budget: streaming kernel
+    (12, 80, 500, 0),        # index_search_range == 0: initial index only (:363-367)
+])
+def test_refine_grid_matches_oracle(engine, oracle, ocl, mm, n_frames, n_points, n_ccta, idx_range):
+    case = mm.synth.synthetic_centerline_case(n_frames=n_frames, n_points=n_points, n_ccta=n_ccta, seed=n_frames,
+                                              true_rotation_deg=23.0, true_index=8)
+    aligned, rcl, idx0 = _aligned(mm, case)
+    og, orcl = to_oracle(oracle, aligned), to_oracle_cl(ocl, rcl)
+    rng_, step = math.radians(6.0), math.radians(1.0)
+    ba, bi, mh, costs = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, idx0, 0.0, case["points"],
+                                                                 rng_, step, idx_range)
+    oba, obi, omh, ocosts = ocl.refine_alignment_hausdorff([og], orcl, idx0, 0.0, case["points"], rng_, step,
+                                                           idx_range)
+    assert len(costs) == len(ocosts) > 0
+    assert np.array_equal(costs, ocosts)                      # bit-exact f64 Hausdorff of every candidate
+    assert (ba, bi, mh) == (oba, obi, omh)
+    assert np.array_equal(aligned.lumen, og.lumen)            # the target is not modified by the search
+
+
+def test_refine_grid_edge_cases(engine, oracle, ocl, mm):
+    case = mm.synth.synthetic_centerline_case(n_frames=10, n_points=64, n_ccta=400, seed=3, true_index=2)
+    aligned, rcl, idx0 = _aligned(mm, case)
+    og, orcl = to_oracle(oracle, aligned), to_oracle_cl(ocl, rcl)
+    step = math.radians(2.0)
+    # negative indices and segments that overrun the centerline are skipped (:371-378)
+    for start, rng_idx in ((1, 3), (len(rcl) - aligned.n_frames - 2, 3)):
+        r = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, start, 0.1, case["points"],
+                                                     math.radians(4.0), step, rng_idx)
+        o = ocl.refine_alignment_hausdorff([og], orcl, start, 0.1, case["points"], math.radians(4.0), step, rng_idx)
+        assert np.array_equal(r[3], o[3]) and r[:3] == o[:3] and 0 < len(r[3]) < (2 * rng_idx + 1) * 5
+    # no CCTA point inside any bounding box: nothing is evaluated, the initial values come back (:406-409)
+    far = case["points"] + 1.0e4
+    r = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, idx0, 0.25, far, math.radians(4.0), step, 1)
+    o = ocl.refine_alignment_hausdorff([og], orcl, idx0, 0.25, far, math.radians(4.0), step, 1)
+    assert r[0] == o[0] == 0.25 and r[1] == o[1] == idx0 and len(r[3]) == len(o[3]) == 0
+    assert r[2] == o[2] == np.finfo(np.float64).max
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_align_combined_matches_oracle_and_truth(engine, oracle, ocl, mm, pair):
+    case = mm.synth.synthetic_centerline_case(n_frames=20, n_points=160, n_ccta=3000, seed=21,
+                                              true_rotation_deg=37.0, true_index=12)
+    g = case["geometry"]
+    geo = g
+    if pair:
+        b = mm.synthetic_pullback(g.n_frames, 128, pullback_id=1, seed=21)
+        mm.centerline.with_lumen_centroids(b)
+        geo = mm.GeometryPair(g, b, "dia - sys")
+    ogs = [to_oracle(oracle, x) for x in ([geo.geom_a, geo.geom_b] if pair else [g])]
+    out, sp, rot_deg = mm.align_combined(case["centerline"], geo, case["main_ref_pt"], case["ccw_ref_pt"],
+                                         case["cw_ref_pt"], case["points"], angle_step_deg=1.0, angle_range_deg=5.0,
+                                         index_range=2, engine=engine)
+    osp, orot, oidx = ocl.align_combined(to_oracle_cl(ocl, case["centerline"]), ogs, g.meta["ref_point_index"],
+                                         case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"], case["points"],
+                                         math.radians(1.0), math.radians(5.0), 2)
+    first = out.geom_a if pair else out
+    assert sp == osp and rot_deg == orot * (180.0 / math.pi) and first.meta["refined_cl_ref_idx"] == oidx
+    assert geoms_equal(first, ogs[0])
+    if pair:
+        assert geoms_equal(out.geom_b, ogs[1])
+    # and it recovers the constructed pose: twist within a step, the same centerline index
+    assert abs(rot_deg - 37.0) <= 1.0 + 1e-9 and oidx == 12
+    assert np.abs(first.lumen - case["truth"]["placed"].lumen).max() < 0.1
+    assert first.meta["refine_evals"] == 5 * 11
