@@ -70,11 +70,12 @@ def synthetic_case(n_frames: int, n_points: int = 501, seed: int = 1234) -> List
 
 
 def synthetic_centerline_case(n_frames: int = 24, n_points: int = 200, n_ccta: int = 4000, seed: int = 7,
-                              true_rotation_deg: float = 37.0, true_index: int = 12, noise: float = 0.03):
+                              true_rotation_deg: float = 37.0, true_index: int = 12, noise: float = 0.03,
+                              clutter_frac: float = 0.0):
     """A centerline-placement problem with a known answer (BASELINE config 5 shape; generator is ours):
     a curved vessel centerline, one pullback geometry, and a CCTA-like point cloud sampled from that
     geometry placed on the centerline at index ``true_index`` after an in-plane rotation of
-    ``true_rotation_deg``, plus noise and off-vessel clutter.
+    ``true_rotation_deg``, plus noise and (optionally) off-vessel clutter.
 
     Returns dict(centerline, geometry, main_ref_pt, ccw_ref_pt, cw_ref_pt, points, truth=...).
     """
@@ -95,7 +96,8 @@ def synthetic_centerline_case(n_frames: int = 24, n_points: int = 200, n_ccta: i
     lum = placed.lumen
     pick = rng.choice(lum.shape[0], size=min(n_ccta, lum.shape[0]), replace=False)
     cloud = lum[np.sort(pick)] + rng.normal(0.0, noise, size=(pick.shape[0], 3))
-    clutter = ref_pt + rng.normal(0.0, 1.0, size=(max(n_ccta // 20, 1), 3)) * np.array([30.0, 30.0, 30.0])
+    # off-vessel points (other structures of a CCTA segmentation); the bounding-box filter keeps some of them
+    clutter = ref_pt + rng.normal(0.0, 30.0, size=(int(n_ccta * clutter_frac), 3))
     points = np.concatenate([cloud, clutter], axis=0)
     # landmarks: where the reference frame's points with point_index = ref, 0 and n/2 land; the
     # three-point sweep rotates without re-sorting (align_algorithms.rs:286-311), so these come from

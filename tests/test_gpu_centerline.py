@@ -35,7 +35,7 @@ def _aligned(mm, case):
 ])
 def test_refine_grid_matches_oracle(engine, oracle, ocl, mm, n_frames, n_points, n_ccta, idx_range):
     case = mm.synth.synthetic_centerline_case(n_frames=n_frames, n_points=n_points, n_ccta=n_ccta, seed=n_frames,
-                                              true_rotation_deg=23.0, true_index=8)
+                                              true_rotation_deg=23.0, true_index=8, clutter_frac=0.05)
     aligned, rcl, idx0 = _aligned(mm, case)
     og, orcl = to_oracle(oracle, aligned), to_oracle_cl(ocl, rcl)
     rng_, step = math.radians(6.0), math.radians(1.0)
@@ -92,8 +92,8 @@ def test_align_combined_matches_oracle_and_truth(engine, oracle, ocl, mm, pair):
     assert geoms_equal(first, ogs[0])
     if pair:
         assert geoms_equal(out.geom_b, ogs[1])
-    # and it lands on the constructed pose: the twist within two steps; the centerline index is only
-    # weakly identifiable (the metric is 2-D and the vessel runs mostly along z), it stays in the window
-    assert abs(rot_deg - 37.0) <= 2.0 + 1e-9 and abs(oidx - 12) <= 2
-    assert np.abs(first.lumen[:, :2] - case["truth"]["placed"].lumen[:, :2]).max() < 1.2   # two index steps of ~0.52 mm
+    # and it recovers the constructed pose (no clutter in this cloud): the three-point sweep is off by a
+    # step because of the landmark noise, the refinement corrects it
+    assert rot_deg == pytest.approx(37.0, abs=1e-9) and oidx == 12
+    assert np.abs(first.lumen - case["truth"]["placed"].lumen).max() < 1e-9
     assert first.meta["refine_evals"] == 5 * 11
