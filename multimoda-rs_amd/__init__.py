@@ -22,6 +22,9 @@ from .api import (GeometryPair, align_frames_in_geometries, from_array_doublepai
 from .centerline import (Centerline, align_combined, align_manual, align_three_point, numpy_to_centerline,
                          preprocess_centerline)
 from . import centerline
+from . import ccta
+from .ccta import (adjust_diameter_centerline_morphing_simple, find_aortic_scaling, find_aortic_wall_scaling,
+                   find_distal_and_proximal_scaling, find_proximal_distal_scaling)
 from .extension import ShiftRotationSearch
 from .synth import synthetic_case, synthetic_pullback
 
@@ -38,6 +41,8 @@ __all__ = [
     "ShiftRotationSearch",
     "Centerline", "numpy_to_centerline", "preprocess_centerline", "align_three_point", "align_manual",
     "align_combined", "centerline",
+    "ccta", "adjust_diameter_centerline_morphing_simple", "find_proximal_distal_scaling", "find_aortic_scaling",
+    "find_aortic_wall_scaling", "find_distal_and_proximal_scaling",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F32_FAST", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

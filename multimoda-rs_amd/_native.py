@@ -62,6 +62,13 @@ class MMGeometry(C.Structure):
     ]
 
 
+# include/mm_ccta.h
+EXPORTS_CCTA = [
+    "mm_nn_min_sq_batch", "mm_symmetric_nn_distance", "mm_diameter_morphing", "mm_find_region_points",
+    "mm_aortic_diameter_optimization", "mm_diameter_optimization", "mm_wall_diameter_optimization",
+]
+
+
 class MMClGeometry(C.Structure):
     """``mm_cl_geometry`` (include/mm_centerline.h)."""
     _fields_ = [
@@ -222,6 +229,21 @@ def lib():
     L.mm_align_combined.restype = I
     L.mm_align_combined.argtypes = [P, P, I64, P, I, U32, P, P, P, P, I64, D, D, I64, I, C.POINTER(D), C.POINTER(D),
                                     C.POINTER(I64), C.POINTER(I64)]
+    # include/mm_ccta.h
+    L.mm_nn_min_sq_batch.restype = I
+    L.mm_nn_min_sq_batch.argtypes = [P, I, P, P, I, P, P, P, P]
+    L.mm_symmetric_nn_distance.restype = I
+    L.mm_symmetric_nn_distance.argtypes = [P, P, I64, P, I64, C.POINTER(D)]
+    L.mm_diameter_morphing.restype = I
+    L.mm_diameter_morphing.argtypes = [P, I64, P, I64, D, P]
+    L.mm_find_region_points.restype = I64
+    L.mm_find_region_points.argtypes = [P, P, I64, P, I64, I64, P, P]
+    L.mm_aortic_diameter_optimization.restype = I
+    L.mm_aortic_diameter_optimization.argtypes = [P, P, I64, P, I64, P, I64, C.POINTER(D), P]
+    L.mm_diameter_optimization.restype = I
+    L.mm_diameter_optimization.argtypes = [P, P, I64, I64, I64, P, I64, P, I64, P, I64, C.POINTER(D), C.POINTER(D)]
+    L.mm_wall_diameter_optimization.restype = I
+    L.mm_wall_diameter_optimization.argtypes = [P, I64, P, P, I64, C.POINTER(D)]
     _lib = L
     return L
 

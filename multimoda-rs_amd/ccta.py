@@ -1,0 +1,126 @@
+"""CCTA diameter search, mirroring the reference's entry points
+``adjust_diameter_centerline_morphing_simple`` / ``find_proximal_distal_scaling`` /
+``find_aortic_scaling`` / ``find_aortic_wall_scaling`` (src/ccta/binding/ccta_py.rs:263-481;
+implementation src/ccta/adjust_mesh/scale_coronary.rs:8-261) and the wrapper
+``find_distal_and_proximal_scaling`` of multimodars/ccta/scaling.py:84-145.
+
+Same argument names, order and meaning; points are ``(N, 3)`` arrays (or lists of tuples).  Each
+search scores its 41 scalings in one GPU batch (exact f64 nearest-neighbour minima,
+csrc/mm_nn_kernels.hip); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+from . import geometry as G
+from .centerline import Centerline
+
+SCALING_STEPS = 41
+
+
+def _p3(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, 3))
+
+
+def _engine(engine: Optional[N.Engine]) -> N.Engine:
+    if engine is not None:
+        return engine
+    from .api import default_engine
+    return default_engine()
+
+
+def nn_min_sq(a, b, engine: Optional[N.Engine] = None) -> np.ndarray:
+    """min_b |a_i - b|^2 for every a_i (the inner fold of symmetric_nn_distance / find_region_points)."""
+    a, b = _p3(a), _p3(b)
+    xyz = np.ascontiguousarray(np.concatenate([a, b], axis=0))
+    set_off = np.array([0, a.shape[0], a.shape[0] + b.shape[0]], dtype=np.int64)
+    q, p = np.array([0], dtype=np.int32), np.array([1], dtype=np.int32)
+    out_off = np.array([0, a.shape[0]], dtype=np.int64)
+    out = np.zeros(a.shape[0], dtype=np.float64)
+    N.check(N.lib().mm_nn_min_sq_batch(_engine(engine).handle, 2, N._ptr(set_off), N._ptr(xyz), 1, N._ptr(q),
+                                       N._ptr(p), N._ptr(out_off), N._ptr(out)), "nn_min_sq")
+    return out
+
+
+def symmetric_nn_distance(a, b, engine: Optional[N.Engine] = None) -> float:
+    """scale_coronary.rs:188-216 (RMS of the two mean squared nearest-neighbour distances)."""
+    a, b = _p3(a), _p3(b)
+    out = C.c_double(0.0)
+    N.check(N.lib().mm_symmetric_nn_distance(_engine(engine).handle, N._ptr(a), a.shape[0], N._ptr(b), b.shape[0],
+                                             C.byref(out)), "symmetric_nn_distance")
+    return out.value
+
+
+def adjust_diameter_centerline_morphing_simple(centerline: Centerline, points, diameter_adjustment_mm: float) -> np.ndarray:
+    """ccta_py.rs:263-278: every point moves by ``diameter_adjustment_mm`` along the direction from
+    its closest centerline point."""
+    p = _p3(points)
+    out = np.zeros_like(p)
+    N.check(N.lib().mm_diameter_morphing(N._ptr(centerline.points), len(centerline), N._ptr(p), p.shape[0],
+                                         float(diameter_adjustment_mm), N._ptr(out)), "diameter_morphing")
+    return out
+
+
+def find_region_points(anomalous_points, reference_points, n_points: int, engine: Optional[N.Engine] = None):
+    """scale_coronary.rs:133-183 -> (selected, remaining)."""
+    a, r = _p3(anomalous_points), _p3(reference_points)
+    sel, rem = np.zeros_like(a), np.zeros_like(a)
+    k = N.lib().mm_find_region_points(_engine(engine).handle, N._ptr(a), a.shape[0], N._ptr(r), r.shape[0],
+                                      int(n_points), N._ptr(sel), N._ptr(rem))
+    if k < 0:
+        N.check(int(k), "find_region_points")
+    return sel[:k].copy(), rem[: a.shape[0] - k].copy()
+
+
+def find_proximal_distal_scaling(anomalous_points, n_proximal: int, n_distal: int, centerline: Centerline,
+                                 proximal_reference, distal_reference,
+                                 engine: Optional[N.Engine] = None) -> Tuple[float, float]:
+    """ccta_py.rs:389-407 / multimodars/_processing.py:1431-1473."""
+    a, pr, dr = _p3(anomalous_points), _p3(proximal_reference), _p3(distal_reference)
+    pb, db = C.c_double(0.0), C.c_double(0.0)
+    N.check(N.lib().mm_diameter_optimization(_engine(engine).handle, N._ptr(a), a.shape[0], int(n_proximal),
+                                             int(n_distal), N._ptr(centerline.points), len(centerline), N._ptr(pr),
+                                             pr.shape[0], N._ptr(dr), dr.shape[0], C.byref(pb), C.byref(db)),
+            "find_proximal_distal_scaling")
+    return pb.value, db.value
+
+
+def find_aortic_scaling(intramural_points, reference_points, centerline: Centerline,
+                        engine: Optional[N.Engine] = None, return_distances: bool = False):
+    """ccta_py.rs:428-442."""
+    i, r = _p3(intramural_points), _p3(reference_points)
+    best = C.c_double(0.0)
+    d = np.zeros(SCALING_STEPS, dtype=np.float64)
+    N.check(N.lib().mm_aortic_diameter_optimization(_engine(engine).handle, N._ptr(i), i.shape[0], N._ptr(r),
+                                                    r.shape[0], N._ptr(centerline.points), len(centerline),
+                                                    C.byref(best), N._ptr(d)), "find_aortic_scaling")
+    return (best.value, d) if return_distances else best.value
+
+
+def find_aortic_wall_scaling(cl_aorta: Centerline, ref_pt_coronary, aortic_pts) -> float:
+    """ccta_py.rs:467-481 (host only)."""
+    r = np.ascontiguousarray(np.asarray(ref_pt_coronary, dtype=np.float64).reshape(3))
+    a = _p3(aortic_pts)
+    out = C.c_double(0.0)
+    N.check(N.lib().mm_wall_diameter_optimization(N._ptr(cl_aorta.points), len(cl_aorta), N._ptr(r), N._ptr(a),
+                                                  a.shape[0], C.byref(out)), "find_aortic_wall_scaling")
+    return out.value
+
+
+def find_distal_and_proximal_scaling(geometry: G.FlatGeometry, centerline: Centerline, results: dict,
+                                     dist_range: int = 3, prox_range: int = 2,
+                                     engine: Optional[N.Engine] = None) -> Tuple[float, float]:
+    """multimodars/ccta/scaling.py:84-145 with the frame list given as a FlatGeometry: the lumen
+    points of the last ``dist_range`` / first ``prox_range`` frames are the references and a quarter
+    of the anomalous points is compared on either side."""
+    F = geometry.n_frames
+    dist_pts = geometry.lumen[geometry.lumen_off[max(F - dist_range, 0)]:geometry.lumen_off[F]]
+    prox_pts = geometry.lumen[geometry.lumen_off[0]:geometry.lumen_off[min(prox_range, F)]]
+    n_section = int(math.ceil(0.25 * len(results["anomalous_points"])))
+    return find_proximal_distal_scaling(results["anomalous_points"], n_section, n_section, centerline, prox_pts,
+                                        dist_pts, engine=engine)

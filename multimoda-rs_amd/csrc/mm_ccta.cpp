@@ -1,0 +1,360 @@
+// mm_ccta.cpp -- CCTA diameter search (include/mm_ccta.h): 41 radial scalings x symmetric RMS
+// nearest-neighbour distance in 3-D.  Every nearest-neighbour minimum is computed on the device in
+// exact f64 (mm_nn_kernels.hip, one batch per search); morphing, sums and selection are host f64
+// in the reference's operation order (-ffp-contract=off).  Reference:
+// src/ccta/adjust_mesh/scale_coronary.rs (lines cited per function).
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "../../include/mm_ccta.h"
+#include "mm_engine.h"
+
+namespace mm {
+namespace {
+
+struct NnPairH { int32_t q_off, nq, p_off, np, out_off, pad; };
+struct NnWorkH { int32_t pair, q0; };
+struct Set3 { const double* xyz; int64_t n; };   // AoS triples
+
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+#define MM_TRY_HIP(call)                                          \
+    do {                                                          \
+        const hipError_t e__ = (call);                            \
+        if (e__ != hipSuccess) return hip_error(e__, #call);      \
+    } while (0)
+
+// out[k] <- per-query minima of pair k (sets[q] against sets[p]); one upload, one launch, one download
+int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::array<int32_t, 2>>& pr,
+             std::vector<std::vector<double>>& out)
+{
+    out.assign(pr.size(), {});
+    std::vector<int64_t> soff(sets.size() + 1, 0);
+    for (size_t s = 0; s < sets.size(); ++s) soff[s + 1] = soff[s] + sets[s].n;
+    const int64_t npts = soff.back();
+    std::vector<NnPairH> hp;
+    std::vector<NnWorkH> hw;
+    std::vector<int> owner;   // device pair -> caller's pair
+    int64_t nout = 0;
+    const int qpb = nn_queries_per_block();
+    for (size_t k = 0; k < pr.size(); ++k) {
+        const int32_t q = pr[k][0], p = pr[k][1];
+        if (q < 0 || p < 0 || (size_t)q >= sets.size() || (size_t)p >= sets.size())
+            return set_error(MM_ERR_INVALID, "nn batch: set index out of range");
+        const int64_t nq = sets[q].n, np = sets[p].n;
+        out[k].assign((size_t)nq, INFINITY);   // fold(INFINITY, min) over an empty set
+        if (nq == 0 || np == 0) continue;
+        const int32_t pi = (int32_t)hp.size();
+        hp.push_back(NnPairH{(int32_t)soff[q], (int32_t)nq, (int32_t)soff[p], (int32_t)np, (int32_t)nout, 0});
+        owner.push_back((int)k);
+        for (int64_t q0 = 0; q0 < nq; q0 += qpb) hw.push_back(NnWorkH{pi, (int32_t)q0});
+        nout += nq;
+    }
+    if (hp.empty()) return MM_OK;
+    if (npts > (int64_t)1 << 30 || nout > (int64_t)1 << 30 || hw.size() > (size_t)1 << 30)
+        return set_error(MM_ERR_TOO_LARGE, "nn batch exceeds 2^30 points");
+    const size_t o_x = 0, o_y = up256((size_t)npts * 8), o_z = up256(o_y + (size_t)npts * 8);
+    const size_t o_pairs = up256(o_z + (size_t)npts * 8), o_work = up256(o_pairs + hp.size() * sizeof(NnPairH));
+    const size_t in_bytes = up256(o_work + hw.size() * sizeof(NnWorkH));
+    const size_t o_out = in_bytes, total = up256(o_out + (size_t)nout * 8);
+    int rc = e->ensure(e->host_pts, std::max(in_bytes, (size_t)nout * 8), true);
+    if (rc) return rc;
+    if ((rc = e->ensure(e->dev_pts, total, false))) return rc;
+    unsigned char* h = (unsigned char*)e->host_pts.p;
+    double *hx = (double*)(h + o_x), *hy = (double*)(h + o_y), *hz = (double*)(h + o_z);
+    for (size_t s = 0; s < sets.size(); ++s) {
+        const double* src = sets[s].xyz;
+        double *dx = hx + soff[s], *dy = hy + soff[s], *dz = hz + soff[s];
+        for (int64_t i = 0; i < sets[s].n; ++i) { dx[i] = src[3 * i]; dy[i] = src[3 * i + 1]; dz[i] = src[3 * i + 2]; }
+    }
+    std::memcpy(h + o_pairs, hp.data(), hp.size() * sizeof(NnPairH));
+    std::memcpy(h + o_work, hw.data(), hw.size() * sizeof(NnWorkH));
+    unsigned char* d = (unsigned char*)e->dev_pts.p;
+    MM_TRY_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, e->stream));
+    const hipError_t he = launch_nn3_min(d + o_pairs, d + o_work, (int)hw.size(), (const double*)(d + o_x),
+                                         (const double*)(d + o_y), (const double*)(d + o_z), (double*)(d + o_out),
+                                         e->stream);
+    if (he != hipSuccess) return hip_error(he, "nearest-neighbour launch");
+    MM_TRY_HIP(hipMemcpyAsync(h, d + o_out, (size_t)nout * 8, hipMemcpyDeviceToHost, e->stream));
+    MM_TRY_HIP(hipStreamSynchronize(e->stream));
+    const double* res = (const double*)h;
+    for (size_t i = 0; i < hp.size(); ++i)
+        std::memcpy(out[(size_t)owner[i]].data(), res + hp[i].out_off, (size_t)hp[i].nq * 8);
+    return MM_OK;
+}
+
+// symmetric_nn_distance (:188-216) from the two vectors of minima
+double symmetric_from_minima(const std::vector<double>& a_to_b, const std::vector<double>& b_to_a)
+{
+    if (a_to_b.empty() || b_to_a.empty()) return INFINITY;                    // :189-191
+    double sa = 0.0;
+    for (double v : a_to_b) sa += v;                                          // :193-200
+    const double avg_a = sa / (double)a_to_b.size();                         // :202
+    double sb = 0.0;
+    for (double v : b_to_a) sb += v;                                          // :204-211
+    const double avg_b = sb / (double)b_to_a.size();                         // :213
+    return std::sqrt((avg_a + avg_b) / 2.0);                                  // :215
+}
+
+// unit vector from the closest centerline point to each point (:226-235); has[i] = 0 when the point sits
+// on its centerline point (try_normalize(0.0) fails -> the point does not move)
+void radial_units(const mm_clpoint* cl, int64_t ncl, const double* pts, int64_t n, std::vector<double>& unit,
+                  std::vector<uint8_t>& has)
+{
+    unit.assign((size_t)n * 3, 0.0);
+    has.assign((size_t)n, 0);
+    std::atomic<int64_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int64_t i0 = next.fetch_add(256);
+            if (i0 >= n) break;
+            for (int64_t i = i0; i < std::min(n, i0 + 256); ++i) {
+                const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+                double best = DBL_MAX;                                        // :249-258
+                int64_t kb = 0;
+                for (int64_t k = 0; k < ncl; ++k) {
+                    const double dx = x - cl[k].x, dy = y - cl[k].y, dz = z - cl[k].z;
+                    const double d = dx * dx + dy * dy + dz * dz;
+                    if (d < best) { best = d; kb = k; }
+                }
+                const double vx = x - cl[kb].x, vy = y - cl[kb].y, vz = z - cl[kb].z;
+                const double nn = std::sqrt(vx * vx + vy * vy + vz * vz);
+                if (nn > 0.0) { unit[3 * i] = vx / nn; unit[3 * i + 1] = vy / nn; unit[3 * i + 2] = vz / nn; has[i] = 1; }
+            }
+        }
+    };
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(hw, (n * ncl) / 200000 + 1));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker);
+    worker();
+    for (std::thread& t : th) t.join();
+}
+
+inline void morph(const double* pts, const std::vector<double>& unit, const std::vector<uint8_t>& has, int64_t n,
+                  double adj, double* out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        if (has[i]) {
+            out[3 * i] = pts[3 * i] + unit[3 * i] * adj;                      // :236 p + unit * x
+            out[3 * i + 1] = pts[3 * i + 1] + unit[3 * i + 1] * adj;
+            out[3 * i + 2] = pts[3 * i + 2] + unit[3 * i + 2] * adj;
+        } else { out[3 * i] = pts[3 * i]; out[3 * i + 1] = pts[3 * i + 1]; out[3 * i + 2] = pts[3 * i + 2]; }  // :239
+    }
+}
+
+// the 41-step loop of :75-87 / :107-129: all scalings scored in one device batch
+int scaling_search(Engine* e, const double* pts, int64_t n, const double* ref, int64_t nr, const mm_clpoint* cl,
+                   int64_t ncl, double& best, double* all_dist)
+{
+    const double start = -2.0, end = 2.0, step = 0.1;
+    const int steps = (int)std::round((end - start) / step);                  // :70-73
+    best = DBL_MAX;
+    double min_dist = DBL_MAX;
+    std::vector<double> dist((size_t)steps + 1, INFINITY);
+    if (n > 0 && nr > 0) {
+        if (ncl <= 0) return set_error(MM_ERR_INVALID, "diameter search: empty centerline");
+        std::vector<double> unit; std::vector<uint8_t> has;
+        radial_units(cl, ncl, pts, n, unit, has);
+        std::vector<double> moved((size_t)(steps + 1) * (size_t)n * 3);
+        std::vector<Set3> sets;
+        std::vector<std::array<int32_t, 2>> pr;
+        sets.push_back(Set3{ref, nr});
+        for (int i = 0; i <= steps; ++i) {
+            const double x = start + (double)i * step;                        // :79
+            double* m = moved.data() + (size_t)i * (size_t)n * 3;
+            morph(pts, unit, has, n, x, m);                                   // :80
+            sets.push_back(Set3{m, n});
+            pr.push_back({0, i + 1});                                         // reference -> moved
+            pr.push_back({i + 1, 0});                                         // moved -> reference
+        }
+        std::vector<std::vector<double>> mins;
+        int rc = nn_batch(e, sets, pr, mins);
+        if (rc) return rc;
+        for (int i = 0; i <= steps; ++i) dist[(size_t)i] = symmetric_from_minima(mins[2 * (size_t)i], mins[2 * (size_t)i + 1]);  // :81
+    }
+    for (int i = 0; i <= steps; ++i) {
+        if (all_dist) all_dist[i] = dist[(size_t)i];
+        if (dist[(size_t)i] < min_dist) { min_dist = dist[(size_t)i]; best = start + (double)i * step; }  // :82-85
+    }
+    return MM_OK;
+}
+
+// find_region_points (:133-183)
+int region_points(Engine* e, const double* an, int64_t n, const double* ref, int64_t nr, int64_t n_points,
+                  std::vector<double>& selected, std::vector<double>& remaining)
+{
+    selected.clear();
+    if (n == 0 || nr == 0 || n_points == 0) { remaining.assign(an, an + 3 * n); return MM_OK; }  // :138-140
+    std::vector<std::vector<double>> mins;
+    int rc = nn_batch(e, {Set3{an, n}, Set3{ref, nr}}, {{0, 1}}, mins);      // :142-152
+    if (rc) return rc;
+    const std::vector<double>& d = mins[0];
+    std::vector<int64_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::sort(order.begin(), order.end(), [&d](int64_t a, int64_t b) {       // :154-158
+        if (d[(size_t)a] < d[(size_t)b]) return true;
+        if (d[(size_t)a] > d[(size_t)b]) return false;
+        return a < b;
+    });
+    const int64_t take = std::min(n_points, n);                               // :160
+    std::vector<uint8_t> sel((size_t)n, 0);
+    selected.reserve((size_t)take * 3);
+    for (int64_t k = 0; k < take; ++k) {
+        const int64_t i = order[(size_t)k];
+        sel[(size_t)i] = 1;
+        selected.insert(selected.end(), an + 3 * i, an + 3 * i + 3);          // :165-168
+    }
+    remaining.clear();
+    remaining.reserve((size_t)(n - take) * 3);
+    for (int64_t i = 0; i < n; ++i) if (!sel[(size_t)i]) remaining.insert(remaining.end(), an + 3 * i, an + 3 * i + 3);  // :170-180
+    return MM_OK;
+}
+
+int engine_of(mm_engine* h, Engine*& e)
+{
+    e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    const hipError_t he = hipSetDevice(e->device);
+    if (he != hipSuccess) return hip_error(he, "hipSetDevice");
+    return MM_OK;
+}
+
+}  // namespace
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" {
+
+int mm_nn_min_sq_batch(mm_engine* h, int n_sets, const int64_t* set_off, const double* xyz, int n_pairs,
+                       const int32_t* q_set, const int32_t* p_set, const int64_t* out_off, double* out)
+{
+    Engine* e;
+    int rc = engine_of(h, e);
+    if (rc) return rc;
+    if (n_sets < 0 || n_pairs < 0 || (n_sets > 0 && !set_off) || (n_pairs > 0 && (!q_set || !p_set || !out_off || !out)))
+        return set_error(MM_ERR_INVALID, "mm_nn_min_sq_batch: bad arguments");
+    std::vector<Set3> sets((size_t)n_sets);
+    for (int s = 0; s < n_sets; ++s) {
+        const int64_t n = set_off[s + 1] - set_off[s];
+        if (n < 0 || n > INT32_MAX || (n > 0 && !xyz)) return set_error(MM_ERR_INVALID, "bad set extent");
+        sets[(size_t)s] = Set3{xyz ? xyz + 3 * set_off[s] : nullptr, n};
+    }
+    std::vector<std::array<int32_t, 2>> pr((size_t)n_pairs);
+    for (int k = 0; k < n_pairs; ++k) {
+        pr[(size_t)k] = {q_set[k], p_set[k]};
+        if (q_set[k] < 0 || q_set[k] >= n_sets || p_set[k] < 0 || p_set[k] >= n_sets)
+            return set_error(MM_ERR_INVALID, "mm_nn_min_sq_batch: set index out of range");
+        if (out_off[k + 1] - out_off[k] != sets[(size_t)q_set[k]].n)
+            return set_error(MM_ERR_INVALID, "mm_nn_min_sq_batch: out_off does not match the query set sizes");
+    }
+    std::vector<std::vector<double>> mins;
+    if ((rc = nn_batch(e, sets, pr, mins))) return rc;
+    for (int k = 0; k < n_pairs; ++k)
+        if (!mins[(size_t)k].empty()) std::memcpy(out + out_off[k], mins[(size_t)k].data(), mins[(size_t)k].size() * 8);
+    return MM_OK;
+}
+
+int mm_symmetric_nn_distance(mm_engine* h, const double* a, int64_t na, const double* b, int64_t nb, double* out)
+{
+    Engine* e;
+    int rc = engine_of(h, e);
+    if (rc) return rc;
+    if (!out || na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b)) return set_error(MM_ERR_INVALID, "mm_symmetric_nn_distance: bad arguments");
+    if (na == 0 || nb == 0) { *out = INFINITY; return MM_OK; }
+    std::vector<std::vector<double>> mins;
+    if ((rc = nn_batch(e, {Set3{a, na}, Set3{b, nb}}, {{0, 1}, {1, 0}}, mins))) return rc;
+    *out = symmetric_from_minima(mins[0], mins[1]);
+    return MM_OK;
+}
+
+int mm_diameter_morphing(const mm_clpoint* cl, int64_t ncl, const double* pts, int64_t n, double adj, double* out)
+{
+    if (n < 0 || (n > 0 && (!pts || !out))) return set_error(MM_ERR_INVALID, "mm_diameter_morphing: bad arguments");
+    if (n > 0 && (ncl <= 0 || !cl)) return set_error(MM_ERR_INVALID, "mm_diameter_morphing: empty centerline");  // points[0] panics
+    std::vector<double> unit; std::vector<uint8_t> has;
+    radial_units(cl, ncl, pts, n, unit, has);
+    morph(pts, unit, has, n, adj, out);
+    return MM_OK;
+}
+
+int64_t mm_find_region_points(mm_engine* h, const double* an, int64_t n, const double* ref, int64_t nr,
+                              int64_t n_points, double* selected, double* remaining)
+{
+    Engine* e;
+    int rc = engine_of(h, e);
+    if (rc) return rc;
+    if (n < 0 || nr < 0 || n_points < 0 || (n > 0 && (!an || !selected || !remaining)) || (nr > 0 && !ref))
+        return set_error(MM_ERR_INVALID, "mm_find_region_points: bad arguments");
+    std::vector<double> sel, rem;
+    if ((rc = region_points(e, an, n, ref, nr, n_points, sel, rem))) return rc;
+    if (!sel.empty()) std::memcpy(selected, sel.data(), sel.size() * 8);
+    if (!rem.empty()) std::memcpy(remaining, rem.data(), rem.size() * 8);
+    return (int64_t)(sel.size() / 3);
+}
+
+int mm_aortic_diameter_optimization(mm_engine* h, const double* intramural, int64_t ni, const double* reference,
+                                    int64_t nr, const mm_clpoint* cl, int64_t ncl, double* best, double* all_dist)
+{
+    Engine* e;
+    int rc = engine_of(h, e);
+    if (rc) return rc;
+    if (!best || ni < 0 || nr < 0 || (ni > 0 && !intramural) || (nr > 0 && !reference))
+        return set_error(MM_ERR_INVALID, "mm_aortic_diameter_optimization: bad arguments");
+    return scaling_search(e, intramural, ni, reference, nr, cl, ncl, *best, all_dist);
+}
+
+int mm_diameter_optimization(mm_engine* h, const double* an, int64_t n, int64_t n_prox, int64_t n_dist,
+                             const mm_clpoint* cl, int64_t ncl, const double* pref, int64_t npr, const double* dref,
+                             int64_t ndr, double* prox_best, double* dist_best)
+{
+    Engine* e;
+    int rc = engine_of(h, e);
+    if (rc) return rc;
+    if (!prox_best || !dist_best || n < 0 || npr < 0 || ndr < 0 || n_prox < 0 || n_dist < 0 || (n > 0 && !an) ||
+        (npr > 0 && !pref) || (ndr > 0 && !dref))
+        return set_error(MM_ERR_INVALID, "mm_diameter_optimization: bad arguments");
+    std::vector<double> prox, rest, dist, rest2;
+    if ((rc = region_points(e, an, n, pref, npr, n_prox, prox, rest))) return rc;                    // :98-99
+    if ((rc = region_points(e, rest.data(), (int64_t)(rest.size() / 3), dref, ndr, n_dist, dist, rest2))) return rc;  // :100
+    if ((rc = scaling_search(e, prox.data(), (int64_t)(prox.size() / 3), pref, npr, cl, ncl, *prox_best, nullptr))) return rc;  // :112-120
+    return scaling_search(e, dist.data(), (int64_t)(dist.size() / 3), dref, ndr, cl, ncl, *dist_best, nullptr);                // :121-129
+}
+
+int mm_wall_diameter_optimization(const mm_clpoint* cl, int64_t ncl, const double ref[3], const double* aortic,
+                                  int64_t na, double* out)
+{
+    if (!out || !ref || ncl < 0 || na < 0 || (ncl > 0 && !cl) || (na > 0 && !aortic))
+        return set_error(MM_ERR_INVALID, "mm_wall_diameter_optimization: bad arguments");
+    *out = 0.0;
+    if (ncl == 0 || na == 0) return MM_OK;                                                           // :13-15
+    int64_t kc = 0, ka = 0;
+    double bc = INFINITY, ba = INFINITY;                                                             // min_by: first minimum (:17-37)
+    for (int64_t k = 0; k < ncl; ++k) {
+        const double dx = cl[k].x - ref[0], dy = cl[k].y - ref[1], dz = cl[k].z - ref[2];
+        const double d = dx * dx + dy * dy + dz * dz;
+        if (d < bc) { bc = d; kc = k; }
+    }
+    for (int64_t k = 0; k < na; ++k) {
+        const double dx = aortic[3 * k] - ref[0], dy = aortic[3 * k + 1] - ref[1], dz = aortic[3 * k + 2] - ref[2];
+        const double d = dx * dx + dy * dy + dz * dz;
+        if (d < ba) { ba = d; ka = k; }
+    }
+    const double vx = ref[0] - cl[kc].x, vy = ref[1] - cl[kc].y, vz = ref[2] - cl[kc].z;             // :52
+    const double nn = std::sqrt(vx * vx + vy * vy + vz * vz);
+    if (!(nn > 0.0)) return MM_OK;                                                                   // :53-55
+    const double ux = vx / nn, uy = vy / nn, uz = vz / nn;
+    const double tx = ref[0] - aortic[3 * ka], ty = ref[1] - aortic[3 * ka + 1], tz = ref[2] - aortic[3 * ka + 2];  // :59
+    const double t = tx * ux + ty * uy + tz * uz;                                                    // :60
+    *out = t > 0.0 ? t : 0.0;                                                                        // :62
+    return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// mm_nn_kernels.hip -- nearest-neighbour squared distances in 3-D, exact f64, for gfx950.
+//
+// For every query point q of a (query set, point set) pair:  out[q] = min_p |q - p|^2  with
+// |q - p|^2 = dx*dx + dy*dy + dz*dz in exactly that order and no contraction (the file is built
+// with -ffp-contract=off), i.e. the inner fold of the reference's symmetric_nn_distance and
+// find_region_points (src/ccta/adjust_mesh/scale_coronary.rs:142-152, 193-199, 204-210;
+// calculate_squared_distance: src/ccta/adjust_mesh.rs:7-12).  min is exact, so the result does not
+// depend on the traversal order.
+//
+// Mapping: one workgroup = 256 lanes x QPT queries of one pair; the point set streams through LDS
+// in chunks of CH points stored as (x, y, z, 0) so that a point is two ds_read_b128 broadcasts
+// (all lanes read the same address: conflict-free).  Per (query, point): 3 sub + 3 mul + 2 add +
+// 1 min = 9 fp64 VALU operations against 2/QPT LDS reads -> fp64-VALU bound.  Sets are SoA f64 in
+// HBM; each point is read from HBM once per workgroup of its pair (L2-resident: a set is a few
+// hundred KB), each query once.
+#include <hip/hip_runtime.h>
+
+#include "mm_device.h"
+
+namespace mm {
+
+struct NnPair { int32_t q_off, nq, p_off, np, out_off, pad; };   // offsets into the point pool / output
+struct NnWork { int32_t pair, q0; };                              // queries [q0, q0 + 256*QPT) of the pair
+
+template <int QPT>
+__global__ void __launch_bounds__(256)
+k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int n_work,
+          const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
+          double* __restrict__ out)
+{
+    constexpr int NT = 256, CH = 1024;
+    __shared__ double4 s_p[CH];
+    const int tid = threadIdx.x;
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const NnWork w = work[wi];
+        const NnPair pd = pairs[w.pair];
+        double qx[QPT], qy[QPT], qz[QPT], m[QPT];
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const int q = w.q0 + k * NT + tid;
+            const int qc = q < pd.nq ? q : pd.nq - 1;   // lanes past the end recompute the last query, never stored
+            qx[k] = px[pd.q_off + qc]; qy[k] = py[pd.q_off + qc]; qz[k] = pz[pd.q_off + qc];
+            m[k] = __builtin_inf();
+        }
+        for (int c0 = 0; c0 < pd.np; c0 += CH) {
+            const int n = pd.np - c0 < CH ? pd.np - c0 : CH;
+            __syncthreads();   // previous chunk fully consumed
+            for (int j = tid; j < n; j += NT)
+                s_p[j] = make_double4(px[pd.p_off + c0 + j], py[pd.p_off + c0 + j], pz[pd.p_off + c0 + j], 0.0);
+            __syncthreads();
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) {
+                const double4 p = s_p[j];
+#pragma unroll
+                for (int k = 0; k < QPT; ++k) {
+                    const double dx = qx[k] - p.x, dy = qy[k] - p.y, dz = qz[k] - p.z;
+                    const double v = dx * dx + dy * dy + dz * dz;
+                    m[k] = __builtin_fmin(m[k], v);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const int q = w.q0 + k * NT + tid;
+            if (q < pd.nq) out[pd.out_off + q] = m[k];
+        }
+    }
+}
+
+int nn_queries_per_block() { return 256 * 2; }
+
+hipError_t launch_nn3_min(const void* pairs, const void* work, int n_work, const double* px, const double* py,
+                          const double* pz, double* out, hipStream_t s)
+{
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_nn3_min<2>, dim3((unsigned)n_work), dim3(256), 0, s, (const NnPair*)pairs,
+                       (const NnWork*)work, n_work, px, py, pz, out);
+    return hipGetLastError();
+}
+
+}  // namespace mm

@@ -114,3 +114,30 @@ def synthetic_centerline_case(n_frames: int = 24, n_points: int = 200, n_ccta: i
     return dict(centerline=cl, geometry=g, main_ref_pt=f0[ref_index] + rng.normal(0.0, noise, 3),
                 ccw_ref_pt=f0[0] + rng.normal(0.0, noise, 3), cw_ref_pt=f0[n_points // 2] + rng.normal(0.0, noise, 3),
                 points=points, truth=dict(rotation_deg=true_rotation_deg, cl_index=true_index, placed=placed))
+
+
+def synthetic_tube_case(n_points: int = 6000, n_reference: int = 5000, true_scaling_mm: float = 0.7,
+                        seed: int = 3, noise: float = 0.02):
+    """A diameter-search problem with a known answer (generator is ours): a vessel segment sampled
+    as a noisy tube of radius 1.6 mm around a curved centerline, and a reference cloud sampled from
+    the same tube at radius 1.6 + ``true_scaling_mm``.  Returns dict(centerline, points, reference)."""
+    from . import centerline as CL
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    s = np.arange(0.0, 40.0, 0.5)
+    path = np.stack([10.0 + 5.0 * np.sin(s / 15.0), -190.0 + 4.0 * np.cos(s / 19.0), 1700.0 - 0.95 * s], axis=1)
+    cl = CL.Centerline.from_contour_points(path)
+    t = cl.points
+
+    def tube(n, r):
+        k = rng.integers(2, len(s) - 2, size=n)
+        tan = np.stack([t["tx"][k], t["ty"][k], t["tz"][k]], axis=1)
+        a = np.cross(tan, np.array([1.0, 0.0, 0.0]))
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b = np.cross(tan, a)
+        phi = rng.uniform(0.0, 2.0 * math.pi, size=n)
+        rad = r + rng.normal(0.0, noise, size=n)
+        return path[k] + a * (rad * np.cos(phi))[:, None] + b * (rad * np.sin(phi))[:, None]
+
+    return dict(centerline=cl, points=tube(n_points, 1.6), reference=tube(n_reference, 1.6 + true_scaling_mm),
+                truth=true_scaling_mm)

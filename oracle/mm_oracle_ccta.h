@@ -1,0 +1,52 @@
+/*
+ * mm_oracle_ccta.h -- CPU oracle for the CCTA diameter search (TEST INFRASTRUCTURE ONLY; same rules
+ * as mm_oracle.h): 41 radial scalings x symmetric RMS nearest-neighbour distance in 3-D.
+ *
+ * Plain-C f64 restatement of src/ccta/adjust_mesh/scale_coronary.rs:8-261 and
+ * src/ccta/adjust_mesh.rs:7-12 (calculate_squared_distance = dx*dx + dy*dy + dz*dz).
+ *
+ * Parity status: centerline_based_diameter_morphing is PINNED by the reference's two tests
+ * (scale_coronary.rs:413-489, tests/test_oracle_ccta_kat.py).  symmetric_nn_distance and the
+ * 41-step searches are UNPINNED by reference fixtures: the only test of the search is commented out
+ * in the reference (:491-567); its expectation (a cloud identical to its reference is best matched at
+ * scaling 0) is checked all the same.  The reference sums the per-point minima with rayon's
+ * `par_iter().sum()`, whose association order depends on the scheduler, so its last bits are not
+ * reproducible run to run; this restatement (and the product) use the sequential order, which is
+ * one of the orders rayon can produce (one worker thread).
+ */
+#ifndef MM_ORACLE_CCTA_H
+#define MM_ORACLE_CCTA_H
+
+#include "mm_oracle_cl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* min over b of |a_i - b|^2 for every a_i (the inner fold of :193-199 and :146-149) */
+void   orc_nn_min_sq(const orc_point* a, size_t na, const orc_point* b, size_t nb, double* out);
+/* symmetric_nn_distance (:188-216); INFINITY if either set is empty */
+double orc_symmetric_nn_distance(const orc_point* a, size_t na, const orc_point* b, size_t nb);
+/* centerline_based_diameter_morphing (:218-261) */
+void   orc_diameter_morphing(const orc_clpoint* cl, size_t ncl, const orc_point* pts, size_t n,
+                             double diameter_adjustment_mm, orc_point* out);
+/* find_region_points (:133-183): n_points nearest anomalous points (by min squared distance to the
+ * reference set; ties by index) in sorted order, and the remaining ones in input order.
+ * Returns the number selected; remaining count = n - selected. */
+size_t orc_find_region_points(const orc_point* anomalous, size_t n, const orc_point* reference, size_t nr,
+                              size_t n_points, orc_point* selected, orc_point* remaining);
+/* centerline_based_aortic_diameter_optimization (:65-88); all_dist (nullable) gets the 41 distances */
+double orc_aortic_diameter_optimization(const orc_point* intramural, size_t ni, const orc_point* reference,
+                                        size_t nr, const orc_clpoint* cl, size_t ncl, double* all_dist);
+/* centerline_based_diameter_optimization (:90-131) */
+void   orc_diameter_optimization(const orc_point* anomalous, size_t n, size_t n_proximal, size_t n_distal,
+                                 const orc_clpoint* cl, size_t ncl, const orc_point* prox_ref, size_t npr,
+                                 const orc_point* dist_ref, size_t ndr, double* prox_best, double* dist_best);
+/* centerline_based_wall_diameter_optimization (:8-63) */
+double orc_wall_diameter_optimization(const orc_clpoint* cl, size_t ncl, const double ref_pt[3],
+                                      const orc_point* aortic, size_t na);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -23,7 +23,7 @@ _LIB_PATH = os.path.join(_HERE, "libmm_oracle.so")
 def build(force: bool = False) -> str:
     """Compile ``libmm_oracle.so`` with gcc (building the checker is not using it)."""
     deps = [os.path.join(_HERE, f) for f in ("mm_oracle.c", "mm_oracle.h", "mm_oracle_cl.c", "mm_oracle_cl.h",
-                                             "Makefile")]
+                                             "mm_oracle_ccta.c", "mm_oracle_ccta.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in deps
     )

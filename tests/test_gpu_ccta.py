@@ -1,0 +1,109 @@
+"""GPU parity tests of the CCTA diameter search (include/mm_ccta.h) against the oracle: per-point
+nearest-neighbour minima, symmetric distances, region selection and the 41-step searches are
+bit-exact (exact f64 minima on the device, sums in index order on the host)."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import to_oracle_cl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def occ(oracle):
+    from oracle import oracle_ccta
+    oracle_ccta.lib()
+    return oracle_ccta
+
+
+@pytest.fixture(scope="module")
+def ocl(oracle):
+    from oracle import oracle_cl
+    oracle_cl.lib()
+    return oracle_cl
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (3, 1), (1, 700), (511, 513), (512, 1024), (513, 1025), (2500, 3333),
+                                   (20000, 77)])
+def test_nn_min_sq_matches_oracle(engine, mm, occ, na, nb):
+    rng = np.random.default_rng(na * 7919 + nb)
+    a = rng.normal(0, 4, size=(na, 3)) + [10.0, -190.0, 1700.0]
+    b = rng.normal(0, 4, size=(nb, 3)) + [10.0, -190.0, 1700.0]
+    if na > 2 and nb > 2:
+        b[1] = a[2]                               # a coincident pair: minimum exactly 0
+    got = mm.ccta.nn_min_sq(a, b, engine=engine)
+    assert np.array_equal(got, occ.nn_min_sq(a, b))
+    assert mm.ccta.symmetric_nn_distance(a, b, engine=engine) == occ.symmetric_nn_distance(a, b)
+
+
+def test_nn_batch_and_empty_sets(engine, mm, occ):
+    rng = np.random.default_rng(5)
+    sets = [rng.normal(0, 3, size=(n, 3)) for n in (40, 0, 700, 1300)]
+    xyz = np.ascontiguousarray(np.concatenate(sets))
+    off = np.zeros(len(sets) + 1, dtype=np.int64); off[1:] = np.cumsum([len(s) for s in sets])
+    pairs = [(0, 2), (2, 0), (3, 2), (0, 1), (1, 0), (3, 3)]
+    q = np.array([p[0] for p in pairs], dtype=np.int32); p_ = np.array([p[1] for p in pairs], dtype=np.int32)
+    out_off = np.zeros(len(pairs) + 1, dtype=np.int64); out_off[1:] = np.cumsum([len(sets[a]) for a, _ in pairs])
+    out = np.full(int(out_off[-1]), np.nan)
+    N = mm._native
+    N.check(N.lib().mm_nn_min_sq_batch(engine.handle, len(sets), N._ptr(off), N._ptr(xyz), len(pairs), N._ptr(q),
+                                       N._ptr(p_), N._ptr(out_off), N._ptr(out)))
+    for k, (a, b) in enumerate(pairs):
+        seg = out[out_off[k]:out_off[k + 1]]
+        if len(sets[b]) == 0:
+            assert np.isinf(seg).all()            # fold over an empty set
+        else:
+            assert np.array_equal(seg, occ.nn_min_sq(sets[a], sets[b]))
+    assert mm.ccta.symmetric_nn_distance(sets[0], sets[1], engine=engine) == math.inf
+    assert (out[out_off[5]:out_off[6]] == 0.0).all()          # a set against itself
+
+
+def test_find_region_points_matches_oracle(engine, mm, occ):
+    case = mm.synth.synthetic_tube_case(n_points=3000, n_reference=900, seed=9)
+    pts = case["points"].copy()
+    pts[17] = pts[5]                                           # exact distance tie: the lower index goes first
+    for n_sel in (0, 1, 750, 2999, 3000, 5000):
+        s, r = mm.ccta.find_region_points(pts, case["reference"], n_sel, engine=engine)
+        os_, or_ = occ.find_region_points(pts, case["reference"], n_sel)
+        assert np.array_equal(s, os_) and np.array_equal(r, or_)
+
+
+def test_aortic_scaling_matches_oracle_and_truth(engine, mm, occ, ocl):
+    case = mm.synth.synthetic_tube_case(n_points=4000, n_reference=3500, true_scaling_mm=0.7, seed=4)
+    best, d = mm.find_aortic_scaling(case["points"], case["reference"], case["centerline"], engine=engine,
+                                     return_distances=True)
+    obest, od = occ.aortic_diameter_optimization(case["points"], case["reference"], to_oracle_cl(ocl, case["centerline"]))
+    assert best == obest and np.array_equal(d, od)
+    assert best == pytest.approx(0.7, abs=1e-12)               # -2.0 + 27 * 0.1
+    # empty inputs: f64::MAX comes back, all distances +inf (:75-76, :189-191)
+    b2, d2 = mm.find_aortic_scaling(np.zeros((0, 3)), case["reference"], case["centerline"], engine=engine,
+                                    return_distances=True)
+    assert b2 == np.finfo(np.float64).max and np.isinf(d2).all()
+
+
+def test_proximal_distal_scaling_matches_oracle(engine, mm, occ, ocl):
+    case = mm.synth.synthetic_tube_case(n_points=6000, n_reference=10, seed=12)
+    pts = case["points"]
+    z = pts[:, 2]
+    order = np.argsort(-z)
+    prox_ref = pts[order[:800]] * 1.0
+    dist_ref = pts[order[-800:]] * 1.0
+    # references: the two ends of the tube pushed outwards by 0.4 / inwards by 0.3 mm
+    prox_ref = mm.adjust_diameter_centerline_morphing_simple(case["centerline"], prox_ref, 0.4)
+    dist_ref = mm.adjust_diameter_centerline_morphing_simple(case["centerline"], dist_ref, -0.3)
+    n_sec = int(math.ceil(0.25 * len(pts)))
+    got = mm.find_proximal_distal_scaling(pts, n_sec, n_sec, case["centerline"], prox_ref, dist_ref, engine=engine)
+    exp = occ.diameter_optimization(pts, n_sec, n_sec, to_oracle_cl(ocl, case["centerline"]), prox_ref, dist_ref)
+    assert got == exp
+    assert got[0] > 0.0 > got[1]
+    # the wrapper of multimodars/ccta/scaling.py:84-145 on a geometry
+    g = mm.synthetic_pullback(8, 100)
+    res = {"anomalous_points": g.lumen + [0.05, 0.0, 0.0]}
+    cl = mm.Centerline.from_contour_points(np.stack([np.full(12, 4.5), np.full(12, 4.5), np.arange(12) * 0.5 - 1.0], axis=1))
+    w = mm.find_distal_and_proximal_scaling(g, cl, res, engine=engine)
+    n4 = int(math.ceil(0.25 * g.lumen.shape[0]))
+    e = occ.diameter_optimization(res["anomalous_points"], n4, n4, to_oracle_cl(ocl, cl),
+                                  g.lumen[:g.lumen_off[2]], g.lumen[g.lumen_off[5]:])
+    assert w == e

@@ -1,0 +1,97 @@
+"""Pin the CCTA diameter-search oracle (oracle/mm_oracle_ccta.c).  The reference holds two tests for
+this path (morphing, scale_coronary.rs:413-489); the search's own test is commented out in the
+reference (:491-567) -- its expectation is checked anyway and the rest is "parity unpinned"
+(see mm_oracle_ccta.h).  CPU tests: they check the checker."""
+import math
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def occ(oracle):
+    from oracle import oracle_ccta
+    oracle_ccta.lib()
+    return oracle_ccta
+
+
+@pytest.fixture(scope="module")
+def ocl(oracle):
+    from oracle import oracle_cl
+    oracle_cl.lib()
+    return oracle_cl
+
+
+def test_centerline_based_diameter_morphing(occ, ocl):          # scale_coronary.rs:413-459
+    cl = ocl.make_centerline([[0, 0, 0], [1, 0, 0]], [[1, 0, 0], [1, 0, 0]])
+    out = occ.diameter_morphing(cl, [[1.0, 1.0, 0.0]], 1.0)
+    assert np.allclose(out, [[1.0, 2.0, 0.0]], atol=1e-6)
+
+
+def test_negative_adjustment(occ, ocl):                         # scale_coronary.rs:461-489
+    cl = ocl.make_centerline([[0, 0, 0]], [[1, 0, 0]])
+    out = occ.diameter_morphing(cl, [[2.0, 0.0, 0.0]], -0.5)
+    assert np.allclose(out, [[1.5, 0.0, 0.0]], atol=1e-6)
+
+
+def test_point_on_the_centerline_does_not_move(occ, ocl):       # :234-240 try_normalize(0.0) -> None
+    cl = ocl.make_centerline([[0, 0, 0], [1, 0, 0]], [[1, 0, 0], [1, 0, 0]])
+    out = occ.diameter_morphing(cl, [[1.0, 0.0, 0.0], [0.4, 0.0, 0.3]], 0.8)
+    assert out[0].tolist() == [1.0, 0.0, 0.0]
+    assert np.allclose(out[1], [0.4 + 0.8 * 0.8, 0.0, 0.3 + 0.8 * 0.6])      # closest is (0,0,0): |(0.4,0,0.3)| = 0.5
+
+
+def test_symmetric_nn_distance(occ):                            # :188-216
+    a = np.array([[0.0, 0, 0], [1.0, 0, 0]])
+    assert occ.symmetric_nn_distance(a, a) == 0.0
+    b = a + [0.0, 3.0, 4.0]                                     # every nearest neighbour is 5 away
+    assert occ.symmetric_nn_distance(a, b) == 5.0
+    assert occ.symmetric_nn_distance(a, np.zeros((0, 3))) == math.inf     # :189-191
+    assert occ.symmetric_nn_distance(np.zeros((0, 3)), a) == math.inf
+    c = np.array([[0.0, 0, 0], [1.0, 0, 0], [10.0, 0, 0]])     # asymmetric sets: means 0 and (0+0+81)/3
+    assert occ.symmetric_nn_distance(a, c) == math.sqrt((0.0 + 27.0) / 2.0)
+
+
+def test_find_region_points(occ):                               # :133-183
+    an = np.array([[5.0, 0, 0], [1.0, 0, 0], [3.0, 0, 0], [1.0, 0, 0], [9.0, 0, 0]])
+    ref = np.array([[0.0, 0, 0]])
+    sel, rem = occ.find_region_points(an, ref, 3)
+    assert sel[:, 0].tolist() == [1.0, 1.0, 3.0]                # by distance, ties by index
+    assert rem[:, 0].tolist() == [5.0, 9.0]                     # input order
+    sel, rem = occ.find_region_points(an, ref, 0)               # :138-140
+    assert len(sel) == 0 and np.array_equal(rem, an)
+    sel, rem = occ.find_region_points(an, ref, 99)              # :160 take = min(n_points, len)
+    assert len(sel) == 5 and len(rem) == 0
+
+
+def test_diameter_optimization_basic(occ, ocl):                 # the reference's commented-out test, :491-567
+    prox = np.array([[1.0, 0, 0], [1.0, 1, 0], [1.0, -1, 0]])
+    dist = np.array([[2.0, 0, 0], [2.0, 1, 0], [2.0, -1, 0]])
+    ref = np.concatenate([prox, dist])
+    cl = ocl.make_centerline([[0, 0, 0], [0, 0, 1]], [[1, 0, 0], [1, 0, 0]])
+    best, d = occ.aortic_diameter_optimization(ref, ref, cl)
+    assert best == pytest.approx(0.0, abs=1e-12) and d.min() == d[20] < 1e-6    # identical clouds: scaling ~ 0
+    pb, db = occ.diameter_optimization(ref, 3, 3, cl, prox, dist)
+    assert pb == pytest.approx(0.0, abs=1e-12) and db == pytest.approx(0.0, abs=1e-12)
+    # empty inputs: every distance is +inf, the initial f64::MAX comes back (:75-76)
+    best, d = occ.aortic_diameter_optimization(np.zeros((0, 3)), ref, cl)
+    assert best == np.finfo(np.float64).max and np.isinf(d).all()
+
+
+def test_scaling_grid_values(occ, ocl):                         # :70-79 x = -2.0 + i * 0.1, 41 candidates
+    # a ring of radius 1 around a z-axis centerline against a ring of radius 1.7: best x = -2 + 27*0.1
+    phi = np.linspace(0, 2 * math.pi, 64, endpoint=False)
+    ring = lambda r: np.stack([r * np.cos(phi), r * np.sin(phi), np.zeros_like(phi)], axis=1)
+    cl = ocl.make_centerline([[0, 0, 0], [0, 0, 1]], [[0, 0, 1], [0, 0, 1]])
+    best, d = occ.aortic_diameter_optimization(ring(1.0), ring(1.7), cl)
+    assert best == -2.0 + 27 * 0.1 and len(d) == 41 and int(np.argmin(d)) == 27
+
+
+def test_wall_diameter_optimization(occ, ocl):                  # :8-63
+    cl = ocl.make_centerline([[0, 0, 0], [0, 0, 1]], [[0, 0, 1], [0, 0, 1]])
+    # ref point 3 mm out along +x; closest aortic point 1 mm closer to the axis along the same ray -> t = 1
+    assert occ.wall_diameter_optimization(cl, (3.0, 0.0, 0.0), [[2.0, 0, 0], [9.0, 9, 9]]) == 1.0
+    # aortic point beyond the reference point: negative projection is clamped (:62)
+    assert occ.wall_diameter_optimization(cl, (3.0, 0.0, 0.0), [[4.0, 0, 0]]) == 0.0
+    assert occ.wall_diameter_optimization(cl, (0.0, 0.0, 0.0), [[4.0, 0, 0]]) == 0.0      # zero vector (:53-55)
+    assert occ.wall_diameter_optimization(cl, (3.0, 0.0, 0.0), np.zeros((0, 3))) == 0.0   # :13-15
