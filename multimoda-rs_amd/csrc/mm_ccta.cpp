@@ -19,7 +19,7 @@ namespace mm {
 namespace {
 
 struct NnPairH { int32_t q_off, nq, p_off, np, out_off, pad; };
-struct NnWorkH { int32_t pair, q0; };
+struct NnWorkH { int32_t pair, q0, c0, pad; };
 struct Set3 { const double* xyz; int64_t n; };   // AoS triples
 
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
@@ -42,7 +42,7 @@ int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::ar
     std::vector<NnWorkH> hw;
     std::vector<int> owner;   // device pair -> caller's pair
     int64_t nout = 0;
-    const int qpb = nn_queries_per_block();
+    const int qpb = nn_queries_per_block(), cpb = nn_points_per_chunk();
     for (size_t k = 0; k < pr.size(); ++k) {
         const int32_t q = pr[k][0], p = pr[k][1];
         if (q < 0 || p < 0 || (size_t)q >= sets.size() || (size_t)p >= sets.size())
@@ -53,7 +53,8 @@ int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::ar
         const int32_t pi = (int32_t)hp.size();
         hp.push_back(NnPairH{(int32_t)soff[q], (int32_t)nq, (int32_t)soff[p], (int32_t)np, (int32_t)nout, 0});
         owner.push_back((int)k);
-        for (int64_t q0 = 0; q0 < nq; q0 += qpb) hw.push_back(NnWorkH{pi, (int32_t)q0});
+        for (int64_t q0 = 0; q0 < nq; q0 += qpb)
+            for (int64_t c0 = 0; c0 < np; c0 += cpb) hw.push_back(NnWorkH{pi, (int32_t)q0, (int32_t)c0, 0});
         nout += nq;
     }
     if (hp.empty()) return MM_OK;
@@ -79,7 +80,7 @@ int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::ar
     MM_TRY_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, e->stream));
     const hipError_t he = launch_nn3_min(d + o_pairs, d + o_work, (int)hw.size(), (const double*)(d + o_x),
                                          (const double*)(d + o_y), (const double*)(d + o_z), (double*)(d + o_out),
-                                         e->stream);
+                                         nout, e->stream);
     if (he != hipSuccess) return hip_error(he, "nearest-neighbour launch");
     MM_TRY_HIP(hipMemcpyAsync(h, d + o_out, (size_t)nout * 8, hipMemcpyDeviceToHost, e->stream));
     MM_TRY_HIP(hipStreamSynchronize(e->stream));

@@ -70,10 +70,11 @@ hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pai
                                   hipStream_t s);
 int        large_rows_per_block();
 // 3-D nearest-neighbour squared distances (mm_nn_kernels.hip); pairs/work are device arrays of the
-// kernel's NnPair {q_off, nq, p_off, np, out_off, pad} / NnWork {pair, q0} records
+// kernel's NnPair {q_off, nq, p_off, np, out_off, pad} / NnWork {pair, q0, c0, pad} records
 hipError_t launch_nn3_min(const void* pairs, const void* work, int n_work, const double* px, const double* py,
-                          const double* pz, double* out, hipStream_t s);
+                          const double* pz, double* out, long long n_out, hipStream_t s);
 int        nn_queries_per_block();
+int        nn_points_per_chunk();
 hipError_t launch_exact_all(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_shortlist(const BatchDev& b, hipStream_t s);
 hipError_t launch_rescore(const BatchDev& b, int max_na, int max_nbp, int total_candidates, hipStream_t s);

@@ -7,12 +7,13 @@
 // calculate_squared_distance: src/ccta/adjust_mesh.rs:7-12).  min is exact, so the result does not
 // depend on the traversal order.
 //
-// Mapping: one workgroup = 256 lanes x QPT queries of one pair; the point set streams through LDS
-// in chunks of CH points stored as (x, y, z, 0) so that a point is two ds_read_b128 broadcasts
-// (all lanes read the same address: conflict-free).  Per (query, point): 3 sub + 3 mul + 2 add +
-// 1 min = 9 fp64 VALU operations against 2/QPT LDS reads -> fp64-VALU bound.  Sets are SoA f64 in
-// HBM; each point is read from HBM once per workgroup of its pair (L2-resident: a set is a few
-// hundred KB), each query once.
+// Mapping: one work item = 256 lanes x QPT queries of one pair against ONE chunk of CH points, staged
+// in LDS as (x, y, z, 0) so that a point is two ds_read broadcasts (all lanes read the same address:
+// conflict-free).  The chunk minima are merged into the output with a 64-bit atomicMin on the bit
+// pattern (order-preserving for values >= 0; the output is pre-filled with +inf), so a search of 82
+// pairs x 20 000 queries x 20 chunks is 65 600 equal items instead of 1 640 long ones -- no tail.
+// Per (query, point): 3 sub + 3 mul + 2 add + 1 min = 9 fp64 VALU operations against 2/QPT LDS
+// reads -> fp64-VALU bound.  Sets are SoA f64 in HBM (L2-resident: a set is a few hundred KB).
 #include <hip/hip_runtime.h>
 
 #include "mm_device.h"
@@ -20,15 +21,24 @@
 namespace mm {
 
 struct NnPair { int32_t q_off, nq, p_off, np, out_off, pad; };   // offsets into the point pool / output
-struct NnWork { int32_t pair, q0; };                              // queries [q0, q0 + 256*QPT) of the pair
+struct NnWork { int32_t pair, q0, c0, pad; };                     // queries [q0, q0+256*QPT) x points [c0, c0+CH)
+
+static constexpr int kNnChunk = 1024;
+
+__global__ void __launch_bounds__(256)
+k_nn3_fill(unsigned long long* __restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = 0x7ff0000000000000ull;   // +inf
+}
 
 template <int QPT>
 __global__ void __launch_bounds__(256)
 k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int n_work,
           const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
-          double* __restrict__ out)
+          unsigned long long* __restrict__ out)
 {
-    constexpr int NT = 256, CH = 1024;
+    constexpr int NT = 256, CH = kNnChunk;
     __shared__ double4 s_p[CH];
     const int tid = threadIdx.x;
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
@@ -42,39 +52,44 @@ k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int
             qx[k] = px[pd.q_off + qc]; qy[k] = py[pd.q_off + qc]; qz[k] = pz[pd.q_off + qc];
             m[k] = __builtin_inf();
         }
-        for (int c0 = 0; c0 < pd.np; c0 += CH) {
-            const int n = pd.np - c0 < CH ? pd.np - c0 : CH;
-            __syncthreads();   // previous chunk fully consumed
-            for (int j = tid; j < n; j += NT)
-                s_p[j] = make_double4(px[pd.p_off + c0 + j], py[pd.p_off + c0 + j], pz[pd.p_off + c0 + j], 0.0);
-            __syncthreads();
+        const int n = pd.np - w.c0 < CH ? pd.np - w.c0 : CH;
+        __syncthreads();   // previous item's chunk fully consumed
+        for (int j = tid; j < n; j += NT)
+            s_p[j] = make_double4(px[pd.p_off + w.c0 + j], py[pd.p_off + w.c0 + j], pz[pd.p_off + w.c0 + j], 0.0);
+        __syncthreads();
 #pragma unroll 4
-            for (int j = 0; j < n; ++j) {
-                const double4 p = s_p[j];
+        for (int j = 0; j < n; ++j) {
+            const double4 p = s_p[j];
 #pragma unroll
-                for (int k = 0; k < QPT; ++k) {
-                    const double dx = qx[k] - p.x, dy = qy[k] - p.y, dz = qz[k] - p.z;
-                    const double v = dx * dx + dy * dy + dz * dz;
-                    m[k] = __builtin_fmin(m[k], v);
-                }
+            for (int k = 0; k < QPT; ++k) {
+                const double dx = qx[k] - p.x, dy = qy[k] - p.y, dz = qz[k] - p.z;
+                const double v = dx * dx + dy * dy + dz * dz;
+                m[k] = __builtin_fmin(m[k], v);
             }
         }
 #pragma unroll
         for (int k = 0; k < QPT; ++k) {
             const int q = w.q0 + k * NT + tid;
-            if (q < pd.nq) out[pd.out_off + q] = m[k];
+            if (q < pd.nq) atomicMin(&out[pd.out_off + q], (unsigned long long)__double_as_longlong(m[k]));
         }
     }
 }
 
-int nn_queries_per_block() { return 256 * 2; }
+// queries per lane: 1..4 measured within 5 % of each other on MI355X (10.9 / 10.4 / 10.4 / 10.3 ms for the
+// 3.3e10-pair search of tools/bench_ccta.py): the kernel is bound by fp64 VALU issue, not by the LDS reads
+static constexpr int kNnQpt = 2;
+int nn_queries_per_block() { return 256 * kNnQpt; }
+int nn_points_per_chunk() { return kNnChunk; }
 
 hipError_t launch_nn3_min(const void* pairs, const void* work, int n_work, const double* px, const double* py,
-                          const double* pz, double* out, hipStream_t s)
+                          const double* pz, double* out, long long n_out, hipStream_t s)
 {
-    if (n_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_nn3_min<2>, dim3((unsigned)n_work), dim3(256), 0, s, (const NnPair*)pairs,
-                       (const NnWork*)work, n_work, px, py, pz, out);
+    if (n_out > 0)
+        hipLaunchKernelGGL(k_nn3_fill, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s,
+                           (unsigned long long*)out, n_out);
+    if (n_work > 0)
+        hipLaunchKernelGGL(k_nn3_min<kNnQpt>, dim3((unsigned)n_work), dim3(256), 0, s, (const NnPair*)pairs,
+                           (const NnWork*)work, n_work, px, py, pz, (unsigned long long*)out);
     return hipGetLastError();
 }
 

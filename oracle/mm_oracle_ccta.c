@@ -6,6 +6,9 @@
 
 #include <float.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -17,7 +20,12 @@ static double sq_dist(double ax, double ay, double az, double bx, double by, dou
 
 void orc_nn_min_sq(const orc_point* a, size_t na, const orc_point* b, size_t nb, double* out)
 {
-#pragma omp parallel for schedule(static)
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+    if (nt > 16) nt = 16;   /* a GPU box's CPU share is 16 cores whatever nproc says */
+#endif
+#pragma omp parallel for schedule(static) num_threads(nt)
     for (long long i = 0; i < (long long)na; ++i) {
         double m = INFINITY;
         for (size_t j = 0; j < nb; ++j) {
