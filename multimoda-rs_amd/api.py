@@ -52,10 +52,26 @@ class GeometryPair:
     label: str = ""
 
 
+def _with_contour_centroids(g: G.FlatGeometry) -> G.FlatGeometry:
+    """Frame.lumen.centroid of a returned geometry (read by the centerline placement, centerline.py).
+    The reference recomputes it as the mean of the points in smooth_frames (geometry.rs:204) and in
+    every Frame::translate (frame.rs:20), and leaves it stale in Frame::rotate: it is the fresh mean
+    after smoothing and for every geometry moved by align_between (which ends with a translation,
+    align_between.rs:68).  Otherwise (smooth=False, reference side of a pair) it is stale in the
+    reference and not tracked here: the field stays None and ``centerline.with_lumen_centroids`` is the
+    caller's choice."""
+    if g.meta.get("lumen_centroid_fresh"):
+        from .centerline import with_lumen_centroids
+        with_lumen_centroids(g)
+    else:
+        g.has_lumen_centroid, g.lumen_centroids = None, None
+    return g
+
+
 def _make_pair(a: G.FlatGeometry, b: G.FlatGeometry) -> GeometryPair:
     """GeometryPair::new: label = "<a> - <b>" (the labels the reference's plumbing tests check,
     binding/functions.rs:1607-1616)."""
-    return GeometryPair(a, b, f"{a.label} - {b.label}")
+    return GeometryPair(_with_contour_centroids(a), _with_contour_centroids(b), f"{a.label} - {b.label}")
 
 
 # ---------------------------------------------------------------------------------------
@@ -239,6 +255,7 @@ def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
     if smooth:
         _smooth_frames(g)
     g.meta["anomalous"] = bool(anomalous)
+    g.meta["lumen_centroid_fresh"] = bool(smooth)        # geometry.rs:204
     return bool(anomalous)
 
 
@@ -300,11 +317,13 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
     logs, _flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
     a, b, c, d = geoms
     G.align_between(eng, [(a, b), (c, d)], rng, step, sample_size)                 # entry.rs:206-240
+    b.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True         # moved last by a translation
     pair_ab = _make_pair(a.copy(), b.copy())
     pair_cd = _make_pair(c.copy(), d.copy())
     if not both_batches:
         return pair_ab, pair_cd, tuple(logs)
     G.align_between(eng, [(a, c), (b, d)], rng, step, sample_size)                 # entry.rs:243-277
+    c.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True
     pair_ac = _make_pair(a.copy(), c.copy())
     pair_bd = _make_pair(b.copy(), d.copy())
     return pair_ab, pair_cd, pair_ac, pair_bd, tuple(logs)
@@ -366,6 +385,7 @@ def _pair(geoms, step, rng, smooth, bruteforce, sample_size, engine):
     logs, _flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
     a, b = geoms
     G.align_between(eng, [(a, b)], rng, step, sample_size)                          # entry.rs:655
+    b.meta["lumen_centroid_fresh"] = True
     return _make_pair(a, b), (logs[0], logs[1])
 
 
@@ -402,7 +422,7 @@ def from_array_single(input_data: InputData, step_rotation_deg: float = 0.5, ran
     geoms = _prepare_from_inputs([input_data], image_center, radius, n_points)
     logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
                                          engine)
-    return geoms[0], logs[0]
+    return _with_contour_centroids(geoms[0]), logs[0]
 
 
 def from_file_single(input_path: str, labels=None, diastole: bool = True, step_rotation_deg: float = 0.5,
@@ -415,4 +435,4 @@ def from_file_single(input_path: str, labels=None, diastole: bool = True, step_r
     geoms = _prepare_from_paths([input_path], labels, 1, image_center, radius, n_points, single_diastole=diastole)
     logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
                                          engine)
-    return geoms[0], logs[0]
+    return _with_contour_centroids(geoms[0]), logs[0]

@@ -97,3 +97,29 @@ def test_align_combined_matches_oracle_and_truth(engine, oracle, ocl, mm, pair):
     assert rot_deg == pytest.approx(37.0, abs=1e-9) and oidx == 12
     assert np.abs(first.lumen - case["truth"]["placed"].lumen).max() < 1e-9
     assert first.meta["refine_evals"] == 5 * 11
+
+
+def test_from_file_pair_then_align_manual(engine, oracle, ocl, mm):
+    """The composition the reference's examples/fullworkflow.py runs: from_file_singlepair -> align_* on a
+    centerline.  The returned geometries carry Frame.lumen.centroid as the reference leaves it (fresh mean
+    after smoothing / after align_between's final translation), and the placement of the pair equals the
+    oracle's placement of the same pair."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ivus_rest")
+    pair, _ = mm.from_file_singlepair(gold, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
+    for g in (pair.geom_a, pair.geom_b):
+        assert g.lumen_centroids is not None and g.has_lumen_centroid.all()
+        for i in range(g.n_frames):
+            assert tuple(g.lumen_centroids[i]) == mm.contour_centroid(g.frame_lumen(i))
+    nocen, _ = mm.from_file_single(gold, smooth=False, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
+    assert nocen.lumen_centroids is None                         # stale in the reference, not tracked here
+    a = pair.geom_a
+    s = np.arange(0.0, 40.0, 0.25)
+    cl = mm.Centerline.from_contour_points(np.stack([20.0 + 4.0 * np.sin(s / 11.0), -150.0 + 0.2 * s, 900.0 - 0.9 * s], axis=1))
+    ref = cl.xyz()[10]
+    out, sp, rot = mm.align_manual(cl, pair, 25.0, ref)
+    oa, ob = to_oracle(oracle, pair.geom_a), to_oracle(oracle, pair.geom_b)
+    osp, orot = ocl.align_manual(to_oracle_cl(ocl, cl), [oa, ob], 25.0, ref)
+    assert sp == osp and rot == orot * (180.0 / math.pi)
+    assert geoms_equal(out.geom_a, oa) and geoms_equal(out.geom_b, ob)
+    assert sp == pytest.approx(np.linalg.norm(np.diff(a.centroids, axis=0), axis=1).mean(), rel=1e-12)
