@@ -4,16 +4,15 @@
 // in the reference's operation order (-ffp-contract=off).  Reference:
 // src/ccta/adjust_mesh/scale_coronary.rs (lines cited per function).
 #include <algorithm>
-#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <numeric>
-#include <thread>
 #include <vector>
 
 #include "../../include/mm_ccta.h"
 #include "mm_engine.h"
+#include "mm_pool.h"
 
 namespace mm {
 namespace {
@@ -110,32 +109,23 @@ void radial_units(const mm_clpoint* cl, int64_t ncl, const double* pts, int64_t 
 {
     unit.assign((size_t)n * 3, 0.0);
     has.assign((size_t)n, 0);
-    std::atomic<int64_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const int64_t i0 = next.fetch_add(256);
-            if (i0 >= n) break;
-            for (int64_t i = i0; i < std::min(n, i0 + 256); ++i) {
-                const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-                double best = DBL_MAX;                                        // :249-258
-                int64_t kb = 0;
-                for (int64_t k = 0; k < ncl; ++k) {
-                    const double dx = x - cl[k].x, dy = y - cl[k].y, dz = z - cl[k].z;
-                    const double d = dx * dx + dy * dy + dz * dz;
-                    if (d < best) { best = d; kb = k; }
-                }
-                const double vx = x - cl[kb].x, vy = y - cl[kb].y, vz = z - cl[kb].z;
-                const double nn = std::sqrt(vx * vx + vy * vy + vz * vz);
-                if (nn > 0.0) { unit[3 * i] = vx / nn; unit[3 * i + 1] = vy / nn; unit[3 * i + 2] = vz / nn; has[i] = 1; }
+    constexpr int64_t kBlock = 256;
+    parallel_for((int)((n + kBlock - 1) / kBlock), [&](int blk) {
+        const int64_t i0 = (int64_t)blk * kBlock;
+        for (int64_t i = i0; i < std::min(n, i0 + kBlock); ++i) {
+            const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+            double best = DBL_MAX;                                            // :249-258
+            int64_t kb = 0;
+            for (int64_t k = 0; k < ncl; ++k) {
+                const double dx = x - cl[k].x, dy = y - cl[k].y, dz = z - cl[k].z;
+                const double d = dx * dx + dy * dy + dz * dz;
+                if (d < best) { best = d; kb = k; }
             }
+            const double vx = x - cl[kb].x, vy = y - cl[kb].y, vz = z - cl[kb].z;
+            const double nn = std::sqrt(vx * vx + vy * vy + vz * vz);
+            if (nn > 0.0) { unit[3 * i] = vx / nn; unit[3 * i + 1] = vy / nn; unit[3 * i + 2] = vz / nn; has[i] = 1; }
         }
-    };
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(hw, (n * ncl) / 200000 + 1));
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker);
-    worker();
-    for (std::thread& t : th) t.join();
+    });
 }
 
 inline void morph(const double* pts, const std::vector<double>& unit, const std::vector<uint8_t>& has, int64_t n,

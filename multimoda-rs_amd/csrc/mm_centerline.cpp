@@ -9,16 +9,15 @@
 // geometry/rotation_specialization.rs, matrix * vector accumulated column by column (blas gemv).
 #include <algorithm>
 #include <array>
-#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <numeric>
-#include <thread>
 #include <vector>
 
 #include "../../include/mm_centerline.h"
 #include "mm_engine.h"
+#include "mm_pool.h"
 
 namespace mm {
 namespace {
@@ -439,52 +438,39 @@ int refine(Engine* e, mm_cl_geometry** geoms, const mm_clpoint* cl, int64_t ncl,
     std::vector<double> flat_x((size_t)flat_total), flat_y((size_t)flat_total);
     int64_t max_len = 0;
     for (int64_t f = 0; f < F; ++f) max_len = std::max(max_len, g->lumen_off[f + 1] - g->lumen_off[f]);
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
+    parallel_for((int)cands.size(), [&](int ci) {
         std::vector<double> buf((size_t)max_len * 3);
         SortScratch sc;
-        for (;;) {
-            const size_t ci = next.fetch_add(1);
-            if (ci >= cands.size()) break;
-            const Candidate& cd = cands[ci];
-            const Group& grp = groups[(size_t)cd.group];
-            double s = 0.0, c = 1.0;
-            if (cd.angle != 0.0) sin_cos(cd.angle, s, c);
-            int64_t w = cd.off;
-            for (int64_t f = 0; f < F; ++f) {
-                const int64_t len = g->lumen_off[f + 1] - g->lumen_off[f];
-                double* p = buf.data();
-                std::memcpy(p, g->lumen + 3 * g->lumen_off[f], (size_t)len * 24);
-                if (cd.angle != 0.0) {                                                        // rotate_by_best_rotation (:395), geometry.rs:241-250
-                    rotate_xy_span(p, 0, len, s, c, g->centroid[3 * f], g->centroid[3 * f + 1]);
-                    sort_contour(p, len, sc);
-                }
-                // cl_segment = points[cur .. cur+F), ref_pt = its first point (:381-392): frame f -> cl[cur + f]
-                const double* lc;
-                const bool hc = lumen_centroid_of(prim, (int32_t)f, lc);
-                const FrameTf tf = align_frame(p, len, hc, lc, cl[cd.cl_idx + f]);
-                auto emit = [&](int64_t src) {
-                    double q[3] = {p[3 * src], p[3 * src + 1], p[3 * src + 2]};
-                    tf.apply(q);
-                    flat_x[(size_t)w] = q[0]; flat_y[(size_t)w] = q[1]; ++w;
-                };
-                if (grp.n_down < m && len > grp.n_down) {                                     // downsample_contour_points
-                    const double stepf = (double)len / (double)grp.n_down;
-                    for (int64_t i = 0; i < grp.n_down; ++i) emit((int64_t)((double)i * stepf));
-                } else {
-                    for (int64_t i = 0; i < len; ++i) emit(i);
-                }
+        const Candidate& cd = cands[(size_t)ci];
+        const Group& grp = groups[(size_t)cd.group];
+        double s = 0.0, c = 1.0;
+        if (cd.angle != 0.0) sin_cos(cd.angle, s, c);
+        int64_t w = cd.off;
+        for (int64_t f = 0; f < F; ++f) {
+            const int64_t len = g->lumen_off[f + 1] - g->lumen_off[f];
+            double* p = buf.data();
+            std::memcpy(p, g->lumen + 3 * g->lumen_off[f], (size_t)len * 24);
+            if (cd.angle != 0.0) {                                                            // rotate_by_best_rotation (:395), geometry.rs:241-250
+                rotate_xy_span(p, 0, len, s, c, g->centroid[3 * f], g->centroid[3 * f + 1]);
+                sort_contour(p, len, sc);
+            }
+            // cl_segment = points[cur .. cur+F), ref_pt = its first point (:381-392): frame f -> cl[cur + f]
+            const double* lc;
+            const bool hc = lumen_centroid_of(prim, (int32_t)f, lc);
+            const FrameTf tf = align_frame(p, len, hc, lc, cl[cd.cl_idx + f]);
+            auto emit = [&](int64_t src) {
+                double q[3] = {p[3 * src], p[3 * src + 1], p[3 * src + 2]};
+                tf.apply(q);
+                flat_x[(size_t)w] = q[0]; flat_y[(size_t)w] = q[1]; ++w;
+            };
+            if (grp.n_down < m && len > grp.n_down) {                                         // downsample_contour_points
+                const double stepf = (double)len / (double)grp.n_down;
+                for (int64_t i = 0; i < grp.n_down; ++i) emit((int64_t)((double)i * stepf));
+            } else {
+                for (int64_t i = 0; i < len; ++i) emit(i);
             }
         }
-    };
-    {
-        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        const unsigned nt = (unsigned)std::min<size_t>(hw, cands.size());
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker);
-        worker();
-        for (std::thread& t : th) t.join();
-    }
+    });
 
     // one device batch: hausdorff_distance(filtered points of the group, placed frames), x,y only (:431)
     std::vector<SetRef> sets;

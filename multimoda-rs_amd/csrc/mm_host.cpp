@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "mm_engine.h"
+#include "mm_pool.h"
 
 #include <chrono>
 #include <thread>
@@ -466,31 +467,48 @@ int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresol
     bool all_resolved = true;
     for (uint8_t r : resolved) all_resolved = all_resolved && (r != 0);
     if (all_resolved) {
-        auto walk_one = [&](int g) {
-            mm_geometry* G = geoms[g];
+        // Pass 1 (serial, O(frames)): the chain couples frames only through the frame centroids.
+        // Rotating a frame about its own centroid leaves that centroid bit for bit
+        // (x = c - c = 0 -> 0*cos - 0*sin + c), so after step i the centroid is c + (p - c) with p the
+        // final centroid of frame i-1; cumulative angles are a prefix sum.  Pass 2 (parallel over
+        // frames, worker pool): the same Frame::rotate / translate / rotate calls as the sequential
+        // walk, with those arguments -- every frame touches only its own data.
+        struct Step { int g; int32_t i; double cum, tx, ty, cx, cy, best; };
+        std::vector<Step> steps;
+        for (int g = 0; g < n_geoms; ++g) {
+            const mm_geometry* G = geoms[g];
             double cumulative = 0.0;
+            double pcx = G->n_frames > 0 ? G->centroid[0] : 0.0, pcy = G->n_frames > 0 ? G->centroid[1] : 0.0;
             for (int32_t i = 1; i < G->n_frames; ++i) {
-                const double pcx = G->centroid[3 * (i - 1)], pcy = G->centroid[3 * (i - 1) + 1];
-                if (cumulative != 0.0)  // align_within.rs:79-82
-                    mm_frame_rotate(G, i, cumulative, G->centroid[3 * i], G->centroid[3 * i + 1]);
-                const double tx = pcx - G->centroid[3 * i], ty = pcy - G->centroid[3 * i + 1];  // :84-88
-                mm_frame_translate(G, i, tx, ty, 0.0);                                            // :90
-                const double cx = G->centroid[3 * i], cy = G->centroid[3 * i + 1];
+                const double c0x = G->centroid[3 * i], c0y = G->centroid[3 * i + 1];
+                const double tx = pcx - c0x, ty = pcy - c0y;                 // align_within.rs:84-88
+                const double cx = c0x + tx, cy = c0y + ty;                   // frame.rs:35-36
                 const double best = centre[job_base[g] + (i - 1)];
-                mm_frame_rotate(G, i, best, cx, cy);  // :121-122
-                cumulative += best;                   // :123
-                if (logs && logs[g]) {
-                    mm_alignlog& L = logs[g][i - 1];
+                steps.push_back(Step{g, i, cumulative, tx, ty, cx, cy, best});
+                cumulative += best;                                          // :123
+                pcx = cx; pcy = cy;
+            }
+        }
+        constexpr int kChunk = 16;
+        const int n_chunks = (int)((steps.size() + kChunk - 1) / kChunk);
+        parallel_for(n_chunks, [&](int c) {
+            const size_t lo = (size_t)c * kChunk, hi = std::min(steps.size(), lo + kChunk);
+            for (size_t k = lo; k < hi; ++k) {
+                const Step& st = steps[k];
+                mm_geometry* G = geoms[st.g];
+                const int32_t i = st.i;
+                if (st.cum != 0.0)  // align_within.rs:79-82
+                    mm_frame_rotate(G, i, st.cum, G->centroid[3 * i], G->centroid[3 * i + 1]);
+                mm_frame_translate(G, i, st.tx, st.ty, 0.0);                 // :90
+                mm_frame_rotate(G, i, st.best, st.cx, st.cy);                // :121-122
+                if (logs && logs[st.g]) {
+                    mm_alignlog& L = logs[st.g][i - 1];
                     L.contour_id = G->id[i]; L.matched_to = G->id[i - 1];
-                    L.rot_deg = rad2deg(best); L.tx = tx; L.ty = ty;
+                    L.rot_deg = rad2deg(st.best); L.tx = st.tx; L.ty = st.ty;
                     L.cx = G->centroid[3 * i]; L.cy = G->centroid[3 * i + 1];
                 }
             }
-        };
-        std::vector<std::thread> th;
-        for (int g = 1; g < n_geoms; ++g) th.emplace_back(walk_one, g);
-        walk_one(0);
-        for (std::thread& t : th) t.join();
+        });
         if (pose_evals) for (int64_t v : evals) *pose_evals += v;
         return MM_OK;
     }
@@ -941,18 +959,15 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
         }
     };
     {
-        // a few threads per pair; small geometries stay on the calling thread
-        std::vector<std::thread> th;
+        // chunks of frames over the worker pool; small geometries stay on the calling thread
+        struct Part { int p; int32_t f0, f1; };
+        std::vector<Part> parts;
         for (int p = 0; p < n_pairs; ++p) {
             const int32_t F = b[p]->n_frames;
-            const int parts = F >= 64 ? 4 : 1;
-            for (int q = 0; q < parts; ++q) {
-                const int32_t f0 = (int32_t)((int64_t)F * q / parts), f1 = (int32_t)((int64_t)F * (q + 1) / parts);
-                if (p == n_pairs - 1 && q == parts - 1) move_frames(p, f0, f1);
-                else th.emplace_back(move_frames, p, f0, f1);
-            }
+            const int32_t step = F >= 64 ? 32 : std::max<int32_t>(F, 1);
+            for (int32_t f0 = 0; f0 < F; f0 += step) parts.push_back(Part{p, f0, std::min<int32_t>(F, f0 + step)});
         }
-        for (std::thread& t : th) t.join();
+        parallel_for((int)parts.size(), [&](int k) { move_frames(parts[(size_t)k].p, parts[(size_t)k].f0, parts[(size_t)k].f1); });
     }
     return MM_OK;
 }
