@@ -3,15 +3,13 @@
 (multimodars/_processing.py:42-1007 -> binding/functions.rs:143-1423 -> binding/entry.rs).
 
 Orchestration follows entry.rs: build geometries (io.py), align frames within every pullback
-(device search, decoupled mode), the lumen-affecting post-steps of
-``align_frames_in_geometry`` (align_within.rs:136-170), then the between-pullback alignments in
-the reference's order (AB | CD, then AC | BD).  Same argument names, meaning and defaults as
-the reference, with two deliberate differences: ``write_obj`` and ``postprocessing`` default to
-False, because OBJ export (to_object/*) and the z-resampling / trimming of
-``postprocess_geom_pair`` are outside this path; passing True
-raises NotImplementedError instead of silently skipping work.  Wall-contour synthesis
-(wall.rs) and hole filling are not restated either: neither changes a lumen coordinate that
-enters the search, and a geometry WITH a z-gap raises instead of being silently mis-handled.
+(device search, decoupled mode), the post-steps of ``align_frames_in_geometry``
+(align_within.rs:136-170: hole filling, reference point to the right, aortic flags, wall contours,
+smoothing -- postproc.py), the between-pullback alignments in the reference's order (AB | CD, then
+AC | BD), then ``postprocess_geom_pair`` per pair.  Same argument names, meaning and defaults as the
+reference, with one deliberate difference: ``write_obj`` defaults to False, because OBJ export
+(to_object/*) is outside this path; passing True raises
+NotImplementedError instead of silently skipping work.
 
 Return values: ``FlatGeometry`` / ``GeometryPair`` (numpy containers) instead of the PyO3 value
 classes; logs are the reference's 7-tuples ``(id, matched_to, rot_deg, tx, ty, cx, cy)``.
@@ -241,19 +239,43 @@ def _ref_or_proximal(g: G.FlatGeometry) -> int:
     return int(g.lumen_ids[0] if g.orig_frames[0] > g.orig_frames[-1] else g.lumen_ids[-1])
 
 
+def _replace(g: G.FlatGeometry, h: G.FlatGeometry) -> None:
+    """g <- h in place (callers hold references to g)."""
+    for name in ("ids", "lumen_ids", "orig_frames", "centroids", "lumen_off", "lumen", "cath_off", "cath",
+                 "extra_off", "extra", "has_ref", "ref", "label", "meta", "has_lumen_centroid", "lumen_centroids"):
+        setattr(g, name, getattr(h, name))
+
+
 def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
-    """align_within.rs:136-160 after the chain; returns the anomalous flag."""
+    """align_within.rs:136-160 after the chain: hole filling, reference point to the right, aortic flags,
+    wall contours, smoothing; returns the anomalous flag.  The lumen contour centroid the reference
+    carries at this point is the mean before the chain's last rotation (frame.rs:20); here it is the
+    mean of the current points (x, y may differ by that rotation; z is exact)."""
+    from . import frames as FR
+    from . import postproc as PP
+    from .centerline import with_lumen_centroids
     hole, _ = _detect_holes(g)
-    if hole:
-        raise NotImplementedError("hole filling (align_within.rs:378-445) is not restated: the pullback has a z-gap")
+    if hole:                                                                   # :136
+        with_lumen_centroids(g)
+        fr = PP.fill_holes(FR.to_frames(g))
+        _replace(g, FR.from_frames(fr, g.label, g.meta))
+    if ref_idx >= g.n_frames:
+        raise RuntimeError("reference frame index out of range")
     lum = g.frame_lumen(ref_idx)
     a_th = g.meta.get("aortic_thickness")
     p_th = g.meta.get("pulmonary_thickness")
     anomalous = (_elliptic_ratio(lum) > 2.0 or (a_th is not None and a_th[ref_idx] is not None)
                  or (p_th is not None and p_th[ref_idx] is not None))        # align_within.rs:249-254
-    _rotate_geometry(g, _angle_ref_point_to_right(g, ref_idx, anomalous))
+    _rotate_geometry(g, _angle_ref_point_to_right(g, ref_idx, anomalous))      # :139-142
+    with_lumen_centroids(g)
+    fr = FR.to_frames(g)
+    if anomalous:
+        PP.assign_aortic(fr)                                                   # :144-148
+    fr = PP.create_wall_frames(fr, anomalous, False)                           # :150-154
     if smooth:
-        _smooth_frames(g)
+        fr = PP.smooth_frames(fr)                                              # :156-158
+    meta = dict(g.meta)
+    _replace(g, FR.from_frames(fr, g.label, meta))
     g.meta["anomalous"] = bool(anomalous)
     g.meta["lumen_centroid_fresh"] = bool(smooth)        # geometry.rs:204
     return bool(anomalous)
@@ -302,31 +324,46 @@ def _prepare_from_inputs(inputs: Sequence[InputData], image_center, radius, n_po
     return [build_geometry_from_inputdata(d, None, d.label, d.diastole, image_center, radius, n_points) for d in inputs]
 
 
-def _check_unsupported(write_obj, postprocessing):
+def _check_unsupported(write_obj):
     if write_obj:
         raise NotImplementedError("write_obj=True: OBJ/MTL export (to_object/*, io/output.rs) is outside this path")
-    if postprocessing:
-        raise NotImplementedError("postprocessing=True: postprocess_geom_pair (postprocessing.rs:12) is outside this path")
+
+
+def _maybe_postprocess(pair: GeometryPair, anomalous: bool, postprocessing: bool) -> GeometryPair:
+    """maybe_postprocess (entry.rs:57-69): postprocess_geom_pair(pair, TOLERANCE, anomalous)."""
+    if not postprocessing:
+        return pair
+    from . import frames as FR
+    from . import postproc as PP
+    try:
+        fa, fb = PP.postprocess_pair(FR.to_frames(pair.geom_a), FR.to_frames(pair.geom_b), TOLERANCE, anomalous)
+    except RuntimeError as e:
+        raise RuntimeError(f"Failed postprocessing of {pair.label}: {e}") from e
+    a = FR.from_frames(fa, pair.geom_a.label, pair.geom_a.meta)
+    b = FR.from_frames(fb, pair.geom_b.label, pair.geom_b.meta)
+    return GeometryPair(a, b, pair.label)
 
 
 # ---------------------------------------------------------------------------------------
 # the four modes (entry.rs:71, 363, 572, 691)
 # ---------------------------------------------------------------------------------------
-def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batches=True):
+def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batches=True, postprocessing=False):
     eng = engine or default_engine()
-    logs, _flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
+    logs, flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
+    anomalous = any(flags)                                                         # entry.rs:279-280
+    post = lambda pr: _maybe_postprocess(pr, anomalous, postprocessing)
     a, b, c, d = geoms
     G.align_between(eng, [(a, b), (c, d)], rng, step, sample_size)                 # entry.rs:206-240
     b.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True         # moved last by a translation
     pair_ab = _make_pair(a.copy(), b.copy())
     pair_cd = _make_pair(c.copy(), d.copy())
     if not both_batches:
-        return pair_ab, pair_cd, tuple(logs)
+        return post(pair_ab), post(pair_cd), tuple(logs)
     G.align_between(eng, [(a, c), (b, d)], rng, step, sample_size)                 # entry.rs:243-277
     c.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True
     pair_ac = _make_pair(a.copy(), c.copy())
     pair_bd = _make_pair(b.copy(), d.copy())
-    return pair_ab, pair_cd, pair_ac, pair_bd, tuple(logs)
+    return post(pair_ab), post(pair_cd), post(pair_ac), post(pair_bd), tuple(logs)
 
 
 def from_array_full(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData, input_data_d: InputData,
@@ -335,11 +372,12 @@ def from_array_full(input_data_a: InputData, input_data_b: InputData, input_data
                     watertight: bool = True, contour_types=None, output_path_ab: str = "output/rest",
                     output_path_cd: str = "output/stress", output_path_ac: str = "output/diastole",
                     output_path_bd: str = "output/systole", interpolation_steps: int = 0, bruteforce: bool = False,
-                    smooth: bool = True, postprocessing: bool = False, engine: Optional[N.Engine] = None):
+                    smooth: bool = True, postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:553 / functions.rs:827 / entry.rs:71 -> (pair_ab, pair_cd, pair_ac, pair_bd, (logs x4))."""
-    _check_unsupported(write_obj, postprocessing)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data_a, input_data_b, input_data_c, input_data_d], image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine,
+                 postprocessing=postprocessing)
 
 
 def from_file_full(input_path_ab: str, input_path_cd: str, labels=None, step_rotation_deg: float = 0.5,
@@ -348,11 +386,12 @@ def from_file_full(input_path_ab: str, input_path_cd: str, labels=None, step_rot
                    contour_types=None, output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
                    output_path_ac: str = "output/diastole", output_path_bd: str = "output/systole",
                    interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
-                   postprocessing: bool = False, engine: Optional[N.Engine] = None):
+                   postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:42 / functions.rs:168 / entry.rs:71."""
-    _check_unsupported(write_obj, postprocessing)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path_ab, input_path_cd], labels, 4, image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine,
+                 postprocessing=postprocessing)
 
 
 def from_array_doublepair(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData,
@@ -361,11 +400,12 @@ def from_array_doublepair(input_data_a: InputData, input_data_b: InputData, inpu
                           write_obj: bool = False, watertight: bool = True, contour_types=None,
                           output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
                           interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
-                          postprocessing: bool = False, engine: Optional[N.Engine] = None):
+                          postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:698 / entry.rs:363 -> (pair_ab, pair_cd, (logs x4))."""
-    _check_unsupported(write_obj, postprocessing)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data_a, input_data_b, input_data_c, input_data_d], image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False,
+                 postprocessing=postprocessing)
 
 
 def from_file_doublepair(input_path_ab: str, input_path_cd: str, labels=None, step_rotation_deg: float = 0.5,
@@ -373,43 +413,44 @@ def from_file_doublepair(input_path_ab: str, input_path_cd: str, labels=None, st
                          radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
                          contour_types=None, output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
                          interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
-                         postprocessing: bool = False, engine: Optional[N.Engine] = None):
+                         postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:201 / entry.rs:363."""
-    _check_unsupported(write_obj, postprocessing)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path_ab, input_path_cd], labels, 4, image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False)
+    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False,
+                 postprocessing=postprocessing)
 
 
-def _pair(geoms, step, rng, smooth, bruteforce, sample_size, engine):
+def _pair(geoms, step, rng, smooth, bruteforce, sample_size, engine, postprocessing=False):
     eng = engine or default_engine()
-    logs, _flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
+    logs, flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
     a, b = geoms
     G.align_between(eng, [(a, b)], rng, step, sample_size)                          # entry.rs:655
     b.meta["lumen_centroid_fresh"] = True
-    return _make_pair(a, b), (logs[0], logs[1])
+    return _maybe_postprocess(_make_pair(a, b), any(flags), postprocessing), (logs[0], logs[1])
 
 
 def from_array_singlepair(input_data_a: InputData, input_data_b: InputData, step_rotation_deg: float = 0.5,
                           range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
                           radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
                           contour_types=None, output_path: str = "output/singlepair", interpolation_steps: int = 0,
-                          bruteforce: bool = False, smooth: bool = True, postprocessing: bool = False,
+                          bruteforce: bool = False, smooth: bool = True, postprocessing: bool = True,
                           engine: Optional[N.Engine] = None):
     """_processing.py:822 / entry.rs:572 -> (pair, (logs_a, logs_b))."""
-    _check_unsupported(write_obj, postprocessing)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data_a, input_data_b], image_center, radius, n_points)
-    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, postprocessing)
 
 
 def from_file_singlepair(input_path: str, labels=None, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
                          sample_size: int = 500, image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20,
                          write_obj: bool = False, watertight: bool = True, contour_types=None,
                          output_path: str = "output/singlepair", interpolation_steps: int = 0, bruteforce: bool = False,
-                         smooth: bool = True, postprocessing: bool = False, engine: Optional[N.Engine] = None):
+                         smooth: bool = True, postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:333 / functions.rs:517 / entry.rs:572: one folder read twice (diastole, systole)."""
-    _check_unsupported(write_obj, postprocessing)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path], labels, 2, image_center, radius, n_points)
-    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine)
+    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, postprocessing)
 
 
 def from_array_single(input_data: InputData, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
@@ -418,7 +459,7 @@ def from_array_single(input_data: InputData, step_rotation_deg: float = 0.5, ran
                       output_path: str = "output/single", bruteforce: bool = False, smooth: bool = True,
                       engine: Optional[N.Engine] = None):
     """_processing.py:922 / functions.rs:1350 / entry.rs:691 -> (geometry, logs)."""
-    _check_unsupported(write_obj, False)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data], image_center, radius, n_points)
     logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
                                          engine)
@@ -431,7 +472,7 @@ def from_file_single(input_path: str, labels=None, diastole: bool = True, step_r
                      contour_types=None, output_path: str = "output/single", bruteforce: bool = False,
                      smooth: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:449 / functions.rs:656 / entry.rs:691."""
-    _check_unsupported(write_obj, False)
+    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path], labels, 1, image_center, radius, n_points, single_diastole=diastole)
     logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
                                          engine)

@@ -7,9 +7,9 @@ Same argument names, meaning, defaults and error behaviour; geometries are ``Fla
 ``GeometryPair`` containers instead of the PyO3 value classes and are returned as transformed
 copies (the reference clones at the boundary too).  The three-point sweep and the frame placement
 are host f64 (csrc/mm_centerline.cpp); every Hausdorff evaluation of ``align_combined``'s
-refinement grid runs on the GPU.  ``write=True`` (OBJ export, to_object/*) and
-``align_wall_anomalous=True`` (align.rs:381-595) are outside this path and raise
-NotImplementedError instead of silently skipping work.
+refinement grid runs on the GPU; ``align_wall_anomalous=True`` applies the wall twist compensation
+(align.rs:381-595, postproc.align_walls) after the placement.  ``write=True`` (OBJ export,
+to_object/*) is outside this path and raises NotImplementedError instead of silently skipping work.
 """
 from __future__ import annotations
 
@@ -170,11 +170,22 @@ def _unpack(geometry):
     raise TypeError("geometry must be a FlatGeometry or a GeometryPair")     # binding/align.rs:151
 
 
-def _unsupported(write: bool, align_wall_anomalous: bool):
+def _unsupported(write: bool):
     if write:
         raise NotImplementedError("write=True (OBJ export, to_object/*) is outside the accelerated path")
-    if align_wall_anomalous:
-        raise NotImplementedError("align_wall_anomalous=True (align.rs:381-595) is not built yet")
+
+
+def _align_walls(geoms: Sequence[G.FlatGeometry], anomalous: bool) -> None:
+    """align_walls (align.rs:589-595): the Wall contours of every geometry follow the parallel-transported
+    direction of their frame 0 (postproc.align_walls); nothing happens with fewer than two frames."""
+    if not anomalous or geoms[0].n_frames < 2:
+        return
+    from . import frames as FR
+    from . import postproc as PP
+    for g in geoms:
+        fr = PP.align_walls(FR.to_frames(g), True)
+        h = FR.from_frames(fr, g.label, g.meta)
+        g.extra_off, g.extra = h.extra_off, h.extra        # only wall points move
 
 
 def _ref_point_index(g: G.FlatGeometry) -> int:
@@ -239,7 +250,7 @@ def align_three_point(centerline: Centerline, geometry, main_ref_pt, countercloc
                       interpolation_steps: int = 0, output_dir: str = "output/aligned", contour_types=None,
                       case_name: str = "None", align_wall_anomalous: bool = False):
     """multimodars/_processing.py:1010-1103 -> (geometry, spacing_mm, total_rotation_deg)."""
-    _unsupported(write, align_wall_anomalous)
+    _unsupported(write)
     geoms, rebuild = _unpack(geometry)
     pk = _ClPack(geoms)
     a, b, d = _v3(main_ref_pt), _v3(counterclockwise_ref_pt), _v3(clockwise_ref_pt)
@@ -248,6 +259,7 @@ def align_three_point(centerline: Centerline, geometry, main_ref_pt, countercloc
                                          _ref_point_index(geoms[0]), N._ptr(a), N._ptr(b), N._ptr(d),
                                          math.radians(angle_step_deg), 0, C.byref(sp), C.byref(rot)),
             "align_three_point")
+    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:105-107
     return rebuild(), sp.value, rot.value * (180.0 / math.pi)
 
 
@@ -255,7 +267,7 @@ def align_manual(centerline: Centerline, geometry, rotation_angle_deg: float, re
                  watertight: bool = True, interpolation_steps: int = 0, output_dir: str = "output/aligned",
                  contour_types=None, case_name: str = "None", align_wall_anomalous: bool = False):
     """multimodars/_processing.py:1106-1188 -> (geometry, spacing_mm, total_rotation_deg)."""
-    _unsupported(write, align_wall_anomalous)
+    _unsupported(write)
     geoms, rebuild = _unpack(geometry)
     pk = _ClPack(geoms)
     r = _v3(ref_point)
@@ -263,6 +275,7 @@ def align_manual(centerline: Centerline, geometry, rotation_angle_deg: float, re
     N.check(N.lib().mm_align_manual(N._ptr(centerline.points), len(centerline), pk.ptr, len(geoms),
                                     float(rotation_angle_deg), N._ptr(r), 0, C.byref(sp), C.byref(rot)),
             "align_manual")
+    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:147-149
     return rebuild(), sp.value, rot.value * (180.0 / math.pi)
 
 
@@ -273,7 +286,7 @@ def align_combined(centerline: Centerline, geometry, main_ref_pt, counterclockwi
                    align_wall_anomalous: bool = False, engine: Optional[N.Engine] = None):
     """multimodars/_processing.py:1191-1300 -> (geometry, spacing_mm, total_rotation_deg).  The
     Hausdorff refinement grid ((2*index_range+1) x angles) is scored on the GPU."""
-    _unsupported(write, align_wall_anomalous)
+    _unsupported(write)
     if engine is None:
         from .api import default_engine
         engine = default_engine()
@@ -287,6 +300,7 @@ def align_combined(centerline: Centerline, geometry, main_ref_pt, counterclockwi
                                       pts.shape[0], math.radians(angle_step_deg), math.radians(angle_range_deg),
                                       int(index_range), 0, C.byref(sp), C.byref(rot), C.byref(ri), C.byref(ne)),
             "align_combined")
+    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:266-268
     out = rebuild()
     first = out.geom_a if hasattr(out, "geom_a") else out
     first.meta["refined_cl_ref_idx"] = int(ri.value)

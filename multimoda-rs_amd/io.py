@@ -23,7 +23,7 @@ from .geometry import FlatGeometry, contour_centroid
 
 RECORD_FILE_NAME = "combined_sorted_manual.csv"          # input.rs:12
 RECORD_FILE_NAME_ALT = "diastolic_systolic_records.csv"  # input.rs:13
-EXTRA_KINDS = ("eem", "calcification", "sidebranch")
+EXTRA_KINDS = ("eem", "calcification", "sidebranch", "wall")   # "wall" is synthesised (processing/wall.rs), never read
 
 
 @dataclass

@@ -17,7 +17,7 @@ def to_oracle(orc, g):
                                  else np.ones(g.n_frames, dtype=np.uint8))
     counts = g.meta.get("extra_counts") if hasattr(g, "meta") else None
     if g.extra_off is not None and counts:
-        kinds = [k for k in ("eem", "calcification", "sidebranch") if k in counts]
+        kinds = [k for k in ("eem", "calcification", "sidebranch", "wall") if k in counts]
         per = np.stack([np.asarray(counts[k], dtype=np.int64) for k in kinds], axis=1)
         ko = np.zeros(per.size + 1, dtype=np.int64)
         ko[1:] = np.cumsum(per.reshape(-1))

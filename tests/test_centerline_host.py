@@ -170,7 +170,5 @@ def test_align_errors(built, mm, case):
         mm.align_three_point(case["centerline"], g, case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"])
     with pytest.raises(NotImplementedError):
         mm.align_manual(case["centerline"], case["geometry"], 10.0, (0, 0, 0), write=True)
-    with pytest.raises(NotImplementedError):
-        mm.align_manual(case["centerline"], case["geometry"], 10.0, (0, 0, 0), align_wall_anomalous=True)
     with pytest.raises(TypeError):
         mm.align_manual(case["centerline"], object(), 10.0, (0, 0, 0))

@@ -171,5 +171,59 @@ def test_entry_point_errors(engine, mm):
         mm.from_file_single(rest, sample_size=0, engine=engine)
     with pytest.raises(NotImplementedError, match="write_obj"):
         mm.from_file_single(rest, write_obj=True, engine=engine)
-    with pytest.raises(NotImplementedError, match="postprocessing"):
-        mm.from_file_singlepair(rest, postprocessing=True, engine=engine)
+    with pytest.raises(NotImplementedError, match="write_obj"):
+        mm.from_file_singlepair(rest, write_obj=True, engine=engine)
+
+
+def _array_input(mm, n_frames=12, n_points=120, drop=(), with_eem=False, thickness=None, seed=1):
+    """(N,4) [frame, x, y, z] arrays of a synthetic pullback, optionally with missing frames, an EEM
+    contour (the lumen scaled about its centre) and per-frame wall thickness records."""
+    g = mm.synthetic_pullback(n_frames, n_points, pullback_id=0, seed=seed, torsion_sigma_deg=1.0)
+    keep = [i for i in range(n_frames) if i not in drop]
+    rows, eem = [], []
+    for i in keep:
+        L = g.frame_lumen(i)
+        rows.append(np.column_stack([np.full(n_points, i + 1), L]))
+        if with_eem:
+            c = L.mean(axis=0)
+            eem.append(np.column_stack([np.full(n_points, i + 1), c + (L - c) * [1.4, 1.4, 1.0]]))
+    rec = None
+    if thickness is not None:
+        rec = [[i + 1, "D", thickness, None] for i in keep]
+    # reference point on the LAST input frame: the builder puts the proximal end (highest frame number) at
+    # index 0, so the reference frame index stays valid when fill_holes inserts frames behind it (the
+    # reference computes ref_idx before the chain and does not update it, align_within.rs:42-44, 139)
+    last = g.frame_lumen(n_frames - 1)
+    ref = [n_frames] + list(last[np.argmax(last[:, 0])])
+    return mm.numpy_to_inputdata(np.concatenate(rows), ref, True, record=rec,
+                                 eem_arr=np.concatenate(eem) if with_eem else None, label="synthetic")
+
+
+@pytest.mark.gpu
+def test_hole_filling_eem_and_walls_through_the_entry_point(engine, mm):
+    """align_within.rs:136-160 through from_array_single: a pullback with a missing frame gets the averaged
+    frame back (fill_holes), EEM and wall contours are smoothed along with the lumen, and the wall comes
+    from the EEM (non-anomalous) offset by 1 mm (wall.rs:7-47)."""
+    full, logs_full = mm.from_array_single(_array_input(mm, with_eem=True), step_rotation_deg=1.0,
+                                           range_rotation_deg=20.0, engine=engine)
+    holed, logs = mm.from_array_single(_array_input(mm, drop=(5,), with_eem=True), step_rotation_deg=1.0,
+                                       range_rotation_deg=20.0, engine=engine)
+    assert full.n_frames == 12 and holed.n_frames == 12 and len(logs) == 10          # one chain step fewer, one frame back
+    assert holed.ids.tolist() == list(range(12)) and holed.lumen_ids.tolist() == list(range(12))
+    dz = np.diff(holed.centroids[:, 2])
+    assert np.allclose(dz, dz[0], atol=1e-9)                                          # the z gap is closed
+    assert holed.meta["anomalous"] is False
+    cnt = holed.meta["extra_counts"]
+    assert cnt["eem"].tolist() == [120] * 12 and cnt["wall"].tolist() == [120] * 12
+    from multimoda_rs_amd import frames as FR
+    fr = FR.to_frames(holed)
+    for f in fr:
+        d_wall = np.linalg.norm(f.extras["wall"].points[:, :2] - f.extras["wall"].points[:, :2].mean(axis=0), axis=1)
+        d_eem = np.linalg.norm(f.extras["eem"].points[:, :2] - f.extras["eem"].points[:, :2].mean(axis=0), axis=1)
+        assert 0.5 < (d_wall - d_eem).mean() < 1.1                                    # EEM + ~1 mm (smoothed)
+        assert (f.extras["wall"].points[:, 2] == f.centroid[2]).all()
+    # an anomalous (thickness-bearing) pullback builds the aortic wall from the lumen and flags the aortic half
+    an, _ = mm.from_array_single(_array_input(mm, thickness=0.9), step_rotation_deg=1.0, range_rotation_deg=20.0,
+                                 engine=engine)
+    assert an.meta["anomalous"] is True and an.meta["lumen_aortic"].sum() == 12 * 60
+    assert an.meta["extra_counts"]["wall"].tolist() == [120] * 12 and an.meta["aortic_thickness"] == [0.9] * 12

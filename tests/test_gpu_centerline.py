@@ -106,11 +106,22 @@ def test_from_file_pair_then_align_manual(engine, oracle, ocl, mm):
     oracle's placement of the same pair."""
     import os
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ivus_rest")
-    pair, _ = mm.from_file_singlepair(gold, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
-    for g in (pair.geom_a, pair.geom_b):
+    raw, _ = mm.from_file_singlepair(gold, step_rotation_deg=1.0, range_rotation_deg=30.0, postprocessing=False,
+                                     engine=engine)
+    for g in (raw.geom_a, raw.geom_b):
         assert g.lumen_centroids is not None and g.has_lumen_centroid.all()
         for i in range(g.n_frames):
             assert tuple(g.lumen_centroids[i]) == mm.contour_centroid(g.frame_lumen(i))
+    # the reference's defaults (postprocessing=True): both geometries trimmed to the common frame range
+    # around the reference frame and resampled to one z spacing; walls present
+    pair, _ = mm.from_file_singlepair(gold, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
+    assert pair.geom_a.n_frames == pair.geom_b.n_frames <= min(raw.geom_a.n_frames, raw.geom_b.n_frames)
+    assert np.allclose(pair.geom_a.centroids[:, 2], pair.geom_b.centroids[:, 2], atol=1e-9)
+    assert np.allclose(np.diff(pair.geom_a.centroids[:, 2]), np.diff(pair.geom_a.centroids[:, 2])[0], atol=1e-9)
+    for g in (pair.geom_a, pair.geom_b):
+        assert g.ids.tolist() == list(range(g.n_frames)) and g.has_ref.sum() == 1
+        assert g.meta["extra_counts"]["wall"].tolist() == [int(g.lumen_off[1])] * g.n_frames
+        assert np.allclose(g.lumen_centroids, [mm.contour_centroid(g.frame_lumen(i)) for i in range(g.n_frames)], atol=1e-9)
     nocen, _ = mm.from_file_single(gold, smooth=False, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
     assert nocen.lumen_centroids is None                         # stale in the reference, not tracked here
     a = pair.geom_a
