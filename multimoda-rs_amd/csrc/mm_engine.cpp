@@ -237,7 +237,6 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // 144.6/138.2/122.3 TFLOP/s) -- many short workgroups keep the co-resident ones out of phase
     // (rotation / epilogue of one overlaps the micro-tile loop of the others) and balance the tail
     int apb = (int)std::min<int64_t>(8, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
-    if (const char* env = std::getenv("MM_APB")) apb = std::max(1, std::atoi(env));   // tuning knob
     host_work.clear();
     for (int p = 0; p < P; ++p) {
         const PairDesc& d = host_pairs[p];

@@ -772,8 +772,8 @@ static hipError_t launch_fast_r(const BatchDev& b, int max_nbp, hipStream_t s)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int grid = b.n_work;
-    if (const char* env = std::getenv("MM_GRID")) grid = std::min(grid, std::max(1, std::atoi(env)));   // tuning knob
+    // one workgroup per work item: a persistent grid (grid-stride over the items) measured slower
+    const int grid = b.n_work;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y,
                        b.cos32, b.sin32, b.sq32);
     return hipGetLastError();

@@ -83,7 +83,10 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(_LIB_PATH)
+    path = _LIB_PATH
+    if os.environ.get("MM_ORACLE_ASAN"):    # sanitizer build of the checker (make libmm_oracle_asan.so; LD_PRELOAD libasan)
+        path = os.path.join(_HERE, "libmm_oracle_asan.so")
+    L = C.CDLL(path)
     P = C.c_void_p
     L.orc_hausdorff_xy.restype = C.c_double
     L.orc_hausdorff_xy.argtypes = [P, P, C.c_size_t, P, P, C.c_size_t]
