@@ -130,6 +130,17 @@ static __device__ __forceinline__ T wave_max(T v)
 //   R      reference points (rows) per lane held in registers
 //   NLI    row lanes per workgroup (threads = 16 * NLI)
 //   EXACT  reference operation order, absolute coordinates, angle==0 shortcut
+// XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (observed, not contractual:
+// b and b+8 share an XCD and its private 4 MiB L2), while the work list is pair-major (all candidate
+// blocks of a pair are adjacent).  With the identity mapping every pair's point sets and tables are
+// pulled into all eight L2s; this bijective remap hands each XCD one contiguous eighth of the list, so
+// a pair is fetched from HBM by one XCD (or two, at a boundary).  Speed/traffic only, never correctness.
+static __device__ __forceinline__ int xcd_work_index(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 // Work items come either from a host-built table (n_work_dev == nullptr) or from the
 // device shortlist queue (count read from *n_work_dev); workgroups stride over them, so
 // every wave terminates whatever the queue length is.
@@ -157,7 +168,9 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
     const int li = tid >> 4;
     const int n_work = n_work_dev ? *n_work_dev : n_work_host;
 
-    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    // one workgroup per item (host-built table): XCD-aware order; otherwise stride over the queue
+    for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
+         wi += gridDim.x) {
         const WorkItem w = work[wi];
         const PairDesc pd = pairs[w.pair];
         const int na = pd.n_ref, nb = pd.n_tgt;
@@ -366,7 +379,8 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lj = tid & 15, li = tid >> 4;
 
-    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
+         wi += gridDim.x) {
         const WorkItem w = work[wi];
         const PairDesc pd = pairs[w.pair];
         const int na = pd.n_ref, nb = pd.n_tgt;
