@@ -123,6 +123,20 @@ def cpu_baseline(cfg, geoms, threads, budget_s=10.0):
                       f"({n_angles} candidates each, N={ss + 20} pts/set), {t_used:.1f} s"}
 
 
+def dominant_launch(ms, pair_evals):
+    """The launches that carry the work (>= half of the largest launch's pair-distances: the one
+    within-stage launch of every step): their count, mean device time and algorithmic rate -- the
+    figures to hold against the per-dispatch rows of the committed rocprofv3 kernel trace."""
+    if len(ms) == 0:
+        return None
+    big = pair_evals >= 0.5 * pair_evals.max()
+    t = float(ms[big].mean())
+    pe = float(pair_evals[big].mean())
+    tf = pe * FLOPS_PER_PAIR_EVAL / (t * 1e-3) * 1e-12
+    return {"launches": int(big.sum()), "avg_ms": t, "pair_distance_evals": pe, "tflops": tf,
+            "frac": tf / FP32_VECTOR_PEAK_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +259,7 @@ def main():
     dt = time.perf_counter() - t0
     if os.environ.get("MM_TRACE"):
         print(f"[bench trace] final barrier {1e3 * (time.perf_counter() - tb):.3f} ms, total {1e3 * dt:.3f} ms", file=sys.stderr)
+    launch_ms, launch_pe = eng.profile_launches()
     prof = eng.profile_read()
     eng.profile(False)
 
@@ -289,6 +304,7 @@ def main():
                 "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33>",
                            "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
+                "dominant_launch": dominant_launch(launch_ms, launch_pe),
                 "note": "point-set min/max metric: bounded by fp32 VALU issue (SURVEY 8(d)), not HBM/MFMA; "
                         "achieved = pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every "
                         "launch); traffic = HBM bytes per launch of the big launch (FETCH_SIZE+WRITE_SIZE, committed "

@@ -80,6 +80,10 @@ void* mm_engine_stream(mm_engine* e);
 int  mm_engine_profile(mm_engine* e, int enable);
 int  mm_engine_profile_read(mm_engine* e, int64_t* n_launches, double* ms_total,
                             double* pair_evals, int64_t* candidates);
+/* The same measurements per launch (call before mm_engine_profile_read, which resets them):
+ * device time in ms and pair-distance evaluations of up to cap launches, in launch order. */
+int  mm_engine_profile_launches(mm_engine* e, int64_t cap, float* ms, double* pair_evals,
+                                int64_t* n_launches);
 
 /* ---- the metric: hausdorff_distance (process_utils.rs:78-82) ------------------------ */
 /* f64-exact on the device; empty set on either side -> 0.0 (process_utils.rs:86-88). */

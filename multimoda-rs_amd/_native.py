@@ -24,7 +24,7 @@ MM_SEARCH_SKIP_ZERO = 1
 EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
     "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream",
-    "mm_engine_profile", "mm_engine_profile_read",
+    "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches",
     "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
     "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_create_indexed", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
@@ -137,6 +137,8 @@ def lib():
     L.mm_engine_profile.argtypes = [P, I]
     L.mm_engine_profile_read.restype = I
     L.mm_engine_profile_read.argtypes = [P, C.POINTER(I64), C.POINTER(D), C.POINTER(D), C.POINTER(I64)]
+    L.mm_engine_profile_launches.restype = I
+    L.mm_engine_profile_launches.argtypes = [P, I64, P, P, C.POINTER(I64)]
     L.mm_hausdorff_2d.restype = I
     L.mm_hausdorff_2d.argtypes = [P, P, P, I, P, P, I, C.POINTER(D)]
     L.mm_hausdorff_batch.restype = I
@@ -402,6 +404,16 @@ class Engine:
     def profile(self, enable: bool = True):
         """hipEvent timing around every launch of the scoring kernel (mm_engine_profile)."""
         check(lib().mm_engine_profile(self._h, int(enable)), "mm_engine_profile")
+
+    def profile_launches(self, cap: int = 4096):
+        """Per-launch (ms, pair-distance evaluations) of the scoring kernel since profiling was enabled;
+        call before profile_read(), which resets them."""
+        ms = np.zeros(cap, dtype=np.float32)
+        pe = np.zeros(cap, dtype=np.float64)
+        n = C.c_int64(0)
+        check(lib().mm_engine_profile_launches(self._h, cap, _ptr(ms), _ptr(pe), C.byref(n)), "mm_engine_profile_launches")
+        k = min(int(n.value), cap)
+        return ms[:k].astype(np.float64), pe[:k]
 
     def profile_read(self):
         n, ms, pe, ca = C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_int64(0)

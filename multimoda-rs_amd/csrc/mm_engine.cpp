@@ -84,6 +84,7 @@ int Engine::profile_end(double pair_evals, int64_t candidates)
     ++launches;
     prof_pair_evals += pair_evals;
     prof_candidates += candidates;
+    launch_pair_evals.push_back(pair_evals);
     return MM_OK;
 }
 
@@ -597,7 +598,7 @@ int mm_engine_profile(mm_engine* h, int enable)
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     MM_HIP(hipStreamSynchronize(e->stream));
     e->profile = enable != 0;
-    e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0;
+    e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0; e->launch_pair_evals.clear();
     // hipEventCreate is slow (~0.5 ms): build the pool now, outside any timed region
     while (e->profile && e->events.size() < 2 * 2048) {
         hipEvent_t ev;
@@ -623,7 +624,22 @@ int mm_engine_profile_read(mm_engine* h, int64_t* n_launches, double* ms_total, 
     if (ms_total) *ms_total = ms;
     if (pair_evals) *pair_evals = e->prof_pair_evals;
     if (candidates) *candidates = e->prof_candidates;
-    e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0;
+    e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0; e->launch_pair_evals.clear();
+    return MM_OK;
+}
+
+int mm_engine_profile_launches(mm_engine* h, int64_t cap, float* ms, double* pair_evals, int64_t* n_launches)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    MM_HIP(hipStreamSynchronize(e->stream));
+    for (size_t k = 0; k < e->launches && (int64_t)k < cap; ++k) {
+        float t = 0.f;
+        MM_HIP(hipEventElapsedTime(&t, e->events[2 * k], e->events[2 * k + 1]));
+        if (ms) ms[k] = t;
+        if (pair_evals) pair_evals[k] = e->launch_pair_evals[k];
+    }
+    if (n_launches) *n_launches = (int64_t)e->launches;
     return MM_OK;
 }
 

@@ -33,6 +33,7 @@ struct Engine {
     std::vector<hipEvent_t> events;   // pairs: [2k] before, [2k+1] after launch k
     size_t launches = 0;
     double prof_pair_evals = 0.0;
+    std::vector<double> launch_pair_evals;   // per launch, same indexing as the event pairs
     int64_t prof_candidates = 0;
     int profile_begin();
     int profile_end(double pair_evals, int64_t candidates);
