@@ -18,6 +18,7 @@
 #include "../../include/mm_centerline.h"
 #include "mm_engine.h"
 #include "mm_pool.h"
+#include "mm_trace.h"
 
 namespace mm {
 namespace {
@@ -397,6 +398,7 @@ int refine(Engine* e, mm_cl_geometry** geoms, const mm_clpoint* cl, int64_t ncl,
     if (F <= 0) return set_error(MM_ERR_NO_FRAMES, "refine_alignment_hausdorff: geometry has no frames");
     if (!(ang_step > 0.0)) return set_error(MM_ERR_INVALID, "refine_alignment_hausdorff: angle_step must be > 0");
     const int64_t m = g->lumen_off[1] - g->lumen_off[0];                                       // :412
+    TraceTimer tt_ref("refine: total");
 
     // candidate list in the reference's evaluation order; only the primary geometry's lumen
     // enters the cost (:411-431), so only that is rebuilt per candidate
@@ -434,43 +436,75 @@ int refine(Engine* e, mm_cl_geometry** geoms, const mm_clpoint* cl, int64_t ncl,
     if (cands.empty()) return MM_OK;
     if (flat_total > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "refine grid exceeds 2^30 points");
 
-    // rebuild the placed frames of every candidate (host, candidates in parallel)
-    std::vector<double> flat_x((size_t)flat_total), flat_y((size_t)flat_total);
-    int64_t max_len = 0;
-    for (int64_t f = 0; f < F; ++f) max_len = std::max(max_len, g->lumen_off[f + 1] - g->lumen_off[f]);
-    parallel_for((int)cands.size(), [&](int ci) {
-        std::vector<double> buf((size_t)max_len * 3);
-        SortScratch sc;
-        const Candidate& cd = cands[(size_t)ci];
-        const Group& grp = groups[(size_t)cd.group];
-        double s = 0.0, c = 1.0;
-        if (cd.angle != 0.0) sin_cos(cd.angle, s, c);
-        int64_t w = cd.off;
-        for (int64_t f = 0; f < F; ++f) {
+    // Rebuild the placed frames of every candidate on the host.  rotate_by_best_rotation (:395,
+    // geometry.rs:241-250: rotate every frame about its centroid, re-sort its points) depends on the
+    // angle only, not on the index shift, so it is done once per (angle, frame) and shared by the
+    // 2R+1 index shifts; the placement (align_frame + apply, :394-398) and the downsampling are per
+    // candidate.  Both phases run over the worker pool.
+    double* flat_x = e->scratch_f64(0, (size_t)flat_total);
+    double* flat_y = e->scratch_f64(1, (size_t)flat_total);
+    std::vector<double> angles;
+    for (double a = initial_rotation - ang_range; a <= initial_rotation + ang_range; a += ang_step) angles.push_back(a);
+    const int64_t NL = g->lumen_off[F];
+    const size_t n_ang = angles.size();
+    double* rotated = e->scratch_f64(2, n_ang * (size_t)NL * 3);
+    {
+        TraceTimer tt("refine: rotate + sort");
+        parallel_for((int)(n_ang * (size_t)F), [&](int job) {
+            const size_t ai = (size_t)job / (size_t)F;
+            const int64_t f = (int64_t)((size_t)job % (size_t)F);
             const int64_t len = g->lumen_off[f + 1] - g->lumen_off[f];
-            double* p = buf.data();
+            double* p = rotated + (ai * (size_t)NL + (size_t)g->lumen_off[f]) * 3;
             std::memcpy(p, g->lumen + 3 * g->lumen_off[f], (size_t)len * 24);
-            if (cd.angle != 0.0) {                                                            // rotate_by_best_rotation (:395), geometry.rs:241-250
+            const double ang = angles[ai];
+            if (ang != 0.0) {                                                                 // geometry.rs:242-244
+                double s, c;
+                sin_cos(ang, s, c);
                 rotate_xy_span(p, 0, len, s, c, g->centroid[3 * f], g->centroid[3 * f + 1]);
+                SortScratch sc;
                 sort_contour(p, len, sc);
             }
-            // cl_segment = points[cur .. cur+F), ref_pt = its first point (:381-392): frame f -> cl[cur + f]
-            const double* lc;
-            const bool hc = lumen_centroid_of(prim, (int32_t)f, lc);
-            const FrameTf tf = align_frame(p, len, hc, lc, cl[cd.cl_idx + f]);
-            auto emit = [&](int64_t src) {
-                double q[3] = {p[3 * src], p[3 * src + 1], p[3 * src + 2]};
-                tf.apply(q);
-                flat_x[(size_t)w] = q[0]; flat_y[(size_t)w] = q[1]; ++w;
-            };
-            if (grp.n_down < m && len > grp.n_down) {                                         // downsample_contour_points
-                const double stepf = (double)len / (double)grp.n_down;
-                for (int64_t i = 0; i < grp.n_down; ++i) emit((int64_t)((double)i * stepf));
-            } else {
-                for (int64_t i = 0; i < len; ++i) emit(i);
+        });
+    }
+    {
+        TraceTimer tt("refine: place + sample");
+        constexpr int64_t kFrames = 8;   // frames per job
+        const int64_t fchunks = (F + kFrames - 1) / kFrames;
+        // write offset of frame f inside a candidate's flat set
+        std::vector<std::vector<int64_t>> frame_off(groups.size(), std::vector<int64_t>((size_t)F + 1, 0));
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            for (int64_t f = 0; f < F; ++f) {
+                const int64_t len = g->lumen_off[f + 1] - g->lumen_off[f];
+                frame_off[gi][(size_t)f + 1] = frame_off[gi][(size_t)f] + ((groups[gi].n_down < m) ? std::min(len, groups[gi].n_down) : len);
             }
-        }
-    });
+        parallel_for((int)(cands.size() * (size_t)fchunks), [&](int job) {
+            const size_t ci = (size_t)job / (size_t)fchunks;
+            const int64_t f0 = (int64_t)((size_t)job % (size_t)fchunks) * kFrames, f1 = std::min(F, f0 + kFrames);
+            const Candidate& cd = cands[ci];
+            const Group& grp = groups[(size_t)cd.group];
+            const size_t ai = ci % n_ang;   // candidates are (group-major, angle-minor)
+            for (int64_t f = f0; f < f1; ++f) {
+                const int64_t len = g->lumen_off[f + 1] - g->lumen_off[f];
+                const double* p = rotated + (ai * (size_t)NL + (size_t)g->lumen_off[f]) * 3;
+                // cl_segment = points[cur .. cur+F), ref_pt = its first point (:381-392): frame f -> cl[cur + f]
+                const double* lc;
+                const bool hc = lumen_centroid_of(prim, (int32_t)f, lc);
+                const FrameTf tf = align_frame(p, len, hc, lc, cl[cd.cl_idx + f]);
+                int64_t w = cd.off + frame_off[(size_t)cd.group][(size_t)f];
+                auto emit = [&](int64_t src) {
+                    double q[3] = {p[3 * src], p[3 * src + 1], p[3 * src + 2]};
+                    tf.apply(q);
+                    flat_x[(size_t)w] = q[0]; flat_y[(size_t)w] = q[1]; ++w;
+                };
+                if (grp.n_down < m && len > grp.n_down) {                                     // downsample_contour_points
+                    const double stepf = (double)len / (double)grp.n_down;
+                    for (int64_t i = 0; i < grp.n_down; ++i) emit((int64_t)((double)i * stepf));
+                } else {
+                    for (int64_t i = 0; i < len; ++i) emit(i);
+                }
+            }
+        });
+    }
 
     // one device batch: hausdorff_distance(filtered points of the group, placed frames), x,y only (:431)
     std::vector<SetRef> sets;
@@ -479,10 +513,14 @@ int refine(Engine* e, mm_cl_geometry** geoms, const mm_clpoint* cl, int64_t ncl,
     for (const Group& grp : groups) sets.push_back(SetRef{grp.fx.data(), grp.fy.data(), (int32_t)grp.fx.size(), 0.0, 0.0});
     for (const Candidate& cd : cands) {
         pr.push_back({cd.group, (int32_t)sets.size()});
-        sets.push_back(SetRef{flat_x.data() + cd.off, flat_y.data() + cd.off, (int32_t)cd.n, 0.0, 0.0});
+        sets.push_back(SetRef{flat_x + cd.off, flat_y + cd.off, (int32_t)cd.n, 0.0, 0.0});
     }
     std::vector<double> cost(cands.size());
-    int rc = hausdorff_sets(e, sets, pr, cost.data());
+    int rc;
+    {
+        TraceTimer tt("refine: device batch");
+        rc = hausdorff_sets(e, sets, pr, cost.data());
+    }
     if (rc) return rc;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         if (all_costs && (int64_t)ci < cap) all_costs[ci] = cost[ci];
@@ -691,12 +729,16 @@ int mm_align_combined(mm_engine* h, const mm_clpoint* cl, int64_t ncl, mm_cl_geo
     if (!p_main || !p_ccw || !p_cw || n_points < 0 || (n_points > 0 && !points_xyz) || refine_index_range < 0)
         return set_error(MM_ERR_INVALID, "mm_align_combined: bad arguments");
     { const hipError_t he = hipSetDevice(e->device); if (he != hipSuccess) return hip_error(he, "hipSetDevice"); }
+    TraceTimer tt_all("combined: total (C ABI)");
     std::vector<mm_clpoint> rcl;
     double sp = 0.0;
     if ((rc = preprocess(cl, ncl, geoms[0]->g, rcl, sp))) return rc;                           // align.rs:191-195
     int64_t initial_idx = 0; double initial_rotation = 0.0;
-    if ((rc = three_point_initial(rcl, geoms, ref_point_index, p_main, p_ccw, p_cw, angle_step, initial_idx,
-                                  initial_rotation))) return rc;                               // :197-217
+    {
+        TraceTimer tt("combined: three-point sweep");
+        if ((rc = three_point_initial(rcl, geoms, ref_point_index, p_main, p_ccw, p_cw, angle_step, initial_idx,
+                                      initial_rotation))) return rc;                           // :197-217
+    }
 
     // `aligned` = the primary geometry rotated by the initial rotation and placed (:219-223); only its
     // lumen, frame centroids and lumen centroids are read by the refinement
@@ -715,15 +757,19 @@ int mm_align_combined(mm_engine* h, const mm_clpoint* cl, int64_t ncl, mm_cl_geo
         a_lc.assign(geoms[0]->lumen_centroid, geoms[0]->lumen_centroid + 3 * F);
         acg.has_lumen_centroid = a_hlc.data(); acg.lumen_centroid = a_lc.data();
     }
-    rotate_geometry(&acg, initial_rotation);
     std::vector<FrameTf> tfs;
-    frame_transforms(&acg, rcl.data(), (int64_t)rcl.size(), p_main, tfs);
-    apply_transforms(&acg, tfs);
+    {
+        TraceTimer tt("combined: initial placement");
+        rotate_geometry(&acg, initial_rotation);
+        frame_transforms(&acg, rcl.data(), (int64_t)rcl.size(), p_main, tfs);
+        apply_transforms(&acg, tfs);
+    }
 
     mm_cl_geometry* ap[1] = {&acg};
     double delta = 0.0, mh = 0.0; int64_t ridx = initial_idx;
     if ((rc = refine(e, ap, rcl.data(), (int64_t)rcl.size(), initial_idx, 0.0, points_xyz, n_points, refine_angle_range,
                      angle_step, refine_index_range, delta, ridx, mh, nullptr, 0, n_evals))) return rc;  // :228-237
+    TraceTimer tt_final("combined: final placement");
     const double total = initial_rotation + delta;                                             // :239
     const double ref_pt[3] = {rcl[(size_t)ridx].x, rcl[(size_t)ridx].y, rcl[(size_t)ridx].z};  // :248-258
     for (int g = 0; g < n_geoms; ++g) rotate_geometry(geoms[g], total);                        // :260-264

@@ -28,6 +28,10 @@ struct Engine {
     Buf host_pts, host_lvl;   // pinned staging: point pool / level (+ results)
     Buf dev_pts, dev_lvl;     // device buffers of transient plans
     int ensure(Buf& b, size_t bytes, bool host);
+    // grow-only pageable scratch for host-side set construction (refinement grid): a fresh 50 MB
+    // std::vector per call costs ~10 ms of zero-fill and page faults
+    std::vector<double> scratch[3];
+    double* scratch_f64(int slot, size_t n) { if (scratch[slot].size() < n) scratch[slot].resize(n); return scratch[slot].data(); }
     // profiling of the scoring kernel (mm_engine_profile*)
     bool profile = false;
     std::vector<hipEvent_t> events;   // pairs: [2k] before, [2k+1] after launch k

@@ -13,6 +13,7 @@
 
 #include "mm_engine.h"
 #include "mm_pool.h"
+#include "mm_trace.h"
 
 #include <chrono>
 #include <thread>
@@ -20,18 +21,6 @@
 #include <cstdlib>
 
 namespace mm {
-
-// MM_TRACE=1: phase timings of the host orchestration on stderr (diagnostics only)
-static bool trace_on() { static const bool on = std::getenv("MM_TRACE") != nullptr; return on; }
-struct TraceTimer {
-    const char* what; std::chrono::steady_clock::time_point t0;
-    explicit TraceTimer(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
-    ~TraceTimer() {
-        if (trace_on())
-            std::fprintf(stderr, "[mm trace] %-28s %9.3f ms\n", what,
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    }
-};
 
 // cos and sin of the same angle: the reference computes both in one function, which LLVM on
 // x86_64-linux-gnu lowers to one glibc `sincos` call; sincos is not bit-identical to separate
