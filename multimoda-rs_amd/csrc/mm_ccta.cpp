@@ -29,11 +29,15 @@ inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
         if (e__ != hipSuccess) return hip_error(e__, #call);      \
     } while (0)
 
-// out[k] <- per-query minima of pair k (sets[q] against sets[p]); one upload, one launch, one download
-int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::array<int32_t, 2>>& pr,
-             std::vector<std::vector<double>>& out)
+// Per-query minima of every pair (sets[q] against sets[p]); one upload, one launch, one download.
+// view[k] = {pointer, count}: pair k's minima inside the engine's pinned staging buffer (valid until
+// the next call on this engine); pointer == nullptr means "all +inf" (an empty point set) or no queries.
+struct MinView { const double* p; int64_t n; };
+
+int nn_batch_view(Engine* e, const std::vector<Set3>& sets, const std::vector<std::array<int32_t, 2>>& pr,
+                  std::vector<MinView>& view)
 {
-    out.assign(pr.size(), {});
+    view.assign(pr.size(), MinView{nullptr, 0});
     std::vector<int64_t> soff(sets.size() + 1, 0);
     for (size_t s = 0; s < sets.size(); ++s) soff[s + 1] = soff[s] + sets[s].n;
     const int64_t npts = soff.back();
@@ -47,7 +51,7 @@ int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::ar
         if (q < 0 || p < 0 || (size_t)q >= sets.size() || (size_t)p >= sets.size())
             return set_error(MM_ERR_INVALID, "nn batch: set index out of range");
         const int64_t nq = sets[q].n, np = sets[p].n;
-        out[k].assign((size_t)nq, INFINITY);   // fold(INFINITY, min) over an empty set
+        view[k].n = nq;                       // fold(INFINITY, min) over an empty set: all +inf
         if (nq == 0 || np == 0) continue;
         const int32_t pi = (int32_t)hp.size();
         hp.push_back(NnPairH{(int32_t)soff[q], (int32_t)nq, (int32_t)soff[p], (int32_t)np, (int32_t)nout, 0});
@@ -68,11 +72,11 @@ int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::ar
     if ((rc = e->ensure(e->dev_pts, total, false))) return rc;
     unsigned char* h = (unsigned char*)e->host_pts.p;
     double *hx = (double*)(h + o_x), *hy = (double*)(h + o_y), *hz = (double*)(h + o_z);
-    for (size_t s = 0; s < sets.size(); ++s) {
-        const double* src = sets[s].xyz;
-        double *dx = hx + soff[s], *dy = hy + soff[s], *dz = hz + soff[s];
-        for (int64_t i = 0; i < sets[s].n; ++i) { dx[i] = src[3 * i]; dy[i] = src[3 * i + 1]; dz[i] = src[3 * i + 2]; }
-    }
+    parallel_for((int)sets.size(), [&](int si) {   // AoS triples -> SoA pool in the pinned staging buffer
+        const double* src = sets[(size_t)si].xyz;
+        double *dx = hx + soff[(size_t)si], *dy = hy + soff[(size_t)si], *dz = hz + soff[(size_t)si];
+        for (int64_t i = 0; i < sets[(size_t)si].n; ++i) { dx[i] = src[3 * i]; dy[i] = src[3 * i + 1]; dz[i] = src[3 * i + 2]; }
+    });
     std::memcpy(h + o_pairs, hp.data(), hp.size() * sizeof(NnPairH));
     std::memcpy(h + o_work, hw.data(), hw.size() * sizeof(NnWorkH));
     unsigned char* d = (unsigned char*)e->dev_pts.p;
@@ -84,21 +88,35 @@ int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::ar
     MM_TRY_HIP(hipMemcpyAsync(h, d + o_out, (size_t)nout * 8, hipMemcpyDeviceToHost, e->stream));
     MM_TRY_HIP(hipStreamSynchronize(e->stream));
     const double* res = (const double*)h;
-    for (size_t i = 0; i < hp.size(); ++i)
-        std::memcpy(out[(size_t)owner[i]].data(), res + hp[i].out_off, (size_t)hp[i].nq * 8);
+    for (size_t i = 0; i < hp.size(); ++i) view[(size_t)owner[i]].p = res + hp[i].out_off;
+    return MM_OK;
+}
+
+int nn_batch(Engine* e, const std::vector<Set3>& sets, const std::vector<std::array<int32_t, 2>>& pr,
+             std::vector<std::vector<double>>& out)
+{
+    std::vector<MinView> view;
+    int rc = nn_batch_view(e, sets, pr, view);
+    if (rc) return rc;
+    out.assign(pr.size(), {});
+    for (size_t k = 0; k < pr.size(); ++k) {
+        if (view[k].p) out[k].assign(view[k].p, view[k].p + view[k].n);
+        else out[k].assign((size_t)view[k].n, INFINITY);
+    }
     return MM_OK;
 }
 
 // symmetric_nn_distance (:188-216) from the two vectors of minima
-double symmetric_from_minima(const std::vector<double>& a_to_b, const std::vector<double>& b_to_a)
+double symmetric_from_minima(const MinView& a_to_b, const MinView& b_to_a)
 {
-    if (a_to_b.empty() || b_to_a.empty()) return INFINITY;                    // :189-191
+    if (a_to_b.n == 0 || b_to_a.n == 0) return INFINITY;                      // :189-191
+    if (!a_to_b.p || !b_to_a.p) return INFINITY;                              // unreachable: both sets non-empty
     double sa = 0.0;
-    for (double v : a_to_b) sa += v;                                          // :193-200
-    const double avg_a = sa / (double)a_to_b.size();                         // :202
+    for (int64_t i = 0; i < a_to_b.n; ++i) sa += a_to_b.p[i];                 // :193-200, index order
+    const double avg_a = sa / (double)a_to_b.n;                              // :202
     double sb = 0.0;
-    for (double v : b_to_a) sb += v;                                          // :204-211
-    const double avg_b = sb / (double)b_to_a.size();                         // :213
+    for (int64_t i = 0; i < b_to_a.n; ++i) sb += b_to_a.p[i];                 // :204-211
+    const double avg_b = sb / (double)b_to_a.n;                              // :213
     return std::sqrt((avg_a + avg_b) / 2.0);                                  // :215
 }
 
@@ -153,22 +171,24 @@ int scaling_search(Engine* e, const double* pts, int64_t n, const double* ref, i
         if (ncl <= 0) return set_error(MM_ERR_INVALID, "diameter search: empty centerline");
         std::vector<double> unit; std::vector<uint8_t> has;
         radial_units(cl, ncl, pts, n, unit, has);
-        std::vector<double> moved((size_t)(steps + 1) * (size_t)n * 3);
+        double* moved = e->scratch_f64(0, (size_t)(steps + 1) * (size_t)n * 3);   // grow-only (a fresh 20 MB vector costs ms)
         std::vector<Set3> sets;
         std::vector<std::array<int32_t, 2>> pr;
         sets.push_back(Set3{ref, nr});
         for (int i = 0; i <= steps; ++i) {
-            const double x = start + (double)i * step;                        // :79
-            double* m = moved.data() + (size_t)i * (size_t)n * 3;
-            morph(pts, unit, has, n, x, m);                                   // :80
-            sets.push_back(Set3{m, n});
+            sets.push_back(Set3{moved + (size_t)i * (size_t)n * 3, n});
             pr.push_back({0, i + 1});                                         // reference -> moved
             pr.push_back({i + 1, 0});                                         // moved -> reference
         }
-        std::vector<std::vector<double>> mins;
-        int rc = nn_batch(e, sets, pr, mins);
+        parallel_for(steps + 1, [&](int i) {
+            const double x = start + (double)i * step;                        // :79
+            morph(pts, unit, has, n, x, moved + (size_t)i * (size_t)n * 3);   // :80
+        });
+        std::vector<MinView> mins;
+        int rc = nn_batch_view(e, sets, pr, mins);
         if (rc) return rc;
-        for (int i = 0; i <= steps; ++i) dist[(size_t)i] = symmetric_from_minima(mins[2 * (size_t)i], mins[2 * (size_t)i + 1]);  // :81
+        // the 82 sums are independent: one job each, every sum sequential in index order
+        parallel_for(steps + 1, [&](int i) { dist[(size_t)i] = symmetric_from_minima(mins[2 * (size_t)i], mins[2 * (size_t)i + 1]); });  // :81
     }
     for (int i = 0; i <= steps; ++i) {
         if (all_dist) all_dist[i] = dist[(size_t)i];
@@ -260,8 +280,8 @@ int mm_symmetric_nn_distance(mm_engine* h, const double* a, int64_t na, const do
     if (rc) return rc;
     if (!out || na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b)) return set_error(MM_ERR_INVALID, "mm_symmetric_nn_distance: bad arguments");
     if (na == 0 || nb == 0) { *out = INFINITY; return MM_OK; }
-    std::vector<std::vector<double>> mins;
-    if ((rc = nn_batch(e, {Set3{a, na}, Set3{b, nb}}, {{0, 1}, {1, 0}}, mins))) return rc;
+    std::vector<MinView> mins;
+    if ((rc = nn_batch_view(e, {Set3{a, na}, Set3{b, nb}}, {{0, 1}, {1, 0}}, mins))) return rc;
     *out = symmetric_from_minima(mins[0], mins[1]);
     return MM_OK;
 }
