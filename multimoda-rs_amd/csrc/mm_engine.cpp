@@ -12,6 +12,7 @@
 // cos/sin tables are computed on the host with glibc sin/cos (what Rust's f64::sin/cos
 // call on linux-gnu) and shared by pairs with identical candidate lists.
 #include "mm_engine.h"
+#include "mm_pool.h"
 
 #include <algorithm>
 #include <cmath>
@@ -466,10 +467,11 @@ static int hausdorff_large(Engine* e, const std::vector<SetRef>& sets, const std
     if ((rc = e->ensure(e->dev_pts, total, false))) return rc;
     unsigned char* h = (unsigned char*)e->host_pts.p;
     double *hx = (double*)(h + o_px), *hy = (double*)(h + o_py);
-    for (int32_t sidx : order) {
+    parallel_for((int)order.size(), [&](int k) {   // tens of MB for a refinement grid: spread the copy
+        const int32_t sidx = order[(size_t)k];
         std::memcpy(hx + set_at[sidx], sets[sidx].x, (size_t)sets[sidx].n * 8);
         std::memcpy(hy + set_at[sidx], sets[sidx].y, (size_t)sets[sidx].n * 8);
-    }
+    });
     std::memcpy(h + o_pairs, hp.data(), (size_t)P * sizeof(LargePairH));
     std::memcpy(h + o_work, hw.data(), hw.size() * sizeof(LargeWorkH));
     unsigned char* d = (unsigned char*)e->dev_pts.p;

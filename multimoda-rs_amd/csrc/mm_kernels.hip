@@ -69,8 +69,15 @@ static __device__ __forceinline__ float umin2f(float a, float b)
     return __uint_as_float(ua < ub ? ua : ub);
 }
 // squared distances are never NaN (finite inputs), so IEEE minNum == the reference's
-// `if d2 < min_sq { min_sq = d2 }` (process_utils.rs:108-110); one v_min_f64.
-static __device__ __forceinline__ double dmin2(double a, double b) { return __builtin_fmin(a, b); }
+// `if d2 < min_sq { min_sq = d2 }` (process_utils.rs:108-110); one v_min_f64.  Written as the
+// instruction itself: __builtin_fmin makes the compiler canonicalise (v_max_f64 x, x) every running
+// minimum that is carried around the loop, one extra fp64 operation per row and step (+14 %).
+static __device__ __forceinline__ double dmin2(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // All-reduce min over the 16 lanes of a DPP row (lanes sharing li).  DPP keeps this on
 // the VALU (v_min_u32_dpp) instead of a ds_bpermute round trip through the LDS crossbar:
@@ -632,6 +639,10 @@ k_large_init(unsigned long long* __restrict__ colmin, long long n_col, unsigned 
     if (i < n_pairs) rowmax[i] = 0ull;
 }
 
+// rows per lane: every 16-column step costs one same-address-conflicting LDS atomicMin per lane against
+// 7*R fp64 VALU operations, so more rows per lane amortise it (R = 8 -> 16: 6.4 -> see DESIGN 6a)
+static constexpr int kLargeR = 16;
+
 template <int R>
 __global__ void __launch_bounds__(256)
 k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restrict__ work,
@@ -718,13 +729,13 @@ hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pai
     hipLaunchKernelGGL(k_large_init, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s,
                        (unsigned long long*)colmin, n_col, (unsigned long long*)rowmax, n_pairs);
     if (n_work > 0)
-        hipLaunchKernelGGL(k_hausdorff_large<8>, dim3(n_work), dim3(256), 0, s, (const LargePair*)pairs,
+        hipLaunchKernelGGL(k_hausdorff_large<kLargeR>, dim3(n_work), dim3(256), 0, s, (const LargePair*)pairs,
                            (const LargeWork*)work, px, py, (unsigned long long*)colmin, (unsigned long long*)rowmax);
     hipLaunchKernelGGL(k_large_finish, dim3(n_pairs), dim3(256), 0, s, (const LargePair*)pairs,
                        (const unsigned long long*)colmin, (const unsigned long long*)rowmax, out);
     return hipGetLastError();
 }
-int large_rows_per_block() { return 16 * 8; }
+int large_rows_per_block() { return 16 * kLargeR; }
 
 // -------------------------------------------------------------------------------------
 // launch helpers
