@@ -34,11 +34,10 @@ def _pts3(a) -> np.ndarray:
 
 def contour_centroid(points: np.ndarray):
     """``Contour::compute_centroid`` (contour.rs:213-224): sequential sums / n."""
-    sx = sy = sz = 0.0
-    for p in points:
-        sx += float(p[0]); sy += float(p[1]); sz += float(p[2])
+    # np.add.accumulate is a strictly sequential running sum (np.sum is pairwise and rounds differently)
+    tot = np.add.accumulate(np.asarray(points, dtype=np.float64)[:, :3], axis=0)[-1]
     n = float(len(points))
-    return (sx / n, sy / n, sz / n)
+    return (float(tot[0]) / n, float(tot[1]) / n, float(tot[2]) / n)
 
 
 def catheter_points(z: float, image_center=(4.5, 4.5), radius=0.5, n_points=20) -> np.ndarray:

@@ -91,9 +91,40 @@ def _detect_delimiter(path: str) -> str:
     return "\t" if first.count("\t") > first.count(",") else ","
 
 
+def _read_numeric_table(path: str, delim: str) -> Optional[np.ndarray]:
+    """Fast path of read_contour_data for the regular case -- every line is exactly four plain numbers,
+    the first a non-negative integer.  Same values as the row-by-row reader (both parse with correctly
+    rounded strtod); anything irregular returns None and the robust reader decides row by row."""
+    with open(path, "r", newline="") as f:
+        text = f.read()
+    if not text or '"' in text:
+        return None
+    if "\r" in text:                                   # CRLF files: the csv crate drops the \r as well
+        if text.count("\r") != text.count("\r\n"):
+            return None
+        text = text.replace("\r\n", "\n")
+    lines = text.count("\n") + (0 if text.endswith("\n") else 1)
+    if text.count(delim) != 3 * lines:
+        return None
+    try:
+        flat = np.fromstring(text.replace("\n", delim), sep=delim, dtype=np.float64)
+    except (ValueError, DeprecationWarning):
+        return None
+    if flat.size != 4 * lines or not np.isfinite(flat).all():
+        return None
+    arr = flat.reshape(lines, 4)
+    fi = arr[:, 0]
+    if (fi < 0).any() or (fi != np.floor(fi)).any() or (fi > 4294967295.0).any():
+        return None
+    return arr
+
+
 def read_contour_data(path: str) -> np.ndarray:
     """input.rs:172-194: headerless ``frame,x,y,z`` rows; invalid rows are skipped."""
     delim = _detect_delimiter(path)
+    fast = _read_numeric_table(path, delim)
+    if fast is not None:
+        return fast
     rows = []
     with open(path, "r", newline="") as f:
         for rec in csv.reader(f, delimiter=delim):
@@ -166,6 +197,11 @@ def sort_contour_points(points: np.ndarray) -> np.ndarray:
     n = points.shape[0]
     if n == 0:
         return points
+    from . import _native as N
+    if os.path.exists(N.LIB_PATH):                     # same function behind the C ABI (host-only, glibc atan2)
+        out = np.ascontiguousarray(points, dtype=np.float64).copy()
+        N.check(N.lib().mm_sort_contour_points(N._ptr(out), n), "sort_contour_points")
+        return out
     sx = sy = 0.0
     for p in points:                                   # fold((0,0), |(sx,sy),p| (sx+p.x, sy+p.y))
         sx += float(p[0]); sy += float(p[1])
@@ -210,10 +246,12 @@ class _Frame:
 
 def _group_by_frame(arr: np.ndarray) -> Dict[int, np.ndarray]:
     """HashMap<u32, Vec<ContourPoint>> with points in input order (contour.rs:163-166)."""
-    groups: Dict[int, List[int]] = {}
-    for i, fi in enumerate(arr[:, 0]):
-        groups.setdefault(int(fi), []).append(i)
-    return {k: arr[v, 1:4].copy() for k, v in groups.items()}
+    fi = arr[:, 0].astype(np.int64)
+    order = np.argsort(fi, kind="stable")                 # rows of one frame stay in input order
+    keys, starts = np.unique(fi[order], return_index=True)
+    bounds = list(starts) + [fi.shape[0]]
+    first_seen = np.argsort(order[starts], kind="stable") # dict order = order of first appearance
+    return {int(keys[k]): arr[order[bounds[k]:bounds[k + 1]], 1:4].copy() for k in first_seen}
 
 
 def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: Optional[str] = None, label: str = "",
@@ -227,10 +265,10 @@ def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: 
     d = input_data
 
     # build.rs:37-71 shared original-frame -> sequential-id mapping
-    originals = set(int(f) for f in d.lumen[:, 0])
+    originals = set(int(f) for f in np.unique(d.lumen[:, 0]))
     for arr in (d.eem, d.calcification, d.sidebranch):
         if arr is not None:
-            originals.update(int(f) for f in arr[:, 0])
+            originals.update(int(f) for f in np.unique(arr[:, 0]))
     ref_frame = int(d.ref_point[0])
     originals.add(ref_frame)
     mapping = {o: i for i, o in enumerate(sorted(originals))}
