@@ -227,3 +227,21 @@ def test_hole_filling_eem_and_walls_through_the_entry_point(engine, mm):
                                  engine=engine)
     assert an.meta["anomalous"] is True and an.meta["lumen_aortic"].sum() == 12 * 60
     assert an.meta["extra_counts"]["wall"].tolist() == [120] * 12 and an.meta["aortic_thickness"] == [0.9] * 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bruteforce", [False, True])
+def test_config1_example_data_singlepair_matches_oracle(engine, mm, oracle, bruteforce):
+    """BASELINE config 1: single-pair mode on the reference's examples/data/ivus_rest (20 + 17 frames x 501
+    points, committed as tests/golden/examples_ivus_rest): chain logs of both pullbacks and the between
+    rotation are identical to the oracle's restatement of align_frames_in_geometry / align_between."""
+    from helpers import to_oracle
+    path = os.path.join(GOLD, "examples_ivus_rest")
+    pair, (logs_d, logs_s) = mm.from_file_singlepair(path, step_rotation_deg=0.5, range_rotation_deg=90.0,
+                                                     bruteforce=bruteforce, smooth=False, postprocessing=False,
+                                                     engine=engine)
+    assert pair.geom_a.n_frames == 20 and pair.geom_b.n_frames == 17 and pair.label == "examples_ivus_rest - examples_ivus_rest"
+    for dia, logs in ((True, logs_d), (False, logs_s)):
+        og = to_oracle(oracle, mm.build_geometry_from_inputdata(None, path, "x", dia))
+        assert list(logs) == oracle.align_within_chain(og, 0.5, 90.0, bruteforce, 500, n_threads=8)
+    assert len(logs_d) == 19 and len(logs_s) == 16
