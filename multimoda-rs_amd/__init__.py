@@ -23,8 +23,8 @@ from .centerline import (Centerline, align_combined, align_manual, align_three_p
                          preprocess_centerline)
 from . import centerline
 from . import ccta
-from .ccta import (adjust_diameter_centerline_morphing_simple, find_aortic_scaling, find_aortic_wall_scaling,
-                   find_distal_and_proximal_scaling, find_proximal_distal_scaling)
+from .ccta import (adjust_diameter_centerline_morphing_simple, find_aorta_scaling, find_aortic_scaling,
+                   find_aortic_wall_scaling, find_distal_and_proximal_scaling, find_proximal_distal_scaling)
 from .extension import ShiftRotationSearch
 from .synth import synthetic_case, synthetic_pullback
 
@@ -42,7 +42,7 @@ __all__ = [
     "Centerline", "numpy_to_centerline", "preprocess_centerline", "align_three_point", "align_manual",
     "align_combined", "centerline",
     "ccta", "adjust_diameter_centerline_morphing_simple", "find_proximal_distal_scaling", "find_aortic_scaling",
-    "find_aortic_wall_scaling", "find_distal_and_proximal_scaling",
+    "find_aortic_wall_scaling", "find_distal_and_proximal_scaling", "find_aorta_scaling",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F32_FAST", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

@@ -102,8 +102,8 @@ def find_aortic_scaling(intramural_points, reference_points, centerline: Centerl
     return (best.value, d) if return_distances else best.value
 
 
-def find_aortic_wall_scaling(cl_aorta: Centerline, ref_pt_coronary, aortic_pts) -> float:
-    """ccta_py.rs:467-481 (host only)."""
+def find_aortic_wall_scaling_raw(cl_aorta: Centerline, ref_pt_coronary, aortic_pts) -> float:
+    """The binding ``find_aortic_wall_scaling`` (ccta_py.rs:467-481, host only)."""
     r = np.ascontiguousarray(np.asarray(ref_pt_coronary, dtype=np.float64).reshape(3))
     a = _p3(aortic_pts)
     out = C.c_double(0.0)
@@ -124,3 +124,54 @@ def find_distal_and_proximal_scaling(geometry: G.FlatGeometry, centerline: Cente
     n_section = int(math.ceil(0.25 * len(results["anomalous_points"])))
     return find_proximal_distal_scaling(results["anomalous_points"], n_section, n_section, centerline, prox_pts,
                                         dist_pts, engine=engine)
+
+
+def _extract_wall_from_frames(geometry: G.FlatGeometry):
+    """multimodars/ccta/scaling.py:239-297: the straight (coronary-side) half of the Wall contour, point
+    indices below n/2, of the LAST frame that carries an aortic thickness; None if there is none."""
+    from . import frames as FR
+    fr = FR.to_frames(geometry)
+    half = len(fr[0].lumen) // 2
+    ref = None
+    for f in fr:
+        if f.lumen.aortic_thickness is None:
+            continue
+        wall = f.extras.get("wall")
+        if wall is None:
+            raise ValueError(f"No Wall extras found for frame {f.id}")
+        if len(wall) == 0:
+            raise ValueError(f"Empty Wall extras for frame {f.id}")
+        ref = wall.points[:half].copy()
+    return ref
+
+
+def find_aorta_scaling(geometry: G.FlatGeometry, cl_aorta: Centerline, results: dict,
+                       engine: Optional[N.Engine] = None) -> float:
+    """multimodars/ccta/scaling.py:148-189: the removed RCA points are scaled radially about the aortic
+    centerline against the straight wall of the intravascular frames."""
+    ref = _extract_wall_from_frames(geometry)
+    if ref is None:
+        raise ValueError("No aortic wall points found in frames for scaling reference")
+    return find_aortic_scaling(results["rca_removed_points"], ref, cl_aorta, engine=engine)
+
+
+def find_aortic_wall_scaling(geometry_or_centerline, cl_aorta=None, results=None, aortic_pts=None):
+    """Both spellings of the reference: the wrapper ``find_aortic_wall_scaling(frames, cl_aorta, results)``
+    (multimodars/ccta/scaling.py:192-236: reference point = the point at index n/4 of the first lumen with
+    an elliptic ratio < 1.3, scored against ``results["aorta_points"]``) when the first argument is a
+    geometry, and the binding ``find_aortic_wall_scaling(cl_aorta, ref_pt_coronary, aortic_pts)``
+    (ccta_py.rs:467-481) when it is a centerline."""
+    if isinstance(geometry_or_centerline, Centerline):
+        pts = aortic_pts if aortic_pts is not None else results
+        return find_aortic_wall_scaling_raw(geometry_or_centerline, cl_aorta, pts)
+    from .api import _elliptic_ratio
+    g = geometry_or_centerline
+    ref_point = None
+    for i in range(g.n_frames):
+        lum = g.frame_lumen(i)
+        if _elliptic_ratio(lum) < 1.3:
+            ref_point = lum[lum.shape[0] // 4].copy()
+            break
+    if ref_point is None:
+        raise ValueError("No coronary reference point found")
+    return find_aortic_wall_scaling_raw(cl_aorta, ref_point, results["aorta_points"])

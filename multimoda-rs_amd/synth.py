@@ -71,7 +71,7 @@ def synthetic_case(n_frames: int, n_points: int = 501, seed: int = 1234) -> List
 
 def synthetic_centerline_case(n_frames: int = 24, n_points: int = 200, n_ccta: int = 4000, seed: int = 7,
                               true_rotation_deg: float = 37.0, true_index: int = 12, noise: float = 0.03,
-                              clutter_frac: float = 0.0):
+                              clutter_frac: float = 0.0, geometry: FlatGeometry = None):
     """A centerline-placement problem with a known answer (BASELINE config 5 shape; generator is ours):
     a curved vessel centerline, one pullback geometry, and a CCTA-like point cloud sampled from that
     geometry placed on the centerline at index ``true_index`` after an in-plane rotation of
@@ -82,8 +82,13 @@ def synthetic_centerline_case(n_frames: int = 24, n_points: int = 200, n_ccta: i
     from . import centerline as CL
 
     rng = np.random.Generator(np.random.PCG64(seed))
-    g = synthetic_pullback(n_frames, n_points, pullback_id=0, seed=seed, torsion_sigma_deg=0.5)
-    CL.with_lumen_centroids(g)
+    if geometry is None:
+        g = synthetic_pullback(n_frames, n_points, pullback_id=0, seed=seed, torsion_sigma_deg=0.5)
+    else:                                   # place a given geometry (e.g. the result of from_array_*)
+        g = geometry.copy()
+        n_frames, n_points = g.n_frames, int(g.lumen_off[1] - g.lumen_off[0])
+    if g.lumen_centroids is None:
+        CL.with_lumen_centroids(g)
     # vessel path: gentle 3-D curve, z descending, raw spacing 0.2 mm (resampled to ~0.5 mm by preprocess)
     s = np.arange(0.0, 0.5 * n_frames + 30.0, 0.2)
     path = np.stack([12.0 + 6.0 * np.sin(s / 17.0), -200.0 + 5.0 * np.cos(s / 23.0), 1750.0 - 0.93 * s], axis=1)
@@ -102,15 +107,16 @@ def synthetic_centerline_case(n_frames: int = 24, n_points: int = 200, n_ccta: i
     # landmarks: where the reference frame's points with point_index = ref, 0 and n/2 land; the
     # three-point sweep rotates without re-sorting (align_algorithms.rs:286-311), so these come from
     # the un-sorted rotation of frame 0
-    ref_index = int(np.argmin(np.linalg.norm(g.frame_lumen(0) - g.ref[0], axis=1)))
+    ref_frame = int(np.nonzero(g.has_ref)[0][0])
+    ref_index = int(np.argmin(np.linalg.norm(g.frame_lumen(ref_frame) - g.ref[ref_frame], axis=1)))
     g.meta["ref_point_index"] = ref_index
     tmp = g.copy()
-    f0 = tmp.frame_lumen(0)
+    f0 = tmp.frame_lumen(ref_frame)
     c, s_ = math.cos(math.radians(true_rotation_deg)), math.sin(math.radians(true_rotation_deg))
-    dx, dy = f0[:, 0] - tmp.centroids[0, 0], f0[:, 1] - tmp.centroids[0, 1]
-    f0[:, 0], f0[:, 1] = dx * c - dy * s_ + tmp.centroids[0, 0], dx * s_ + dy * c + tmp.centroids[0, 1]
+    dx, dy = f0[:, 0] - tmp.centroids[ref_frame, 0], f0[:, 1] - tmp.centroids[ref_frame, 1]
+    f0[:, 0], f0[:, 1] = dx * c - dy * s_ + tmp.centroids[ref_frame, 0], dx * s_ + dy * c + tmp.centroids[ref_frame, 1]
     CL.apply_transformations([tmp], rcl, ref_pt)
-    f0 = tmp.frame_lumen(0)
+    f0 = tmp.frame_lumen(ref_frame)
     return dict(centerline=cl, geometry=g, main_ref_pt=f0[ref_index] + rng.normal(0.0, noise, 3),
                 ccw_ref_pt=f0[0] + rng.normal(0.0, noise, 3), cw_ref_pt=f0[n_points // 2] + rng.normal(0.0, noise, 3),
                 points=points, truth=dict(rotation_deg=true_rotation_deg, cl_index=true_index, placed=placed))
