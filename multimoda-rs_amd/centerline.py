@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Optional, Sequence, Tuple, Union
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 

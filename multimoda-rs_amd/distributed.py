@@ -11,7 +11,6 @@ process_utils.rs:72 -- identically on every rank.  Message size: 28 B x pairs x 
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict, Optional
 
 import numpy as np

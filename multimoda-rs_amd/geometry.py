@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 

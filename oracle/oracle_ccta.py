@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import oracle as O
-from .oracle_cl import CL_DTYPE, _cl, _v3
+from .oracle_cl import _cl, _v3
 
 _ready = False
 

@@ -7,7 +7,7 @@ Centerline placement, three-point search and Hausdorff refinement of the referen
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import Sequence
 
 import numpy as np
 

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import geoms_equal, to_oracle
+from helpers import to_oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
