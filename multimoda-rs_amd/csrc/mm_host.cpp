@@ -278,7 +278,7 @@ struct WithinPlan {
     int prepare();
     int level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
     int level_commit(size_t l, const uint8_t* ok, const double* angle);
-    void build_level_pairs(size_t l, const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
+    void build_level_pairs(size_t l, const std::vector<double>& centres, const std::vector<uint8_t>& take,
                            std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out);
     int search();
     int walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
@@ -342,21 +342,21 @@ int WithinPlan::prepare()
 
 // PairSpecs of one level for the jobs that are still resolved; `lists` holds per-job
 // candidate lists for levels >= 1 (level 0 shares one list).
-void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centre, const std::vector<uint8_t>& resolved,
+void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centres, const std::vector<uint8_t>& take,
                                    std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out)
 {
     const int J = (int)job_geom.size();
     pairs.clear(); active.clear();
     if (l > 0 && (int)lists.size() != J) lists.assign(J, std::vector<double>());
     for (int j = 0; j < J; ++j) {
-        if (!resolved[j]) continue;
+        if (!take[j]) continue;
         const double* lp; int32_t ln;
         if (l == 0) {
             if (!level0_ok) { if (centre_out) (*centre_out)[j] = level0_early; continue; }
             lp = level0.data(); ln = (int32_t)level0.size();
         } else {
             double early = 0.0;
-            if (!enumerate_angles(levels[l].step, levels[l].range, true, centre[j], range_deg, lists[j], early)) {
+            if (!enumerate_angles(levels[l].step, levels[l].range, true, centres[j], range_deg, lists[j], early)) {
                 if (centre_out) (*centre_out)[j] = early;
                 continue;
             }
