@@ -303,35 +303,56 @@ int WithinPlan::prepare()
     set_base.assign(n_geoms + 1, 0); job_base.assign(n_geoms + 1, 0);
     sx.clear(); sy.clear(); job_geom.clear(); job_frame.clear();
     eps.assign(n_geoms, 0.0);
-    for (int g = 0; g < n_geoms; ++g) {
-        const mm_geometry* G = geoms[g];
-        set_base[g] = (int32_t)sx.size();
-        job_base[g] = (int32_t)job_geom.size();
-        double scale = 0.0;
-        for (int32_t i = 0; i < G->n_frames; ++i) {
-            std::vector<double> x, y;
+    {
+        TraceTimer t_sets("prepare: search sets");
+        int32_t n_sets = 0;
+        for (int g = 0; g < n_geoms; ++g) {
+            set_base[g] = n_sets;
+            job_base[g] = (int32_t)job_geom.size();
+            for (int32_t i = 1; i < geoms[g]->n_frames; ++i) { job_geom.push_back(g); job_frame.push_back(i); }
+            n_sets += geoms[g]->n_frames;
+        }
+        sx.assign((size_t)n_sets, {}); sy.assign((size_t)n_sets, {});
+        std::vector<double> set_scale((size_t)n_sets, 0.0);
+        std::vector<int> set_geom((size_t)n_sets);
+        for (int g = 0; g < n_geoms; ++g)
+            for (int32_t i = 0; i < geoms[g]->n_frames; ++i) set_geom[(size_t)(set_base[g] + i)] = g;
+        parallel_for(n_sets, [&](int s) {           // sets are independent: build them over the worker pool
+            const int g = set_geom[(size_t)s];
+            const int32_t i = s - set_base[g];
+            const mm_geometry* G = geoms[g];
+            std::vector<double>&x = sx[(size_t)s], &y = sy[(size_t)s];
             frame_search_set(G, i, spec[g], x, y);
             const double cx = G->centroid[3 * i], cy = G->centroid[3 * i + 1];
+            double scale = 0.0;
             for (size_t k = 0; k < x.size(); ++k) {
                 scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
                 x[k] -= cx; y[k] -= cy;
                 scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
             }
-            sx.push_back(std::move(x)); sy.push_back(std::move(y));
-            if (i >= 1) { job_geom.push_back(g); job_frame.push_back(i); }
+            set_scale[(size_t)s] = scale;
+        });
+        for (int g = 0; g < n_geoms; ++g) {
+            double scale = 0.0;
+            for (int32_t i = 0; i < geoms[g]->n_frames; ++i) scale = std::max(scale, set_scale[(size_t)(set_base[g] + i)]);
+            // chain-state coordinates stay within |frame-0 centroid| + radius: 4x covers it amply
+            eps[g] = std::ldexp(4.0 * scale + 1.0, -42);
         }
-        // chain-state coordinates stay within |frame-0 centroid| + radius: 4x covers it amply
-        eps[g] = std::ldexp(4.0 * scale + 1.0, -42);
     }
     set_base[n_geoms] = (int32_t)sx.size();
     job_base[n_geoms] = (int32_t)job_geom.size();
 
     std::vector<SetRef> sets(sx.size());
     for (size_t s = 0; s < sx.size(); ++s) sets[s] = SetRef{sx[s].data(), sy[s].data(), (int32_t)sx[s].size(), 0.0, 0.0};
-    int rc = plan.stage_sets(e, sets, /*transient=*/false);
+    int rc;
+    {
+        TraceTimer t("prepare: stage sets");
+        rc = plan.stage_sets(e, sets, /*transient=*/false);
+    }
     if (rc) return rc;
     // level 0 has no centre: its candidate list, descriptors and tables are known now
     if (level0_ok) {
+        TraceTimer t("prepare: stage level 0");
         build_level_pairs(0, std::vector<double>(), std::vector<uint8_t>(job_geom.size(), 1), lvl_pairs, lvl_active, nullptr);
         if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
         level0_staged = true;
