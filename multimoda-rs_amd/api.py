@@ -26,7 +26,7 @@ import numpy as np
 from . import _native as N
 from . import geometry as G
 from ._libm import sincos
-from .io import EXTRA_KINDS, InputData, build_geometry_from_inputdata, sort_contour_points
+from .io import InputData, build_geometry_from_inputdata
 
 AlignLog = List[Tuple[int, int, float, float, float, float, float]]
 TOLERANCE = 0.03  # entry.rs:21 (used by postprocessing only)
@@ -176,54 +176,13 @@ def _angle_ref_point_to_right(g: G.FlatGeometry, ref_idx: int, anomalous: bool) 
     return rotation
 
 
-def _sort_frame_points(g: G.FlatGeometry):
-    """Frame::sort_frame_points for every frame: lumen and every extras contour (frame.rs:119-125)."""
-    counts = g.meta.get("extra_counts")
-    for i in range(g.n_frames):
-        lo, hi = int(g.lumen_off[i]), int(g.lumen_off[i + 1])
-        g.lumen[lo:hi] = sort_contour_points(g.lumen[lo:hi])
-        if g.cath_off is not None:
-            lo, hi = int(g.cath_off[i]), int(g.cath_off[i + 1])
-            g.cath[lo:hi] = sort_contour_points(g.cath[lo:hi])
-        if g.extra_off is not None and counts:
-            lo = int(g.extra_off[i])
-            for k in EXTRA_KINDS:
-                n = int(counts[k][i])
-                if n:
-                    g.extra[lo:lo + n] = sort_contour_points(g.extra[lo:lo + n])
-                    lo += n
-
-
 def _rotate_geometry(g: G.FlatGeometry, angle: float):
-    """Geometry::rotate_geometry (geometry.rs:241-250): every frame about its own centroid, then
-    its contours re-sorted."""
+    """Geometry::rotate_geometry (geometry.rs:241-250): every frame about its own centroid, then its
+    contours re-sorted -- one call into the C ABI (mm_rotate_geometry, csrc/mm_centerline.cpp)."""
     if angle == 0.0:
         return
-    import ctypes as C
-    s = g.c_struct()
-    for i in range(g.n_frames):
-        N.lib().mm_frame_rotate(C.byref(s), i, angle, float(g.centroids[i, 0]), float(g.centroids[i, 1]))
-    _sort_frame_points(g)
-
-
-def _smooth_frames(g: G.FlatGeometry):
-    """Geometry::smooth_frames (geometry.rs:165-239) for the lumen: 3-frame moving average of x, y
-    (first / last frame mirrored); z and the frame centroid stay.  Frames must have equal point
-    counts (the reference indexes prev/next by the current frame's count)."""
-    F = g.n_frames
-    cnt = np.diff(g.lumen_off)
-    if F == 0 or not np.all(cnt == cnt[0]):
-        raise NotImplementedError("smooth=True needs the same number of lumen points in every frame")
-    if g.extra_off is not None and g.meta.get("extra_counts", {}).get("eem", np.zeros(1)).sum():
-        raise NotImplementedError("smooth=True with EEM contours is not restated (geometry.rs:226-236)")
-    m = int(cnt[0])
-    L = g.lumen.reshape(F, m, 3)
-    prev = np.concatenate([L[:1], L[:-1]], axis=0)
-    nxt = np.concatenate([L[1:], L[-1:]], axis=0)
-    out = L.copy()
-    out[:, :, 0] = (prev[:, :, 0] + L[:, :, 0] + nxt[:, :, 0]) / 3.0
-    out[:, :, 1] = (prev[:, :, 1] + L[:, :, 1] + nxt[:, :, 1]) / 3.0
-    g.lumen[:] = out.reshape(-1, 3)
+    from .centerline import rotate_geometry
+    rotate_geometry(g, angle)
 
 
 def _ref_or_proximal(g: G.FlatGeometry) -> int:
@@ -244,6 +203,78 @@ def _replace(g: G.FlatGeometry, h: G.FlatGeometry) -> None:
     for name in ("ids", "lumen_ids", "orig_frames", "centroids", "lumen_off", "lumen", "cath_off", "cath",
                  "extra_off", "extra", "has_ref", "ref", "label", "meta", "has_lumen_centroid", "lumen_centroids"):
         setattr(g, name, getattr(h, name))
+
+
+def _finish_within_batched(g: G.FlatGeometry, anomalous: bool, smooth: bool) -> bool:
+    """The regular case of align_within.rs:144-158 without a Python loop over frames: every lumen (and
+    EEM, if present) has the same number of points and no other extras kind is present.  Aortic flags,
+    wall contours and smoothing are computed on (F, m, 3) arrays with the per-element arithmetic of
+    postproc.assign_aortic / create_wall_frames / smooth_frames (frames with a measured thickness still
+    build their aortic wall one by one); the results are bit-identical (tests/test_postproc.py).
+    Returns False, leaving g untouched, when the geometry is not regular."""
+    from . import frames as FR
+    from . import postproc as PP
+    F = g.n_frames
+    cnt = np.diff(g.lumen_off)
+    if F == 0 or not np.all(cnt == cnt[0]) or cnt[0] == 0:
+        return False
+    m = int(cnt[0])
+    counts = g.meta.get("extra_counts") or {}
+    has_eem = "eem" in counts and int(np.sum(counts["eem"])) > 0
+    if any(int(np.sum(c)) for k, c in counts.items() if k != "eem"):
+        return False
+    if has_eem and not np.all(counts["eem"] == m):
+        return False
+    if (g.extra_off is not None) != has_eem:
+        return False
+    L = g.lumen.reshape(F, m, 3)
+    E = g.extra.reshape(F, m, 3) if has_eem else None
+    a_th = g.meta.get("aortic_thickness") or [None] * F
+    p_th = g.meta.get("pulmonary_thickness") or [None] * F
+    aortic = np.zeros((F, m), dtype=bool)
+    if anomalous:
+        aortic[:, m // 2:] = True                                              # assign_aortic
+    src = L if anomalous or not has_eem else E                                 # wall.rs:13-19
+    src_aortic = aortic if src is L else np.zeros((F, m), dtype=bool)
+    W = PP.offset_contours_batched(src, 1.0)                                   # offset_contour(.., 1.0, None)
+    w_aortic = src_aortic.copy()
+    # frames whose source contour carries a measured aortic thickness get the aortic-wall construction;
+    # only the lumen carries thicknesses (contour.rs:128-141), the EEM never does
+    if src is L:
+        for i in range(F):
+            if a_th[i] is not None:
+                c = FR.Contour(int(g.lumen_ids[i]), int(g.orig_frames[i]), L[i].copy(), None, a_th[i], p_th[i], "lumen",
+                               aortic[i].copy())
+                w = PP.create_aortic_wall(c)
+                if len(w) != m:
+                    return False
+                W[i] = w.points
+                w_aortic[i] = w.aortic
+    if smooth:
+        L = PP.smooth_batched(L)
+        W = PP.smooth_batched(W)
+        if has_eem:
+            E = PP.smooth_batched(E)
+    g.lumen = np.ascontiguousarray(L.reshape(F * m, 3))
+    blob = np.concatenate([E, W], axis=1) if has_eem else W
+    g.extra = np.ascontiguousarray(blob.reshape(-1, 3))
+    g.extra_off = np.arange(F + 1, dtype=np.int64) * blob.shape[1]
+    meta = dict(g.meta)
+    from .io import EXTRA_KINDS
+    meta["extra_counts"] = {k: (np.full(F, m, dtype=np.int64) if k == "wall" or (k == "eem" and has_eem)
+                                else np.zeros(F, dtype=np.int64)) for k in EXTRA_KINDS}
+    if aortic.any():
+        meta["lumen_aortic"] = aortic.reshape(-1)
+    else:
+        meta.pop("lumen_aortic", None)
+    if w_aortic.any():
+        meta["wall_aortic"] = w_aortic.reshape(-1)
+    else:
+        meta.pop("wall_aortic", None)
+    g.meta = meta
+    g.has_lumen_centroid = np.ones(F, dtype=np.uint8)
+    g.lumen_centroids = np.ascontiguousarray(PP.centroids_batched(L))
+    return True
 
 
 def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
@@ -267,15 +298,16 @@ def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
     anomalous = (_elliptic_ratio(lum) > 2.0 or (a_th is not None and a_th[ref_idx] is not None)
                  or (p_th is not None and p_th[ref_idx] is not None))        # align_within.rs:249-254
     _rotate_geometry(g, _angle_ref_point_to_right(g, ref_idx, anomalous))      # :139-142
-    with_lumen_centroids(g)
-    fr = FR.to_frames(g)
-    if anomalous:
-        PP.assign_aortic(fr)                                                   # :144-148
-    fr = PP.create_wall_frames(fr, anomalous, False)                           # :150-154
-    if smooth:
-        fr = PP.smooth_frames(fr)                                              # :156-158
-    meta = dict(g.meta)
-    _replace(g, FR.from_frames(fr, g.label, meta))
+    if not _finish_within_batched(g, anomalous, smooth):
+        with_lumen_centroids(g)
+        fr = FR.to_frames(g)
+        if anomalous:
+            PP.assign_aortic(fr)                                               # :144-148
+        fr = PP.create_wall_frames(fr, anomalous, False)                       # :150-154
+        if smooth:
+            fr = PP.smooth_frames(fr)                                          # :156-158
+        meta = dict(g.meta)
+        _replace(g, FR.from_frames(fr, g.label, meta))
     g.meta["anomalous"] = bool(anomalous)
     g.meta["lumen_centroid_fresh"] = bool(smooth)        # geometry.rs:204
     return bool(anomalous)
@@ -335,7 +367,11 @@ def _maybe_postprocess(pair: GeometryPair, anomalous: bool, postprocessing: bool
         return pair
     from . import frames as FR
     from . import postproc as PP
+    from .postproc_flat import postprocess_pair_regular
     try:
+        fast = postprocess_pair_regular(pair.geom_a, pair.geom_b, TOLERANCE, anomalous)
+        if fast is not None:
+            return GeometryPair(fast[0], fast[1], pair.label)
         fa, fb = PP.postprocess_pair(FR.to_frames(pair.geom_a), FR.to_frames(pair.geom_b), TOLERANCE, anomalous)
     except RuntimeError as e:
         raise RuntimeError(f"Failed postprocessing of {pair.label}: {e}") from e

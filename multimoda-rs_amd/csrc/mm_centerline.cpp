@@ -313,23 +313,26 @@ void rotate_geometry(mm_cl_geometry* cg, double angle)
 {
     if (angle == 0.0) return;                                                                  // geometry.rs:242-244
     mm_geometry* g = cg->g;
-    SortScratch sc;
-    for (int32_t i = 0; i < g->n_frames; ++i) {
-        mm_frame_rotate(g, i, angle, g->centroid[3 * i], g->centroid[3 * i + 1]);              // :246-247
-        sort_contour(g->lumen + 3 * g->lumen_off[i], g->lumen_off[i + 1] - g->lumen_off[i], sc);  // frame.rs:123-129
-        if (g->cath_off) sort_contour(g->cath + 3 * g->cath_off[i], g->cath_off[i + 1] - g->cath_off[i], sc);
-        if (g->extra_off) {
-            if (cg->extra_kind_off) {
-                const int32_t K = cg->n_extra_kinds;
-                for (int32_t k = 0; k < K; ++k) {
-                    const int64_t lo = cg->extra_kind_off[(int64_t)i * K + k], hi = cg->extra_kind_off[(int64_t)i * K + k + 1];
-                    sort_contour(g->extra + 3 * lo, hi - lo, sc);
+    constexpr int kFrames = 8;   // frames are independent: chunks of them over the worker pool
+    parallel_for((g->n_frames + kFrames - 1) / kFrames, [&](int c) {
+        SortScratch sc;
+        for (int32_t i = c * kFrames; i < std::min<int32_t>(g->n_frames, (c + 1) * kFrames); ++i) {
+            mm_frame_rotate(g, i, angle, g->centroid[3 * i], g->centroid[3 * i + 1]);          // :246-247
+            sort_contour(g->lumen + 3 * g->lumen_off[i], g->lumen_off[i + 1] - g->lumen_off[i], sc);  // frame.rs:123-129
+            if (g->cath_off) sort_contour(g->cath + 3 * g->cath_off[i], g->cath_off[i + 1] - g->cath_off[i], sc);
+            if (g->extra_off) {
+                if (cg->extra_kind_off) {
+                    const int32_t K = cg->n_extra_kinds;
+                    for (int32_t k = 0; k < K; ++k) {
+                        const int64_t lo = cg->extra_kind_off[(int64_t)i * K + k], hi = cg->extra_kind_off[(int64_t)i * K + k + 1];
+                        sort_contour(g->extra + 3 * lo, hi - lo, sc);
+                    }
+                } else {
+                    sort_contour(g->extra + 3 * g->extra_off[i], g->extra_off[i + 1] - g->extra_off[i], sc);
                 }
-            } else {
-                sort_contour(g->extra + 3 * g->extra_off[i], g->extra_off[i + 1] - g->extra_off[i], sc);
             }
         }
-    }
+    });
 }
 
 // best_rotation_three_point (align_algorithms.rs:263-336)

@@ -254,6 +254,38 @@ def create_wall_frames(frames: List[Frame], anomalous: bool, with_pulmonary: boo
     return out
 
 
+def offset_contours_batched(P: np.ndarray, distance: float) -> np.ndarray:
+    """offset_contour (wall.rs:52-100) for F contours of equal length at once: P is (F, m, 3).  The
+    arithmetic per element is that of the per-contour version (sequential centroid sums, the same
+    elementwise operations), so the result is bit-identical; only the Python loop over frames is gone."""
+    F, m, _ = P.shape
+    c = np.add.accumulate(P, axis=1)[:, -1, :] / float(m)                     # compute_centroid per contour
+    d = P - c[:, None, :]
+    ln = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
+    ok = ln > F64_EPS
+    safe = np.where(ok, ln, 1.0)
+    out = P.copy()
+    for k in range(3):
+        out[..., k] = np.where(ok, P[..., k] + (d[..., k] / safe) * distance, P[..., k])
+    return out
+
+
+def smooth_batched(P: np.ndarray) -> np.ndarray:
+    """The lumen / EEM / wall part of smooth_frames for F contours of equal length: (F, m, 3) ->
+    (F, m, 3), x and y averaged over (previous, current, next) frame with the ends mirrored."""
+    prev = np.concatenate([P[:1], P[:-1]], axis=0)
+    nxt = np.concatenate([P[1:], P[-1:]], axis=0)
+    out = P.copy()
+    out[..., 0] = (prev[..., 0] + P[..., 0] + nxt[..., 0]) / 3.0
+    out[..., 1] = (prev[..., 1] + P[..., 1] + nxt[..., 1]) / 3.0
+    return out
+
+
+def centroids_batched(P: np.ndarray) -> np.ndarray:
+    """compute_centroid (contour.rs:213-224) of F contours of equal length: sequential sums / m."""
+    return np.add.accumulate(P, axis=1)[:, -1, :] / float(P.shape[1])
+
+
 # ======================================================================================
 # smoothing (geometry.rs:165-239)
 # ======================================================================================

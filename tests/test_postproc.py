@@ -359,3 +359,111 @@ def test_align_walls_untwists(PP, FR):
     for f in el[1:]:
         ax = f.extras["wall"].points[0, :2] - f.extras["wall"].points[n // 2, :2]
         assert abs(ax[1]) < 1e-9 and abs(abs(ax[0]) - 6.0) < 1e-9      # major axis back on x (either sign)
+
+
+# ---- the batched fast path of api._finish_within equals the frame-by-frame one -------------------
+@pytest.mark.parametrize("with_eem,anomalous,smooth,thick", [
+    (False, False, True, ()), (True, False, True, ()), (True, True, True, ()), (False, True, False, (1, 4)),
+    (True, True, True, (0, 2, 5)), (False, False, False, ()),
+])
+def test_finish_within_batched_equals_frame_model(mm, PP, FR, with_eem, anomalous, smooth, thick):
+    from multimoda_rs_amd import api
+    from multimoda_rs_amd.io import EXTRA_KINDS
+    F, m = 6, 48
+    g = mm.synthetic_pullback(F, m, pullback_id=1, seed=5)
+    if with_eem:
+        L = g.lumen.reshape(F, m, 3)
+        c = L.mean(axis=1, keepdims=True)
+        g.extra = np.ascontiguousarray((c + (L - c) * [1.5, 1.5, 1.0]).reshape(-1, 3))
+        g.extra_off = np.arange(F + 1, dtype=np.int64) * m
+    g.meta["extra_counts"] = {k: (np.full(F, m, dtype=np.int64) if (k == "eem" and with_eem) else np.zeros(F, dtype=np.int64))
+                              for k in EXTRA_KINDS}
+    g.meta["aortic_thickness"] = [0.8 + 0.1 * i if i in thick else None for i in range(F)]
+    g.meta["pulmonary_thickness"] = [None] * F
+    a, b = g.copy(), g.copy()
+    assert api._finish_within_batched(a, anomalous, smooth) is True
+    mm.centerline.with_lumen_centroids(b)
+    fr = FR.to_frames(b)
+    if anomalous:
+        PP.assign_aortic(fr)
+    fr = PP.create_wall_frames(fr, anomalous, False)
+    if smooth:
+        fr = PP.smooth_frames(fr)
+    ref = FR.from_frames(fr, b.label, b.meta)
+    for name in ("lumen", "lumen_off", "extra", "extra_off", "cath", "centroids", "ref", "lumen_centroids"):
+        assert np.array_equal(getattr(a, name), getattr(ref, name)), name
+    for k in EXTRA_KINDS:
+        assert np.array_equal(a.meta["extra_counts"][k], ref.meta["extra_counts"][k]), k
+    for k in ("lumen_aortic", "wall_aortic"):
+        assert (k in a.meta) == (k in ref.meta) and (k not in a.meta or np.array_equal(a.meta[k], ref.meta[k])), k
+    # irregular geometries fall back
+    c = g.copy()
+    c.meta["extra_counts"]["calcification"] = np.ones(F, dtype=np.int64)
+    assert api._finish_within_batched(c, anomalous, smooth) is False
+
+
+# ---- the flat fast path of postprocess_geom_pair equals the frame-list one ---------------------------
+def _regular_geom(mm, F, m, seed, z0, dz, ref_at, with_eem, with_wall, thick, roll=0, lc=True):
+    from multimoda_rs_amd.io import EXTRA_KINDS
+    rng = np.random.default_rng(seed)
+    g = mm.synthetic_pullback(F, m, pullback_id=seed % 4, seed=seed)
+    z = z0 + dz * np.arange(F)
+    if roll:
+        z = np.roll(z, roll)
+    g.lumen[:, 2] = np.repeat(z, m); g.cath[:, 2] = np.repeat(z, 20); g.centroids[:, 2] = z
+    g.has_ref[:] = 0; g.has_ref[ref_at] = 1; g.ref[:] = 0.0; g.ref[ref_at] = [7.0, 4.0, z[ref_at]]
+    blobs, counts = [], {k: np.zeros(F, dtype=np.int64) for k in EXTRA_KINDS}
+    L = g.lumen.reshape(F, m, 3)
+    if with_eem:
+        blobs.append(L * [1.3, 1.3, 1.0]); counts["eem"][:] = m
+    if with_wall:
+        blobs.append(L * [1.6, 1.6, 1.0]); counts["wall"][:] = m
+    if blobs:
+        X = np.concatenate(blobs, axis=1)
+        g.extra = np.ascontiguousarray(X.reshape(-1, 3)); g.extra_off = np.arange(F + 1, dtype=np.int64) * X.shape[1]
+    g.meta["extra_counts"] = counts
+    g.meta["aortic_thickness"] = [0.7 + 0.05 * i if i in thick else None for i in range(F)]
+    g.meta["pulmonary_thickness"] = [None] * F
+    if thick:
+        la = np.zeros((F, m), dtype=bool); la[:, m // 2:] = True
+        g.meta["lumen_aortic"] = la.reshape(-1)
+        if with_wall:
+            g.meta["wall_aortic"] = la.reshape(-1).copy()
+    if lc:
+        mm.centerline.with_lumen_centroids(g)
+    return g
+
+
+@pytest.mark.parametrize("case", [
+    dict(Fa=7, Fb=5, ra=3, rb=1, anomalous=False, eem=True, wall=True, thick_a=(), thick_b=()),
+    dict(Fa=6, Fb=6, ra=0, rb=0, anomalous=True, eem=False, wall=True, thick_a=(0, 1, 2), thick_b=(1, 4)),
+    dict(Fa=5, Fb=8, ra=2, rb=6, anomalous=True, eem=True, wall=False, thick_a=(), thick_b=(3,)),
+    dict(Fa=6, Fb=6, ra=4, rb=2, anomalous=False, eem=False, wall=False, thick_a=(), thick_b=(), roll=2),
+    dict(Fa=4, Fb=4, ra=1, rb=1, anomalous=True, eem=True, wall=True, thick_a=(0, 1, 2, 3), thick_b=(), lc=False),
+])
+def test_postprocess_pair_flat_equals_frame_model(mm, PP, FR, case):
+    from multimoda_rs_amd.postproc_flat import postprocess_pair_regular
+    m = 48
+    a = _regular_geom(mm, case["Fa"], m, 11, 0.0, 0.5, case["ra"], case["eem"], case["wall"], case["thick_a"],
+                      roll=case.get("roll", 0), lc=case.get("lc", True))
+    b = _regular_geom(mm, case["Fb"], m, 12, 3.0, 0.5 + 1e-3, case["rb"], case["eem"], case["wall"], case["thick_b"],
+                      lc=case.get("lc", True))
+    fast = postprocess_pair_regular(a.copy(), b.copy(), 0.03, case["anomalous"])
+    assert fast is not None
+    fa, fb = PP.postprocess_pair(FR.to_frames(a), FR.to_frames(b), 0.03, case["anomalous"])
+    for got, exp_frames, src in ((fast[0], fa, a), (fast[1], fb, b)):
+        exp = FR.from_frames(exp_frames, src.label, src.meta)
+        for name in ("ids", "lumen_ids", "orig_frames", "centroids", "lumen_off", "lumen", "cath_off", "cath", "extra_off",
+                     "extra", "has_ref", "ref", "lumen_centroids", "has_lumen_centroid"):
+            x, y = getattr(got, name), getattr(exp, name)
+            assert (x is None) == (y is None), name
+            assert x is None or np.array_equal(x, y), name
+        for k in got.meta["extra_counts"]:
+            assert np.array_equal(got.meta["extra_counts"][k], exp.meta["extra_counts"][k]), k
+        assert got.meta["aortic_thickness"] == exp.meta["aortic_thickness"]
+        for k in ("lumen_aortic", "wall_aortic"):
+            assert (k in got.meta) == (k in exp.meta), k
+            assert k not in got.meta or np.array_equal(got.meta[k], exp.meta[k]), k
+    # different sampling rates take the interpolating branch: not handled here
+    c = _regular_geom(mm, 6, m, 13, 0.0, 1.0, 2, False, False, ())
+    assert postprocess_pair_regular(c, b, 0.03, False) is None
