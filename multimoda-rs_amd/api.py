@@ -328,7 +328,14 @@ def align_frames_in_geometries(geoms: Sequence[G.FlatGeometry], step_deg: float,
         raise RuntimeError("sample_size must be > 0")
     ref_idx = [_ref_or_proximal(g) for g in geoms]       # :42-44, before the chain
     logs, _ = G.align_within(eng, geoms, step_deg, range_deg, bruteforce, sample_size, precision=precision, mode=mode)
-    flags = [_finish_within(g, r, smooth) for g, r in zip(geoms, ref_idx)]
+    if len(geoms) > 1:
+        # the reference finishes the pullbacks in parallel threads (entry.rs:140-203); the bulk numpy and
+        # C-ABI calls of the post-steps release the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(geoms)) as ex:
+            flags = list(ex.map(lambda gr: _finish_within(gr[0], gr[1], smooth), zip(geoms, ref_idx)))
+    else:
+        flags = [_finish_within(g, r, smooth) for g, r in zip(geoms, ref_idx)]
     return logs, flags
 
 
