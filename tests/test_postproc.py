@@ -467,3 +467,25 @@ def test_postprocess_pair_flat_equals_frame_model(mm, PP, FR, case):
     # different sampling rates take the interpolating branch: not handled here
     c = _regular_geom(mm, 6, m, 13, 0.0, 1.0, 2, False, False, ())
     assert postprocess_pair_regular(c, b, 0.03, False) is None
+
+
+# ---- converters (multimodars/_converters.py) -------------------------------------------------------
+def test_to_array_and_numpy_to_geometry(mm):
+    g = mm.synthetic_pullback(4, 30, pullback_id=2)
+    d = mm.to_array(g)
+    assert set(d) == {"lumen", "eem", "calcification", "sidebranch", "catheter", "wall", "reference"}
+    assert d["lumen"].shape == (120, 4) and d["catheter"].shape == (80, 4) and d["reference"].shape == (1, 4)
+    assert d["lumen"][:, 0].tolist() == sorted(d["lumen"][:, 0].tolist()) and d["eem"].shape == (0, 4)
+    assert np.array_equal(d["lumen"][:, 1:], g.lumen) and np.array_equal(d["reference"][0, 1:], g.ref[0])
+    h = mm.numpy_to_geometry(d["lumen"], catheter_arr=d["catheter"], reference_arr=d["reference"], label="x")
+    assert np.array_equal(h.lumen, g.lumen) and np.array_equal(h.cath, g.cath) and h.ids.tolist() == [0, 1, 2, 3]
+    assert h.has_ref.all() and np.array_equal(h.ref, np.tile(g.ref[0], (4, 1)))        # the reference's quirk (:592)
+    assert np.allclose(h.centroids, [g.frame_lumen(i).mean(axis=0) for i in range(4)])
+    a, b = mm.to_array(mm.GeometryPair(g, h, "p"))
+    assert np.array_equal(a["lumen"], b["lumen"])
+    cl = mm.Centerline.from_contour_points([[0, 0, 0], [1, 0, 0], [2, 0, 0]])
+    assert mm.to_array(cl).tolist() == [[0, 0, 0, 0], [1, 1, 0, 0], [2, 2, 0, 0]]
+    with pytest.raises(ValueError, match="cannot be empty"):
+        mm.numpy_to_geometry(np.zeros((0, 4)))
+    with pytest.raises(TypeError):
+        mm.to_array(object())
