@@ -26,6 +26,8 @@ from . import ccta
 from .ccta import (adjust_diameter_centerline_morphing_simple, find_aorta_scaling, find_aortic_scaling,
                    find_aortic_wall_scaling, find_distal_and_proximal_scaling, find_proximal_distal_scaling)
 from .convert import numpy_to_geometry, to_array
+from .export import to_obj
+from . import export
 from .extension import ShiftRotationSearch
 from .synth import synthetic_case, synthetic_pullback
 
@@ -39,7 +41,7 @@ __all__ = [
     "from_array_full", "from_array_doublepair", "from_array_singlepair", "from_array_single",
     "InputData", "Record", "numpy_to_inputdata", "build_geometry_from_inputdata", "process_directory",
     "GeometryPair", "align_frames_in_geometries",
-    "ShiftRotationSearch", "to_array", "numpy_to_geometry",
+    "ShiftRotationSearch", "to_array", "numpy_to_geometry", "to_obj", "export",
     "Centerline", "numpy_to_centerline", "preprocess_centerline", "align_three_point", "align_manual",
     "align_combined", "centerline",
     "ccta", "adjust_diameter_centerline_morphing_simple", "find_proximal_distal_scaling", "find_aortic_scaling",

@@ -6,10 +6,9 @@ Orchestration follows entry.rs: build geometries (io.py), align frames within ev
 (device search, decoupled mode), the post-steps of ``align_frames_in_geometry``
 (align_within.rs:136-170: hole filling, reference point to the right, aortic flags, wall contours,
 smoothing -- postproc.py), the between-pullback alignments in the reference's order (AB | CD, then
-AC | BD), then ``postprocess_geom_pair`` per pair.  Same argument names, meaning and defaults as the
-reference, with one deliberate difference: ``write_obj`` defaults to False, because OBJ export
-(to_object/*) is outside this path; passing True raises
-NotImplementedError instead of silently skipping work.
+AC | BD), then ``postprocess_geom_pair`` per pair and, with ``write_obj`` (the default, as in the
+reference), the OBJ / MTL / texture files (export.py).  Same argument names, meaning and defaults as the
+reference.
 
 Return values: ``FlatGeometry`` / ``GeometryPair`` (numpy containers) instead of the PyO3 value
 classes; logs are the reference's 7-tuples ``(id, matched_to, rot_deg, tx, ty, cx, cy)``.
@@ -363,9 +362,26 @@ def _prepare_from_inputs(inputs: Sequence[InputData], image_center, radius, n_po
     return [build_geometry_from_inputdata(d, None, d.label, d.diastole, image_center, radius, n_points) for d in inputs]
 
 
-def _check_unsupported(write_obj):
+def _write_pairs(write_obj: bool, pairs, paths, interpolation_steps: int, watertight: bool, contour_types):
+    """to_object::process_case per pair (entry.rs:291-349): OBJ + MTL + textures into the pair's directory."""
+    if not write_obj:
+        return
+    from . import export as EX
+    from . import frames as FR
+    kinds = EX.DEFAULT_CONTOUR_TYPES if contour_types is None else contour_types
+    for pr, path in zip(pairs, paths):
+        try:
+            EX.process_case(pr.label, FR.to_frames(pr.geom_a), FR.to_frames(pr.geom_b), path, interpolation_steps,
+                            watertight, kinds)
+        except RuntimeError as e:
+            raise RuntimeError(f"process case failed for {pr.label}: {e}") from e
+
+
+def _write_single(write_obj: bool, g: G.FlatGeometry, path: str, watertight: bool, contour_types):
+    """entry.rs:740-776."""
     if write_obj:
-        raise NotImplementedError("write_obj=True: OBJ/MTL export (to_object/*, io/output.rs) is outside this path")
+        from . import export as EX
+        EX.write_single_mode(g, path, watertight, EX.DEFAULT_CONTOUR_TYPES if contour_types is None else contour_types)
 
 
 def _maybe_postprocess(pair: GeometryPair, anomalous: bool, postprocessing: bool) -> GeometryPair:
@@ -411,57 +427,63 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
 
 def from_array_full(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData, input_data_d: InputData,
                     step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0, sample_size: int = 500,
-                    image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20, write_obj: bool = False,
+                    image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20, write_obj: bool = True,
                     watertight: bool = True, contour_types=None, output_path_ab: str = "output/rest",
                     output_path_cd: str = "output/stress", output_path_ac: str = "output/diastole",
                     output_path_bd: str = "output/systole", interpolation_steps: int = 0, bruteforce: bool = False,
                     smooth: bool = True, postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:553 / functions.rs:827 / entry.rs:71 -> (pair_ab, pair_cd, pair_ac, pair_bd, (logs x4))."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data_a, input_data_b, input_data_c, input_data_d], image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine,
-                 postprocessing=postprocessing)
+    out = _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine,
+                postprocessing=postprocessing)
+    _write_pairs(write_obj, out[:4], (output_path_ab, output_path_cd, output_path_ac, output_path_bd), interpolation_steps,
+                 watertight, contour_types)
+    return out
 
 
 def from_file_full(input_path_ab: str, input_path_cd: str, labels=None, step_rotation_deg: float = 0.5,
                    range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
-                   radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                   radius: float = 0.5, n_points: int = 20, write_obj: bool = True, watertight: bool = True,
                    contour_types=None, output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
                    output_path_ac: str = "output/diastole", output_path_bd: str = "output/systole",
                    interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
                    postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:42 / functions.rs:168 / entry.rs:71."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path_ab, input_path_cd], labels, 4, image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine,
-                 postprocessing=postprocessing)
+    out = _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine,
+                postprocessing=postprocessing)
+    _write_pairs(write_obj, out[:4], (output_path_ab, output_path_cd, output_path_ac, output_path_bd), interpolation_steps,
+                 watertight, contour_types)
+    return out
 
 
 def from_array_doublepair(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData,
                           input_data_d: InputData, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
                           sample_size: int = 500, image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20,
-                          write_obj: bool = False, watertight: bool = True, contour_types=None,
+                          write_obj: bool = True, watertight: bool = True, contour_types=None,
                           output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
                           interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
                           postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:698 / entry.rs:363 -> (pair_ab, pair_cd, (logs x4))."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data_a, input_data_b, input_data_c, input_data_d], image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False,
-                 postprocessing=postprocessing)
+    out = _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False,
+                postprocessing=postprocessing)
+    _write_pairs(write_obj, out[:2], (output_path_ab, output_path_cd), interpolation_steps, watertight, contour_types)
+    return out
 
 
 def from_file_doublepair(input_path_ab: str, input_path_cd: str, labels=None, step_rotation_deg: float = 0.5,
                          range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
-                         radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                         radius: float = 0.5, n_points: int = 20, write_obj: bool = True, watertight: bool = True,
                          contour_types=None, output_path_ab: str = "output/rest", output_path_cd: str = "output/stress",
                          interpolation_steps: int = 0, bruteforce: bool = False, smooth: bool = True,
                          postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:201 / entry.rs:363."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path_ab, input_path_cd], labels, 4, image_center, radius, n_points)
-    return _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False,
-                 postprocessing=postprocessing)
+    out = _full(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, both_batches=False,
+                postprocessing=postprocessing)
+    _write_pairs(write_obj, out[:2], (output_path_ab, output_path_cd), interpolation_steps, watertight, contour_types)
+    return out
 
 
 def _pair(geoms, step, rng, smooth, bruteforce, sample_size, engine, postprocessing=False):
@@ -475,48 +497,52 @@ def _pair(geoms, step, rng, smooth, bruteforce, sample_size, engine, postprocess
 
 def from_array_singlepair(input_data_a: InputData, input_data_b: InputData, step_rotation_deg: float = 0.5,
                           range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
-                          radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                          radius: float = 0.5, n_points: int = 20, write_obj: bool = True, watertight: bool = True,
                           contour_types=None, output_path: str = "output/singlepair", interpolation_steps: int = 0,
                           bruteforce: bool = False, smooth: bool = True, postprocessing: bool = True,
                           engine: Optional[N.Engine] = None):
     """_processing.py:822 / entry.rs:572 -> (pair, (logs_a, logs_b))."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data_a, input_data_b], image_center, radius, n_points)
-    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, postprocessing)
+    out = _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, postprocessing)
+    _write_pairs(write_obj, out[:1], (output_path,), interpolation_steps, watertight, contour_types)
+    return out
 
 
 def from_file_singlepair(input_path: str, labels=None, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
                          sample_size: int = 500, image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20,
-                         write_obj: bool = False, watertight: bool = True, contour_types=None,
+                         write_obj: bool = True, watertight: bool = True, contour_types=None,
                          output_path: str = "output/singlepair", interpolation_steps: int = 0, bruteforce: bool = False,
                          smooth: bool = True, postprocessing: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:333 / functions.rs:517 / entry.rs:572: one folder read twice (diastole, systole)."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path], labels, 2, image_center, radius, n_points)
-    return _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, postprocessing)
+    out = _pair(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size, engine, postprocessing)
+    _write_pairs(write_obj, out[:1], (output_path,), interpolation_steps, watertight, contour_types)
+    return out
 
 
 def from_array_single(input_data: InputData, step_rotation_deg: float = 0.5, range_rotation_deg: float = 90.0,
                       sample_size: int = 500, image_center=(4.5, 4.5), radius: float = 0.5, n_points: int = 20,
-                      write_obj: bool = False, watertight: bool = True, contour_types=None,
+                      write_obj: bool = True, watertight: bool = True, contour_types=None,
                       output_path: str = "output/single", bruteforce: bool = False, smooth: bool = True,
                       engine: Optional[N.Engine] = None):
     """_processing.py:922 / functions.rs:1350 / entry.rs:691 -> (geometry, logs)."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_inputs([input_data], image_center, radius, n_points)
     logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
                                          engine)
-    return _with_contour_centroids(geoms[0]), logs[0]
+    g = _with_contour_centroids(geoms[0])
+    _write_single(write_obj, g, output_path, watertight, contour_types)
+    return g, logs[0]
 
 
 def from_file_single(input_path: str, labels=None, diastole: bool = True, step_rotation_deg: float = 0.5,
                      range_rotation_deg: float = 90.0, sample_size: int = 500, image_center=(4.5, 4.5),
-                     radius: float = 0.5, n_points: int = 20, write_obj: bool = False, watertight: bool = True,
+                     radius: float = 0.5, n_points: int = 20, write_obj: bool = True, watertight: bool = True,
                      contour_types=None, output_path: str = "output/single", bruteforce: bool = False,
                      smooth: bool = True, engine: Optional[N.Engine] = None):
     """_processing.py:449 / functions.rs:656 / entry.rs:691."""
-    _check_unsupported(write_obj)
     geoms = _prepare_from_paths([input_path], labels, 1, image_center, radius, n_points, single_diastole=diastole)
     logs, _ = align_frames_in_geometries(geoms, step_rotation_deg, range_rotation_deg, smooth, bruteforce, sample_size,
                                          engine)
-    return _with_contour_centroids(geoms[0]), logs[0]
+    g = _with_contour_centroids(geoms[0])
+    _write_single(write_obj, g, output_path, watertight, contour_types)
+    return g, logs[0]

@@ -8,8 +8,8 @@ Same argument names, meaning, defaults and error behaviour; geometries are ``Fla
 copies (the reference clones at the boundary too).  The three-point sweep and the frame placement
 are host f64 (csrc/mm_centerline.cpp); every Hausdorff evaluation of ``align_combined``'s
 refinement grid runs on the GPU; ``align_wall_anomalous=True`` applies the wall twist compensation
-(align.rs:381-595, postproc.align_walls) after the placement.  ``write=True`` (OBJ export,
-to_object/*) is outside this path and raises NotImplementedError instead of silently skipping work.
+(align.rs:381-595, postproc.align_walls) after the placement; ``write=True`` writes the OBJ / MTL /
+texture files (export.py).
 """
 from __future__ import annotations
 
@@ -174,9 +174,23 @@ def _unpack(geometry):
     raise TypeError("geometry must be a FlatGeometry or a GeometryPair")     # binding/align.rs:151
 
 
-def _unsupported(write: bool):
-    if write:
-        raise NotImplementedError("write=True (OBJ export, to_object/*) is outside the accelerated path")
+def _process_and_write(write: bool, result, case_name: str, output_dir: str, interpolation_steps: int,
+                       watertight: bool, contour_types):
+    """Processable::process_and_write (align.rs:19-61): a pair goes through process_case, a single
+    geometry through write_single_geometry."""
+    if not write:
+        return
+    from . import export as EX
+    from . import frames as FR
+    kinds = EX.DEFAULT_CONTOUR_TYPES if contour_types is None else contour_types
+    try:
+        if hasattr(result, "geom_a"):
+            EX.process_case(case_name, FR.to_frames(result.geom_a), FR.to_frames(result.geom_b), output_dir,
+                            interpolation_steps, watertight, kinds)
+        else:
+            EX.write_single_geometry(case_name, result, output_dir, watertight, kinds)
+    except RuntimeError as e:
+        raise RuntimeError(f"Failed to write obj: {e}") from e
 
 
 def _align_walls(geoms: Sequence[G.FlatGeometry], anomalous: bool) -> None:
@@ -254,7 +268,6 @@ def align_three_point(centerline: Centerline, geometry, main_ref_pt, countercloc
                       interpolation_steps: int = 0, output_dir: str = "output/aligned", contour_types=None,
                       case_name: str = "None", align_wall_anomalous: bool = False):
     """multimodars/_processing.py:1010-1103 -> (geometry, spacing_mm, total_rotation_deg)."""
-    _unsupported(write)
     geoms, rebuild = _unpack(geometry)
     pk = _ClPack(geoms)
     a, b, d = _v3(main_ref_pt), _v3(counterclockwise_ref_pt), _v3(clockwise_ref_pt)
@@ -264,14 +277,15 @@ def align_three_point(centerline: Centerline, geometry, main_ref_pt, countercloc
                                          math.radians(angle_step_deg), 0, C.byref(sp), C.byref(rot)),
             "align_three_point")
     _align_walls(geoms, align_wall_anomalous)                                   # align.rs:105-107
-    return rebuild(), sp.value, rot.value * (180.0 / math.pi)
+    out = rebuild()
+    _process_and_write(write, out, case_name, output_dir, interpolation_steps, watertight, contour_types)  # :109-121
+    return out, sp.value, rot.value * (180.0 / math.pi)
 
 
 def align_manual(centerline: Centerline, geometry, rotation_angle_deg: float, ref_point, write: bool = False,
                  watertight: bool = True, interpolation_steps: int = 0, output_dir: str = "output/aligned",
                  contour_types=None, case_name: str = "None", align_wall_anomalous: bool = False):
     """multimodars/_processing.py:1106-1188 -> (geometry, spacing_mm, total_rotation_deg)."""
-    _unsupported(write)
     geoms, rebuild = _unpack(geometry)
     pk = _ClPack(geoms)
     r = _v3(ref_point)
@@ -280,7 +294,9 @@ def align_manual(centerline: Centerline, geometry, rotation_angle_deg: float, re
                                     float(rotation_angle_deg), N._ptr(r), 0, C.byref(sp), C.byref(rot)),
             "align_manual")
     _align_walls(geoms, align_wall_anomalous)                                   # align.rs:147-149
-    return rebuild(), sp.value, rot.value * (180.0 / math.pi)
+    out = rebuild()
+    _process_and_write(write, out, case_name, output_dir, interpolation_steps, watertight, contour_types)  # :151-163
+    return out, sp.value, rot.value * (180.0 / math.pi)
 
 
 def align_combined(centerline: Centerline, geometry, main_ref_pt, counterclockwise_ref_pt, clockwise_ref_pt, points,
@@ -290,7 +306,6 @@ def align_combined(centerline: Centerline, geometry, main_ref_pt, counterclockwi
                    align_wall_anomalous: bool = False, engine: Optional[N.Engine] = None):
     """multimodars/_processing.py:1191-1300 -> (geometry, spacing_mm, total_rotation_deg).  The
     Hausdorff refinement grid ((2*index_range+1) x angles) is scored on the GPU."""
-    _unsupported(write)
     if engine is None:
         from .api import default_engine
         engine = default_engine()
@@ -309,4 +324,5 @@ def align_combined(centerline: Centerline, geometry, main_ref_pt, counterclockwi
     first = out.geom_a if hasattr(out, "geom_a") else out
     first.meta["refined_cl_ref_idx"] = int(ri.value)
     first.meta["refine_evals"] = int(ne.value)
+    _process_and_write(write, out, case_name, output_dir, interpolation_steps, watertight, contour_types)  # align.rs:270-282
     return out, sp.value, rot.value * (180.0 / math.pi)

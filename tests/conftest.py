@@ -13,6 +13,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _scratch_cwd(tmp_path, monkeypatch):
+    """The entry points write OBJ files to relative ``output/...`` directories by default, like the
+    reference (write_obj=True); every test runs in its own scratch directory."""
+    monkeypatch.chdir(tmp_path)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure; compiled on demand with gcc)."""

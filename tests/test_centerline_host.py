@@ -168,7 +168,5 @@ def test_align_errors(built, mm, case):
     g.has_ref[:] = 0
     with pytest.raises(RuntimeError, match="No reference point found"):
         mm.align_three_point(case["centerline"], g, case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"])
-    with pytest.raises(NotImplementedError):
-        mm.align_manual(case["centerline"], case["geometry"], 10.0, (0, 0, 0), write=True)
     with pytest.raises(TypeError):
         mm.align_manual(case["centerline"], object(), 10.0, (0, 0, 0))

@@ -169,10 +169,8 @@ def test_entry_point_errors(engine, mm):
     rest = os.path.join(GOLD, "ivus_rest")
     with pytest.raises(RuntimeError, match="sample_size must be > 0"):
         mm.from_file_single(rest, sample_size=0, engine=engine)
-    with pytest.raises(NotImplementedError, match="write_obj"):
-        mm.from_file_single(rest, write_obj=True, engine=engine)
-    with pytest.raises(NotImplementedError, match="write_obj"):
-        mm.from_file_singlepair(rest, write_obj=True, engine=engine)
+    with pytest.raises(RuntimeError, match="required contours file missing"):
+        mm.from_file_singlepair(os.path.join(GOLD, "nope"), engine=engine)
 
 
 def _array_input(mm, n_frames=12, n_points=120, drop=(), with_eem=False, thickness=None, seed=1):

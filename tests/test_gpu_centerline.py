@@ -115,6 +115,10 @@ def test_from_file_pair_then_align_manual(engine, oracle, ocl, mm):
     # the reference's defaults (postprocessing=True): both geometries trimmed to the common frame range
     # around the reference frame and resampled to one z spacing; walls present
     pair, _ = mm.from_file_singlepair(gold, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
+    # write_obj=True is the default, as in the reference: start + end geometry per contour type (entry.rs:655-670)
+    written = sorted(os.listdir(os.path.join("output", "singlepair")))
+    assert written == sorted(f"{k}_{i:03d}_{pair.label}.{e}" for k in ("lumen", "catheter", "wall") for i in (0, 1)
+                             for e in ("obj", "mtl", "png"))
     assert pair.geom_a.n_frames == pair.geom_b.n_frames <= min(raw.geom_a.n_frames, raw.geom_b.n_frames)
     assert np.allclose(pair.geom_a.centroids[:, 2], pair.geom_b.centroids[:, 2], atol=1e-9)
     assert np.allclose(np.diff(pair.geom_a.centroids[:, 2]), np.diff(pair.geom_a.centroids[:, 2])[0], atol=1e-9)
@@ -128,7 +132,8 @@ def test_from_file_pair_then_align_manual(engine, oracle, ocl, mm):
     s = np.arange(0.0, 40.0, 0.25)
     cl = mm.Centerline.from_contour_points(np.stack([20.0 + 4.0 * np.sin(s / 11.0), -150.0 + 0.2 * s, 900.0 - 0.9 * s], axis=1))
     ref = cl.xyz()[10]
-    out, sp, rot = mm.align_manual(cl, pair, 25.0, ref)
+    out, sp, rot = mm.align_manual(cl, pair, 25.0, ref, write=True, output_dir="aligned", case_name="case7")
+    assert "lumen_001_case7.obj" in os.listdir("aligned") and "wall_000_case7.png" in os.listdir("aligned")
     oa, ob = to_oracle(oracle, pair.geom_a), to_oracle(oracle, pair.geom_b)
     osp, orot = ocl.align_manual(to_oracle_cl(ocl, cl), [oa, ob], 25.0, ref)
     assert sp == osp and rot == orot * (180.0 / math.pi)
