@@ -65,6 +65,88 @@ class Centerline:
     def xyz(self) -> np.ndarray:
         return np.stack([self.points["x"], self.points["y"], self.points["z"]], axis=1)
 
+    # -- branches (centerline.rs: points of one branch are contiguous, branch 0 = main vessel) -------
+    def _branch_runs(self):
+        b = self.points["branch_id"]
+        if len(b) == 0:
+            return []
+        starts = [0] + [i for i in range(1, len(b)) if b[i] != b[i - 1]]
+        return [(s, e) for s, e in zip(starts, starts[1:] + [len(b)])]
+
+    def get_branch(self, branch_id: int) -> "Centerline":
+        """py_centerline.rs:211-232: the points of one branch as a single-branch centerline (branch 0)."""
+        sel = self.points[self.points["branch_id"] == branch_id].copy()
+        if sel.shape[0] == 0:
+            raise ValueError(f"branch_id {branch_id} not found in centerline")
+        sel["branch_id"] = 0
+        return Centerline(sel)
+
+    def mean_spacing(self) -> float:
+        """centerline.rs:304-320: mean distance of consecutive points of branch 0 (1.0 if fewer than two)."""
+        runs = self._branch_runs()
+        if not runs or runs[0][1] - runs[0][0] < 2:
+            return 1.0
+        xyz = self.xyz()[runs[0][0]:runs[0][1]]
+        d = xyz[1:] - xyz[:-1]
+        dist = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])
+        return float(np.add.accumulate(dist)[-1]) / float(len(dist))
+
+    def resample(self, spacing_mm: float) -> "Centerline":
+        """Centerline::resample (centerline.rs:717-796): every branch resampled to even arc-length spacing by
+        linear interpolation (samples at 0, s, 2s, ... and the end point), branch ids renumbered in order,
+        tangents recomputed as normalised forward differences inside a branch (:377-391).  Returns a new
+        centerline, like the Python binding (py_centerline.rs:287-296)."""
+        if len(self) == 0 or spacing_mm <= 1e-12:
+            return Centerline(self.points.copy())
+        out = []
+        for new_id, (s0, s1) in enumerate(self._branch_runs()):
+            pts = self.points[s0:s1]
+            xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1)
+            n = len(pts)
+            if n < 2:
+                res = pts.copy()
+            else:
+                cum = [0.0]
+                for i in range(1, n):
+                    d = xyz[i - 1] - xyz[i]                               # distance_to(other): self - other
+                    cum.append(cum[-1] + math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
+                total = cum[-1]
+                if total < 1e-12:
+                    res = pts.copy()
+                else:
+                    targets, s = [], 0.0
+                    while s < total:
+                        targets.append(s)
+                        s += spacing_mm
+                    targets.append(total)
+                    res = np.zeros(len(targets), dtype=CL_DTYPE)
+                    seg = 0
+                    for k, t in enumerate(targets):
+                        while seg < n - 2 and cum[seg + 1] < t:
+                            seg += 1
+                        a, b = cum[seg], cum[seg + 1]
+                        frac = 0.0 if abs(b - a) < 1e-12 else (t - a) / (b - a)
+                        p0, p1 = xyz[seg], xyz[seg + 1]
+                        res[k]["x"] = p0[0] + frac * (p1[0] - p0[0])
+                        res[k]["y"] = p0[1] + frac * (p1[1] - p0[1])
+                        res[k]["z"] = p0[2] + frac * (p1[2] - p0[2])
+                        res[k]["radius"] = pts["radius"][seg] + frac * (pts["radius"][seg + 1] - pts["radius"][seg])
+            res["branch_id"] = new_id
+            out.append(res)
+        pts = np.concatenate(out)
+        n = len(pts)
+        for i in range(n):                                                # recompute_tangents
+            if i + 1 < n and pts["branch_id"][i] == pts["branch_id"][i + 1]:
+                d = np.array([pts["x"][i + 1] - pts["x"][i], pts["y"][i + 1] - pts["y"][i], pts["z"][i + 1] - pts["z"][i]])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    t = d / math.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+            elif i > 0 and pts["branch_id"][i - 1] == pts["branch_id"][i]:
+                t = np.array([pts["tx"][i - 1], pts["ty"][i - 1], pts["tz"][i - 1]])
+            else:
+                t = np.zeros(3)
+            pts["tx"][i], pts["ty"][i], pts["tz"][i] = t
+        return Centerline(pts)
+
     def find_reference_cl_point_idx(self, reference_point) -> int:
         r = np.ascontiguousarray(np.asarray(reference_point, dtype=np.float64).reshape(3))
         return int(N.lib().mm_centerline_find_ref_idx(N._ptr(self.points), len(self), N._ptr(r)))

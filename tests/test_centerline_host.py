@@ -170,3 +170,22 @@ def test_align_errors(built, mm, case):
         mm.align_three_point(case["centerline"], g, case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"])
     with pytest.raises(TypeError):
         mm.align_manual(case["centerline"], object(), 10.0, (0, 0, 0))
+
+
+def test_centerline_resample_and_branches(built, mm):              # centerline.rs:1378-1403, py_centerline.rs:211-232
+    cl = mm.Centerline.from_contour_points([[0.0, 0, 0], [10.0, 0, 0]]).resample(2.5)
+    assert len(cl) == 5 and np.allclose(cl.points["x"], np.arange(5) * 2.5, atol=1e-9) and cl.points["x"][-1] == 10.0
+    assert np.allclose(cl.points["tx"], 1.0) and (cl.points["ty"] == 0.0).all()
+    two = mm.Centerline.from_arrays([[0, 0, 0], [10, 0, 0], [10, 0, 0], [10, 5, 0]], np.zeros((4, 3)), branch_id=[0, 0, 1, 1])
+    r = two.resample(2.0)
+    b = r.points["branch_id"]
+    assert sorted(set(b.tolist())) == [0, 1] and (np.diff(b) >= 0).all()
+    side = r.points[b == 1]
+    assert abs(side["y"][0]) < 1e-9 and side["x"].tolist() == [10.0] * len(side) and side["y"][-1] == 5.0
+    assert (r.points[b == 0]["x"] <= 10.0).all() and r.points[b == 0]["y"].max() == 0.0
+    main = r.get_branch(1)
+    assert (main.points["branch_id"] == 0).all() and len(main) == len(side)
+    with pytest.raises(ValueError, match="branch_id 7 not found"):
+        r.get_branch(7)
+    assert two.mean_spacing() == 10.0 and mm.Centerline.from_contour_points([[0.0, 0, 0], [3.0, 4.0, 0]]).mean_spacing() == 5.0
+    assert len(cl.resample(0.0)) == 5
