@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
-    ap.add_argument("--precision", default="fast", choices=["f32", "fast", "f64"],
+    ap.add_argument("--precision", default="fast", choices=["f32", "fast", "bounded", "f64"],
                     help="candidate scoring: f32 = direct-form f32 screen + exact f64 re-score; fast = expanded-form "
                          "f32 screen + exact f64 re-score (default); f64 = every candidate in exact f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,7 +183,8 @@ def main():
 
     cfg = WORKLOADS[args.workload]
     mode = 0 if args.mode == "chain" else 1
-    PREC = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "f64": mm.MM_PRECISION_F64}[args.precision]
+    PREC = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED,
+            "f64": mm.MM_PRECISION_F64}[args.precision]
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
     eng = mm.Engine(local_rank)
 
@@ -286,6 +287,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": {"f32": "f32 screen (direct form) + f64 exact re-score", "fast": "f32 screen (expanded form) + f64 exact re-score",
+                      "bounded": "f32 lower bound + f32 screen (expanded form) of the survivors + f64 exact re-score",
                       "f64": "f64"}[args.precision],
             "data": "synthetic",
             "config": {"workload": (f"{args.workload}: EXTENSION (not in the reference's 4-phase path) rotation x frame-shift "
@@ -302,6 +304,7 @@ def main():
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": committed_traffic(args.workload, args.precision),
                 "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33>",
+                           "bounded": "mm::k_screen_lb<5>",
                            "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "dominant_launch": dominant_launch(launch_ms, launch_pe),

@@ -46,9 +46,17 @@ enum {
     MM_PRECISION_F32 = 1, /* f32 screening of every candidate + f64 exact re-score of all
                              candidates within 2*delta of the f32 minimum; the winner and
                              its cost are bit-identical to MM_PRECISION_F64              */
-    MM_PRECISION_F32_FAST = 2 /* same contract; screening in the expanded distance form
+    MM_PRECISION_F32_FAST = 2, /* same contract; screening in the expanded distance form
                              |a|^2 + |b|^2 - 2ab (25 % fewer packed instructions; absolute error
                              5*2^-24*(rho_a+rho_b)^2 on the squared value -> wider shortlist) */
+    MM_PRECISION_F32_BOUNDED = 3 /* same contract (winner and cost bit-identical to MM_PRECISION_F64);
+                             before the expanded-form screen every candidate gets a LOWER bound of its
+                             Hausdorff distance from every k-th point of either set against all points
+                             of the other (2/k of the distance matrix), one full evaluation per pair
+                             gives an upper bound, and only candidates whose bound does not exceed it
+                             are screened and re-scored.  Candidates ruled out are never the minimum.
+                             Falls back to MM_PRECISION_F32_FAST when per-candidate costs are requested
+                             or a set exceeds the bound kernel's LDS budget                          */
 };
 
 /* flags of one search */

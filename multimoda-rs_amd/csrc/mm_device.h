@@ -47,8 +47,14 @@ struct BatchDev {
     double*   sq64;       // exact squared Hausdorff (valid where flag != 0 or in exact mode)
     uint8_t*  flag;       // 1 = shortlisted (re-scored in f64)
     // shortlist queue
-    WorkItem* items;      // capacity = total candidates
-    int32_t*  n_items;    // device counter
+    WorkItem* items;      // capacity = total candidates (bounded mode: first the survivors' runs)
+    int32_t*  n_items;    // device counters: [0] re-score queue, [1] picks, [2] survivor runs
+    // bounded screen (MM_PRECISION_F32_BOUNDED)
+    const WorkItem* work_lb;   // bound kernel's work list (more candidates per workgroup)
+    int32_t   n_work_lb, lb_stride;
+    float*    lb32;        // per-candidate lower bound of the screened squared value
+    int32_t*  pick_idx;    // per pair: candidate with the smallest bound (-1: no candidates)
+    WorkItem* items_pick;  // one queue entry per pair with candidates
     // per-pair results
     double*   best_cost;
     int32_t*  best_idx;
@@ -63,6 +69,15 @@ hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStre
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 int        max_rows_fast();
 int        max_target_points_fast();
+// bounded screen: lower bound of every candidate -> per-pair pick -> full screen of the picks ->
+// survivors -> full screen of the survivors (runs of <= 8 candidates, at most `cap` of them)
+hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStream_t s);
+hipError_t launch_lb_pick(const BatchDev& b, hipStream_t s);
+hipError_t launch_screen_picks(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
+hipError_t launch_lb_keep(const BatchDev& b, hipStream_t s);
+hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s);
+int        lb_max_query_points();   // subset size the bound kernel holds in registers
+int        lb_max_points();         // largest set (either side) the bound kernel stages in LDS
 // large-set Hausdorff (no LDS limit on the set sizes); pairs/work are device arrays of the kernel's
 // LargePair {a_off, na, b_off, nb, col_off, pad} / LargeWork {pair, row0} records
 hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pairs, int n_work, const double* px,

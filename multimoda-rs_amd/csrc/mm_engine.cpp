@@ -161,8 +161,11 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     want_costs = want_costs_;
     slice_end = angle_end;
     P = (int)pairs.size();
-    if (precision != MM_PRECISION_F64 && precision != MM_PRECISION_F32 && precision != MM_PRECISION_F32_FAST)
-        return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64, MM_PRECISION_F32 or MM_PRECISION_F32_FAST");
+    if (precision != MM_PRECISION_F64 && precision != MM_PRECISION_F32 && precision != MM_PRECISION_F32_FAST &&
+        precision != MM_PRECISION_F32_BOUNDED)
+        return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64, MM_PRECISION_F32, MM_PRECISION_F32_FAST or "
+                                         "MM_PRECISION_F32_BOUNDED");
+    const bool expanded = precision == MM_PRECISION_F32_FAST || precision == MM_PRECISION_F32_BOUNDED;
     if (angle_begin < 0) angle_begin = 0;
 
     host_pairs.assign(P, PairDesc{});
@@ -170,7 +173,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     pair_slice_end.assign(P, 0);
     host_tables.clear();
     A = 0; T = 0;
-    max_na = 1; max_nbp = 16;
+    max_na = 1; max_nbp = 16; max_nt = 1;
     pair_evals = 0.0;
     // table sharing: same list as the previous distinct table (pointer or content) and same slice
     const double* last_ptr = nullptr; int32_t last_n = -1, last_b = -1, last_tab = 0, last_len = -1;
@@ -196,7 +199,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
                       ? screen_delta(set_rho[sp.ref_set], set_rho[sp.tgt_set]) + sp.delta_extra : 0.0;
         {   // expanded-form screening: |d2_f32 - d2| <= 5 u (rho_a + rho_b)^2; we use 8 u (..)^2
             const double rs = set_rho[sp.ref_set] + set_rho[sp.tgt_set];
-            d.e2 = (precision == MM_PRECISION_F32_FAST) ? 8.0 * 5.9604644775390625e-08 * rs * rs : 0.0;
+            d.e2 = expanded ? 8.0 * 5.9604644775390625e-08 * rs * rs : 0.0;
         }
         if (nr == 0 || nt == 0) {
             // process_utils.rs:86-88: an empty set makes every cost 0.0 -> the first candidate wins;
@@ -221,14 +224,19 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         A += na;
         max_na = std::max<int>(max_na, nr);
         max_nbp = std::max<int>(max_nbp, (nt + 15) & ~15);
+        max_nt = std::max<int>(max_nt, nt);
         pair_evals += 2.0 * (double)nr * (double)nt * (double)na;
         if (A > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 candidates");
     }
     T = (int64_t)host_tables.size();
     // the fast screening kernel keeps one row block in registers; bigger sets use the direct form
-    use_fast = (precision == MM_PRECISION_F32_FAST) && max_na <= max_rows_fast() && max_nbp <= max_target_points_fast();
-    if (precision == MM_PRECISION_F32_FAST && !use_fast)
+    use_fast = expanded && max_na <= max_rows_fast() && max_nbp <= max_target_points_fast();
+    if (expanded && !use_fast)
         for (PairDesc& d : host_pairs) d.e2 = 0.0;
+    // the bound pass pays for itself on sets of a few dozen points or more; per-candidate costs need
+    // every candidate evaluated
+    use_lb = precision == MM_PRECISION_F32_BOUNDED && use_fast && !want_costs && A > 0 &&
+             std::min(max_na, max_nt) >= 64 && std::max(max_na, max_nt) <= lb_max_points();
     if (max_nbp > max_target_points_f64() || (precision != MM_PRECISION_F64 && max_nbp > max_target_points_f32()))
         return set_error(MM_ERR_TOO_LARGE, "target set does not fit the kernel's LDS budget (" +
                                                std::to_string(max_target_points_f64()) + " points)");
@@ -245,17 +253,37 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         for (int a0 = 0; a0 < d.n_ang; a0 += apb) host_work.push_back(WorkItem{p, a0, std::min(apb, d.n_ang - a0), 0});
     }
     W = (int)host_work.size();
+    host_work_lb.clear();
+    W_lb = 0; lb_runs_cap = 0; lb_pair_evals = 0.0;
+    if (use_lb) {
+        // every lb_stride-th point of either set is a query; the subset has to fit the kernel's registers
+        const int qmax = lb_max_query_points();
+        lb_stride = std::max(8, (std::max(max_na, max_nt) + qmax - 1) / qmax);
+        const int apb_lb = 32;   // 4 waves x 8 candidates: amortises staging the reference set
+        for (int p = 0; p < P; ++p) {
+            const PairDesc& d = host_pairs[p];
+            for (int a0 = 0; a0 < d.n_ang; a0 += apb_lb)
+                host_work_lb.push_back(WorkItem{p, a0, std::min(apb_lb, d.n_ang - a0), 0});
+            lb_runs_cap += (d.n_ang + 7) / 8;
+            const double qa = (d.n_ref + lb_stride - 1) / lb_stride, qb = (d.n_tgt + lb_stride - 1) / lb_stride;
+            lb_pair_evals += (qa * d.n_tgt + qb * d.n_ref) * (double)d.n_ang;
+        }
+        W_lb = (int)host_work_lb.size();
+    }
 
     // ---- layout ---------------------------------------------------------------------------
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + std::max<size_t>(bytes, 16)); return at; };
     const size_t o_pairs = take((size_t)P * sizeof(PairDesc));
     const size_t o_work = take((size_t)W * sizeof(WorkItem));
+    const size_t o_work_lb = take((size_t)W_lb * sizeof(WorkItem));
     const size_t o_c32 = take((size_t)T * 4), o_s32 = take((size_t)T * 4);
     const size_t o_c64 = take((size_t)T * 8), o_s64 = take((size_t)T * 8);
     lvl_in_bytes = o;
     const size_t o_sq32 = take((size_t)A * 4), o_sq64 = take((size_t)A * 8), o_flag = take((size_t)A);
     const size_t o_items = take((size_t)A * sizeof(WorkItem)), o_nitems = take(16);
+    const size_t o_lb32 = take(use_lb ? (size_t)A * 4 : 0), o_pick = take(use_lb ? (size_t)P * 4 : 0);
+    const size_t o_items_pick = take(use_lb ? (size_t)P * sizeof(WorkItem) : 0);
     const size_t o_bc = take((size_t)P * 8), o_bi = take((size_t)P * 4), o_nr = take((size_t)P * 4);
     const size_t o_nc = take((size_t)P * 4), o_ni = take((size_t)P * 4 * kMaxNear);
     off_best_cost = o_bc; res_bytes = o - o_bc;
@@ -276,6 +304,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     }
     if (P) std::memcpy(h + o_pairs, host_pairs.data(), (size_t)P * sizeof(PairDesc));
     if (W) std::memcpy(h + o_work, host_work.data(), (size_t)W * sizeof(WorkItem));
+    if (W_lb) std::memcpy(h + o_work_lb, host_work_lb.data(), (size_t)W_lb * sizeof(WorkItem));
 
     if (transient) {
         rc = e->ensure(e->dev_lvl, lvl_bytes, false);
@@ -296,6 +325,8 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     dev.cos64 = (const double*)(B + o_c64); dev.sin64 = (const double*)(B + o_s64);
     dev.sq32 = (float*)(B + o_sq32); dev.sq64 = (double*)(B + o_sq64); dev.flag = (uint8_t*)(B + o_flag);
     dev.items = (WorkItem*)(B + o_items); dev.n_items = (int32_t*)(B + o_nitems);
+    dev.work_lb = (const WorkItem*)(B + o_work_lb); dev.n_work_lb = W_lb; dev.lb_stride = lb_stride;
+    dev.lb32 = (float*)(B + o_lb32); dev.pick_idx = (int32_t*)(B + o_pick); dev.items_pick = (WorkItem*)(B + o_items_pick);
     dev.best_cost = (double*)(B + o_bc); dev.best_idx = (int32_t*)(B + o_bi); dev.n_rescored = (int32_t*)(B + o_nr);
     dev.near_cnt = (int32_t*)(B + o_nc); dev.near_idx = (int32_t*)(B + o_ni);
     dev.all_costs = want_costs ? (double*)(B + off_all_costs) : nullptr;
@@ -312,10 +343,26 @@ int Plan::run(bool screen_only)
     hipError_t e;
     int prc;
     if (precision != MM_PRECISION_F64) {
-        if ((prc = eng->profile_begin())) return prc;
-        e = use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s);
-        if (e != hipSuccess) return hip_error(e, "screen kernel launch");
-        if ((prc = eng->profile_end(pair_evals, A))) return prc;
+        if (use_lb) {
+            // bound every candidate, fully screen one per pair, then only those the bound cannot rule out
+            MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
+            if ((prc = eng->profile_begin())) return prc;
+            e = launch_screen_lb(dev, (max_na + 31) & ~31, (max_nt + 31) & ~31, s);
+            if (e != hipSuccess) return hip_error(e, "bound kernel launch");
+            if ((prc = eng->profile_end(lb_pair_evals, A))) return prc;
+            if ((prc = eng->profile_begin())) return prc;
+            if ((e = launch_lb_pick(dev, s)) != hipSuccess) return hip_error(e, "pick kernel launch");
+            if ((e = launch_screen_picks(dev, max_na, max_nbp, s)) != hipSuccess) return hip_error(e, "screen kernel launch (picks)");
+            if ((e = launch_lb_keep(dev, s)) != hipSuccess) return hip_error(e, "keep kernel launch");
+            if ((e = launch_screen_kept(dev, max_na, max_nbp, lb_runs_cap, s)) != hipSuccess)
+                return hip_error(e, "screen kernel launch (survivors)");
+            if ((prc = eng->profile_end(0.0, 0))) return prc;
+        } else {
+            if ((prc = eng->profile_begin())) return prc;
+            e = use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s);
+            if (e != hipSuccess) return hip_error(e, "screen kernel launch");
+            if ((prc = eng->profile_end(pair_evals, A))) return prc;
+        }
         if (screen_only) return MM_OK;
         MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
         e = launch_shortlist(dev, s);

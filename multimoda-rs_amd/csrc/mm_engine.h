@@ -90,6 +90,10 @@ struct Plan {
     std::vector<uint8_t> trivial;             // pair has an empty set: every cost is 0.0
     bool want_costs = false;
     bool use_fast = false;                    // expanded-form screening kernel selected
+    bool use_lb = false;                      // lower-bound pass in front of the screen (MM_PRECISION_F32_BOUNDED)
+    int W_lb = 0, lb_stride = 0, lb_runs_cap = 0, max_nt = 1;
+    double lb_pair_evals = 0.0;               // pair-distances of the bound pass
+    std::vector<WorkItem> host_work_lb;
 
     int stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient);
     int stage_level(const std::vector<PairSpec>& pairs, int precision, int32_t angle_begin, int32_t angle_end,

@@ -376,7 +376,8 @@ static __device__ __forceinline__ int dpp_min_i32(int v)
 
 template <int R>
 __global__ void __launch_bounds__(256, 3)
-k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
+k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
+              int n_work_host, const int* __restrict__ n_work_dev,
               const float* __restrict__ ptx, const float* __restrict__ pty,
               const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
 {
@@ -385,6 +386,7 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
     constexpr bool ODD = (R & 1) != 0;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lj = tid & 15, li = tid >> 4;
+    const int n_work = n_work_dev ? *n_work_dev : n_work_host;   // device queue: workgroups stride over it
 
     for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
          wi += gridDim.x) {
@@ -495,6 +497,217 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
             if ((tid & 63) == 0) atomicMax(&s_red[0], m);
             __syncthreads();  // S3
             if (tid == 0) out_sq[pd.out_off + a] = __int_as_float(s_red[0]);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Bounded screen.  For subsets A' of the reference set and B' of the target set,
+//     L = max( max_{a in A'} min_{b in B} d(a,b),  max_{b in B'} min_{a in A} d(a,b) )  <=  H(A,B):
+// both terms take the outer max of a directed distance over fewer points and the inner min over
+// all of them, so L never exceeds the Hausdorff distance, for any subsets.  With every k-th point
+// (k = stride) it costs 2/k of the full distance matrix and, the contours being smooth, lies
+// within a few percent of H -- close enough that one full evaluation per pair (at the candidate
+// with the smallest L) gives an upper bound that rules out ~97-99 % of the candidates.  The
+// survivors go through k_screen_fast and the exact f64 re-score as before, so winners are
+// unchanged; L only decides what is NOT evaluated, under the same error bounds (PairDesc::delta,
+// e2) that relate every f32 squared distance to its f64 value.
+//
+// One wave scores one candidate at a time (no workgroup barrier in the candidate loop): it rotates
+// the target into its own LDS slice, then runs two passes of the same primitive -- a small query
+// set in registers (16 column lanes x 4 row groups x 2 RP rows) against a large set in LDS:
+//     e(q,p) = |p|^2 - 2 q.p   (2 v_pk_fma_f32 + 1 v_min3_f32 per two distances; + |q|^2 after the min)
+// pass 1: queries A' (fixed per work item), points = rotated B; pass 2: queries = rotated B', points A.
+// -------------------------------------------------------------------------------------
+static constexpr int kLbRP = 5;   // row PAIRS per row group: query sets up to 8 * kLbRP points
+
+static __device__ __forceinline__ float fmin3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // finite inputs only
+    return r;
+}
+
+// max over this wave's queries of (min over the n_groups*16 points of e) + |q|^2, as an int bit
+// pattern floored at +0 (same convention as k_screen_fast); identical in all 64 lanes
+template <int RP>
+static __device__ __forceinline__ int lb_pass(const v2f (&qx)[RP], const v2f (&qy)[RP], const v2f (&q2)[RP],
+                                              const float4* __restrict__ s_p, int n_groups, int lj)
+{
+    v2f rm[RP];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) rm[q] = (v2f)(__int_as_float(0x7f800000));
+    for (int k = 0; k < n_groups; k += 2) {   // n_groups is even (sets are padded to 32 points)
+        const float4 p0 = s_p[k * 16 + lj];
+        const float4 p1 = s_p[(k + 1) * 16 + lj];
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+            const v2f t0 = __builtin_elementwise_fma(qy[q], (v2f)(p0.y), (v2f)(p0.z));
+            const v2f t1 = __builtin_elementwise_fma(qy[q], (v2f)(p1.y), (v2f)(p1.z));
+            const v2f e0 = __builtin_elementwise_fma(qx[q], (v2f)(p0.x), t0);
+            const v2f e1 = __builtin_elementwise_fma(qx[q], (v2f)(p1.x), t1);
+            rm[q].x = fmin3_f32(rm[q].x, e0.x, e1.x);
+            rm[q].y = fmin3_f32(rm[q].y, e0.y, e1.y);
+        }
+    }
+    int m = 0;
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+        const v2f d = rm[q] + q2[q];
+        int v = __float_as_int(d.x);
+        v = dpp_min_i32<0xB1>(v); v = dpp_min_i32<0x4E>(v); v = dpp_min_i32<0x141>(v); v = dpp_min_i32<0x140>(v);
+        m = v > m ? v : m;
+        v = __float_as_int(d.y);
+        v = dpp_min_i32<0xB1>(v); v = dpp_min_i32<0x4E>(v); v = dpp_min_i32<0x141>(v); v = dpp_min_i32<0x140>(v);
+        m = v > m ? v : m;
+    }
+    int o = __shfl_xor(m, 16, 64); m = o > m ? o : m;
+    o = __shfl_xor(m, 32, 64); m = o > m ? o : m;
+    return m;
+}
+
+template <int RP>
+__global__ void __launch_bounds__(256, 2)
+k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work, int stride,
+            const float* __restrict__ ptx, const float* __restrict__ pty,
+            const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_lb)
+{
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 15, li = lane >> 4;
+
+    for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
+         wi += gridDim.x) {
+        const WorkItem w = work[wi];
+        const PairDesc pd = pairs[w.pair];
+        const int na = pd.n_ref, nb = pd.n_tgt;
+        const int nap = (na + 31) & ~31, nbp = (nb + 31) & ~31;
+        const int qa = (na + stride - 1) / stride, qb = (nb + stride - 1) / stride;   // <= 8 RP (host)
+
+        float4* s_a = reinterpret_cast<float4*>(smem);                 // (ax, ay, |a|^2, 0), shared
+        float2* s_tgt = reinterpret_cast<float2*>(s_a + nap);          // unrotated target, shared
+        float4* s_b = reinterpret_cast<float4*>(s_tgt + nbp) + (size_t)wave * nbp;   // this wave's rotated target
+
+        __syncthreads();   // the previous item's readers are done
+        // padding entries duplicate the last point: no effect on a minimum over the set
+        for (int i = tid; i < nap; i += NT) {
+            const int ic = i < na ? i : na - 1;
+            const float x = ptx[pd.ref_off + ic], y = pty[pd.ref_off + ic];
+            s_a[i] = make_float4(x, y, __builtin_fmaf(x, x, y * y), 0.0f);
+        }
+        for (int j = tid; j < nbp; j += NT) {
+            const int jc = j < nb ? j : nb - 1;
+            s_tgt[j] = make_float2(ptx[pd.tgt_off + jc], pty[pd.tgt_off + jc]);
+        }
+        // pass-1 queries: every stride-th reference point; rows past the subset repeat its last point
+        // (no effect on the maximum over the subset)
+        v2f ax[RP], ay[RP], a2[RP];
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = li * (2 * RP) + 2 * q + h;
+                const int idx = (row < qa ? row : qa - 1) * stride;
+                const float x = ptx[pd.ref_off + idx], y = pty[pd.ref_off + idx];
+                const float n2 = __builtin_fmaf(x, x, y * y);
+                if (h) { ax[q].y = -2.0f * x; ay[q].y = -2.0f * y; a2[q].y = n2; }
+                else   { ax[q].x = -2.0f * x; ay[q].x = -2.0f * y; a2[q].x = n2; }
+            }
+        }
+        __syncthreads();
+
+        for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
+            const float c = cosv[pd.tab_off + a], s = sinv[pd.tab_off + a];
+            for (int j = lane; j < nbp; j += 64) {
+                const float2 t = s_tgt[j];
+                float4 b;
+                b.x = __builtin_fmaf(t.x, c, -(t.y * s));
+                b.y = __builtin_fmaf(t.x, s, t.y * c);
+                b.z = __builtin_fmaf(b.x, b.x, b.y * b.y);
+                b.w = 0.0f;
+                s_b[j] = b;
+            }
+            // the slice is private to this wave: its LDS writes only have to land before its own reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+            const int m1 = lb_pass<RP>(ax, ay, a2, s_b, nbp >> 4, lj);
+
+            v2f bx[RP], by[RP], b2[RP];
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = li * (2 * RP) + 2 * q + h;
+                    const float4 b = s_b[(row < qb ? row : qb - 1) * stride];
+                    if (h) { bx[q].y = -2.0f * b.x; by[q].y = -2.0f * b.y; b2[q].y = b.z; }
+                    else   { bx[q].x = -2.0f * b.x; by[q].x = -2.0f * b.y; b2[q].x = b.z; }
+                }
+            }
+            const int m2 = lb_pass<RP>(bx, by, b2, s_a, nap >> 4, lj);
+
+            if (lane == 0) out_lb[pd.out_off + a] = __int_as_float(m1 > m2 ? m1 : m2);
+            __builtin_amdgcn_wave_barrier();   // all reads of the slice precede the next candidate's writes
+        }
+    }
+}
+
+// Per pair: the candidate with the smallest bound (first one on ties) is queued for a full
+// screen evaluation; its value is the pair's upper bound.
+__global__ void __launch_bounds__(256)
+k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, int32_t* __restrict__ pick_idx,
+          WorkItem* __restrict__ items, int* __restrict__ n_items)
+{
+    __shared__ unsigned long long s_key;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const PairDesc pd = pairs[p];
+    if (pd.n_ang <= 0) { if (tid == 0) pick_idx[p] = -1; return; }
+    if (tid == 0) s_key = ~0ull;
+    __syncthreads();
+    unsigned long long key = ~0ull;
+    for (int a = tid; a < pd.n_ang; a += 256) {
+        const unsigned long long k = ((unsigned long long)__float_as_uint(lb32[pd.out_off + a]) << 32) | (unsigned)a;
+        key = k < key ? k : key;
+    }
+    atomicMin(&s_key, key);
+    __syncthreads();
+    if (tid == 0) {
+        const int a = (int)(s_key & 0xffffffffull);
+        pick_idx[p] = a;
+        const int slot = atomicAdd(n_items, 1);
+        WorkItem w; w.pair = p; w.a0 = a; w.cnt = 1; w.pad = 0;
+        items[slot] = w;
+    }
+}
+
+// Per pair: a candidate survives if the smallest exact cost its bound allows does not exceed the
+// largest exact cost the picked candidate can have (same interval arithmetic as k_shortlist).
+// Survivors are queued as runs inside aligned groups of 8 candidates; every other candidate gets
+// +inf as its screened value, which k_shortlist never keeps.
+__global__ void __launch_bounds__(256)
+k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, float* __restrict__ sq32,
+          const int32_t* __restrict__ pick_idx, WorkItem* __restrict__ items, int* __restrict__ n_items)
+{
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const PairDesc pd = pairs[p];
+    if (pd.n_ang <= 0) return;
+    const int c1 = pick_idx[p];
+    const double ub = sqrt((double)sq32[pd.out_off + c1] + pd.e2) + 2.0 * pd.delta;
+    for (int g = tid; g * 8 < pd.n_ang; g += 256) {
+        const int lo = g * 8, hi = (lo + 8 < pd.n_ang) ? lo + 8 : pd.n_ang;
+        int first = -1, last = -1;
+        for (int a = lo; a < hi; ++a) {
+            const double sv = (double)lb32[pd.out_off + a] - pd.e2;
+            if (a == c1 || sqrt(sv > 0.0 ? sv : 0.0) <= ub) { if (first < 0) first = a; last = a; }
+        }
+        for (int a = lo; a < hi; ++a)
+            if (a < first || a > last) sq32[pd.out_off + a] = __int_as_float(0x7f800000);
+        if (first >= 0) {
+            const int slot = atomicAdd(n_items, 1);
+            WorkItem w; w.pair = p; w.a0 = first; w.cnt = last - first + 1; w.pad = 0;
+            items[slot] = w;
         }
     }
 }
@@ -793,8 +1006,12 @@ size_t lds_bytes_fast(int nbp) { return (size_t)nbp * (16 + 8 + 4) + 16; }
 int max_rows_fast() { return 16 * 33; }
 int max_target_points_fast() { return ((LDS_CAP - 16) / 28) & ~15; }
 
+// Work from the host-built table (n_dev == nullptr: one workgroup per item -- a persistent grid
+// measured slower on the big launch) or from a device queue of at most `cap` items whose length is
+// *n_dev (a bounded grid strides over it).
 template <int Rv>
-static hipError_t launch_fast_r(const BatchDev& b, int max_nbp, hipStream_t s)
+static hipError_t launch_fast_r(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
+                                int max_nbp, hipStream_t s)
 {
     auto kern = k_screen_fast<Rv>;
     const size_t lds = lds_bytes_fast(max_nbp);
@@ -803,21 +1020,74 @@ static hipError_t launch_fast_r(const BatchDev& b, int max_nbp, hipStream_t s)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // one workgroup per work item: a persistent grid (grid-stride over the items) measured slower
-    const int grid = b.n_work;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y,
+    const int grid = n_dev ? std::min(cap, 256 * 12) : n_host;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, work, n_host, n_dev, b.p32x, b.p32y,
                        b.cos32, b.sin32, b.sq32);
     return hipGetLastError();
+}
+
+static hipError_t launch_fast_any(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
+                                  int max_na, int max_nbp, hipStream_t s)
+{
+    if (max_na <= 16 * 8) return launch_fast_r<8>(b, work, n_host, n_dev, cap, max_nbp, s);
+    if (max_na <= 16 * 14) return launch_fast_r<14>(b, work, n_host, n_dev, cap, max_nbp, s);
+    if (max_na <= 16 * 20) return launch_fast_r<20>(b, work, n_host, n_dev, cap, max_nbp, s);
+    if (max_na <= 16 * 26) return launch_fast_r<26>(b, work, n_host, n_dev, cap, max_nbp, s);
+    return launch_fast_r<33>(b, work, n_host, n_dev, cap, max_nbp, s);
 }
 
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
 {
     if (b.n_work <= 0) return hipSuccess;
-    if (max_na <= 16 * 8) return launch_fast_r<8>(b, max_nbp, s);
-    if (max_na <= 16 * 14) return launch_fast_r<14>(b, max_nbp, s);
-    if (max_na <= 16 * 20) return launch_fast_r<20>(b, max_nbp, s);
-    if (max_na <= 16 * 26) return launch_fast_r<26>(b, max_nbp, s);
-    return launch_fast_r<33>(b, max_nbp, s);
+    return launch_fast_any(b, b.work, b.n_work, nullptr, 0, max_na, max_nbp, s);
+}
+
+// ---- bounded screen (k_screen_lb -> pick -> screen the picks -> keep -> screen the survivors) ----
+int lb_max_query_points() { return 8 * kLbRP; }
+int lb_max_points() { return 1024; }
+size_t lds_bytes_lb(int nap, int nbp) { return (size_t)nap * 16 + (size_t)nbp * (8 + 4 * 16); }
+
+hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStream_t s)
+{
+    if (b.n_work_lb <= 0) return hipSuccess;
+    auto kern = k_screen_lb<kLbRP>;
+    const size_t lds = lds_bytes_lb(max_nap, max_nbp);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(b.n_work_lb), dim3(256), lds, s, b.pairs, b.work_lb, b.n_work_lb, b.lb_stride,
+                       b.p32x, b.p32y, b.cos32, b.sin32, b.lb32);
+    return hipGetLastError();
+}
+
+hipError_t launch_lb_pick(const BatchDev& b, hipStream_t s)
+{
+    if (b.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lb_pick, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.pick_idx, b.items_pick,
+                       b.n_items + 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_screen_picks(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
+{
+    if (b.n_pairs <= 0) return hipSuccess;
+    return launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, s);
+}
+
+hipError_t launch_lb_keep(const BatchDev& b, hipStream_t s)
+{
+    if (b.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lb_keep, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx, b.items,
+                       b.n_items + 2);
+    return hipGetLastError();
+}
+
+hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s)
+{
+    if (cap <= 0) return hipSuccess;
+    return launch_fast_any(b, b.items, 0, b.n_items + 2, cap, max_na, max_nbp, s);
 }
 
 template <bool FROM_QUEUE>

@@ -452,7 +452,7 @@ def test_fast_precision_ties_and_identical_sets(engine, oracle, mm):
     assert out[0] == int(np.argmin(oc)) and out[2] == oc.min()
 
 
-@pytest.mark.parametrize("precision", [0, 1, 2])
+@pytest.mark.parametrize("precision", [0, 1, 2, 3])
 def test_near_ties_between_neighbouring_candidates(engine, oracle, mm, precision):
     """Adversarial for the screen-then-exact scheme: the true rotation sits (almost) exactly between
     two grid candidates, so their costs differ by ~1e-9 .. 1e-5 -- far below the f32 screening error.
@@ -479,6 +479,88 @@ def test_near_ties_between_neighbouring_candidates(engine, oracle, mm, precision
         srt = np.sort(oc)
         n_close += int(srt[1] - srt[0] < 1e-6)
     assert n_close >= 8     # the scenario really produces near-ties
+
+
+# ---------------------------------------------------------------------------------------
+# MM_PRECISION_F32_BOUNDED: a lower bound rules candidates out before the screen; winners and costs
+# must still be the oracle's, bit for bit
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,step,rng_deg", [(64, 1.0, 180.0), (100, 1.0, 180.0), (208, 0.5, 90.0), (320, 1.0, 180.0),
+                                            (521, 0.5, 180.0), (528, 1.0, 90.0)])
+def test_bounded_screen_winner_bit_exact_and_prunes(engine, oracle, mm, n, step, rng_deg):
+    rng = np.random.default_rng(4000 + n)
+    ref = blob(rng, n)
+    tgt = blob(rng, n) + rng.normal(0, 0.02, (n, 2))
+    c = ref.mean(axis=0)
+    centre = (float(c[0]), float(c[1]))
+    angles, _, _ = mm.search_angles(step, rng_deg)
+    batch = mm.Batch([ref], [tgt], [angles], [centre], [1])
+    out = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32_BOUNDED)
+    full = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32_FAST)
+    ocosts = oracle.costs_over_angles(ref, tgt, angles, centre[0], centre[1])
+    obi = int(np.argmin(ocosts))
+    assert out["best_idx"][0] == obi and out["best_angle"][0] == angles[obi] and out["best_cost"][0] == ocosts[obi]
+    # the bound never widens the exact re-score set
+    assert 1 <= out["n_rescored"][0] <= full["n_rescored"][0]
+
+
+def test_bounded_screen_mixed_batch(engine, oracle, mm):
+    """Pairs of very different sizes, an empty set, different candidate lists and unordered point sets
+    (any subset gives a valid bound; order only affects how tight it is) in one batch."""
+    rng = np.random.default_rng(4100)
+    a1, _, _ = mm.search_angles(1.0, 180.0)
+    a2, _, _ = mm.search_angles(0.5, 45.0)
+    refs, tgts, angs, cs = [], [], [], []
+    for n, m, ang, shuffle in [(521, 521, a1, False), (70, 400, a2, False), (400, 70, a1, False), (300, 300, a2, True),
+                               (128, 0, a1, False), (9, 12, a2, False), (528, 100, a1, True)]:
+        r = blob(rng, n)
+        t = blob(rng, m) if m else np.zeros((0, 2))
+        if shuffle:
+            rng.shuffle(r); rng.shuffle(t)
+        refs.append(r); tgts.append(t); angs.append(ang); cs.append((4.5, 4.5))
+    batch = mm.Batch(refs, tgts, angs, cs, [1] * len(refs))
+    out = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32_BOUNDED)
+    for p, (r, t, ang) in enumerate(zip(refs, tgts, angs)):
+        oc = oracle.costs_over_angles(r, t, ang, 4.5, 4.5)
+        k = int(np.argmin(oc))
+        assert out["best_idx"][p] == k and out["best_cost"][p] == oc[k], p
+
+
+def test_bounded_screen_with_costs_falls_back_to_full_screen(engine, oracle, mm):
+    rng = np.random.default_rng(4200)
+    ref, tgt = blob(rng, 200), blob(rng, 200)
+    angles, _, _ = mm.search_angles(2.0, 180.0)
+    bi, ba, bc, costs = engine.best_rotation(ref, tgt, angles, (4.5, 4.5), precision=mm.MM_PRECISION_F32_BOUNDED,
+                                             return_costs=True)
+    oc = oracle.costs_over_angles(ref, tgt, angles, 4.5, 4.5)
+    assert bi == int(np.argmin(oc)) and bc == oc.min()
+    assert np.all(np.isfinite(costs)) and np.abs(costs - oc).max() < 5e-3
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", [(True, 1.0, 180.0, 501), (False, 0.05, 45.0, 200), (True, 0.5, 180.0, 500)])
+def test_bounded_precision_chain_bit_identical(engine, oracle, mm, mode, bruteforce, step, rng_deg, ss):
+    geoms = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((8, 6, 7, 5))]
+    ogeoms = [to_oracle(oracle, g) for g in geoms]
+    logs, _ = mm.align_within(engine, geoms, step, rng_deg, bruteforce, ss, precision=mm.MM_PRECISION_F32_BOUNDED, mode=mode)
+    for g, og, lg in zip(geoms, ogeoms, logs):
+        assert lg == oracle.align_within_chain(og, step, rng_deg, bruteforce, ss, n_threads=8)
+        assert geoms_equal(g, og)
+
+
+def test_bounded_precision_ties_and_identical_sets(engine, oracle, mm):
+    t = np.arange(360) * (2 * math.pi / 360)
+    ref = np.stack([4.5 + 2 * np.cos(t) * (1 + 0.2 * np.cos(3 * t)), 4.5 + 2 * np.sin(t)], 1)
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    for tgt in (ref.copy(), np.roll(ref, 7, axis=0)):
+        oc = oracle.costs_over_angles(ref, tgt, angles, 4.5, 4.5)
+        out = engine.best_rotation(ref, tgt, angles, (4.5, 4.5), precision=mm.MM_PRECISION_F32_BOUNDED)
+        assert out[0] == int(np.argmin(oc)) and out[2] == oc.min()
+    # a circle against itself: every candidate costs (about) the same, nothing can be ruled out
+    circ = np.stack([4.5 + 2 * np.cos(t), 4.5 + 2 * np.sin(t)], 1)
+    oc = oracle.costs_over_angles(circ, circ, angles, 4.5, 4.5)
+    out = engine.best_rotation(circ, circ, angles, (4.5, 4.5), precision=mm.MM_PRECISION_F32_BOUNDED)
+    assert out[0] == int(np.argmin(oc)) and out[2] == oc.min()
 
 
 # ---------------------------------------------------------------------------------------
