@@ -261,6 +261,7 @@ def main():
     if os.environ.get("MM_TRACE"):
         print(f"[bench trace] final barrier {1e3 * (time.perf_counter() - tb):.3f} ms, total {1e3 * dt:.3f} ms", file=sys.stderr)
     launch_ms, launch_pe = eng.profile_launches()
+    bound = eng.bound_stats() if args.precision == "bounded" else None
     prof = eng.profile_read()
     eng.profile(False)
 
@@ -317,6 +318,8 @@ def main():
                         "note": "algorithmic no-reuse bytes ((Na+Nb)*8+8 per pose-eval) / kernel time"},
             },
         }
+        if bound is not None:
+            out["config"]["bounded_screen"] = bound
         if not args.no_cpu_baseline and world == 1:
             try:
                 avail = len(os.sched_getaffinity(0))

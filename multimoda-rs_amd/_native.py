@@ -25,7 +25,7 @@ MM_SEARCH_SKIP_ZERO = 1
 EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
     "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream",
-    "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches",
+    "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches", "mm_engine_bound_stats",
     "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
     "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_create_indexed", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
@@ -140,6 +140,8 @@ def lib():
     L.mm_engine_profile_read.argtypes = [P, C.POINTER(I64), C.POINTER(D), C.POINTER(D), C.POINTER(I64)]
     L.mm_engine_profile_launches.restype = I
     L.mm_engine_profile_launches.argtypes = [P, I64, P, P, C.POINTER(I64)]
+    L.mm_engine_bound_stats.restype = I
+    L.mm_engine_bound_stats.argtypes = [P, P]
     L.mm_hausdorff_2d.restype = I
     L.mm_hausdorff_2d.argtypes = [P, P, P, I, P, P, I, C.POINTER(D)]
     L.mm_hausdorff_batch.restype = I
@@ -415,6 +417,14 @@ class Engine:
         check(lib().mm_engine_profile_launches(self._h, cap, _ptr(ms), _ptr(pe), C.byref(n)), "mm_engine_profile_launches")
         k = min(int(n.value), cap)
         return ms[:k].astype(np.float64), pe[:k]
+
+    def bound_stats(self):
+        """MM_PRECISION_F32_BOUNDED since profile(True): candidates offered, lower-bounded in the sparse round,
+        lower-bounded in the second round, and fully screened."""
+        out = np.zeros(4, dtype=np.int64)
+        check(lib().mm_engine_bound_stats(self._h, _ptr(out)), "mm_engine_bound_stats")
+        return {"offered": int(out[0]), "bounded_round1": int(out[1]), "bounded_round2": int(out[2]),
+                "screened": int(out[3])}
 
     def profile_read(self):
         n, ms, pe, ca = C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_int64(0)

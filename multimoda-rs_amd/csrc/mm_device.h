@@ -23,6 +23,7 @@ struct PairDesc {
     double  delta;            // f32 screening error bound (same unit as the costs)
     double  tol2;             // candidates within tol2 of the exact minimum are reported as near-ties
     double  e2;               // absolute error bound of the screened SQUARED value (fast kernel; else 0)
+    double  rho_t;            // largest distance of a target point from the rotation centre
 };
 
 // One workgroup's share: `cnt` consecutive candidates of one pair.
@@ -48,13 +49,14 @@ struct BatchDev {
     uint8_t*  flag;       // 1 = shortlisted (re-scored in f64)
     // shortlist queue
     WorkItem* items;      // capacity = total candidates (bounded mode: first the survivors' runs)
-    int32_t*  n_items;    // device counters: [0] re-score queue, [1] picks, [2] survivor runs
+    int32_t*  n_items;    // device counters: [0] re-score queue, [1] picks, [2] second bound round, [3] survivor runs
     // bounded screen (MM_PRECISION_F32_BOUNDED)
     const WorkItem* work_lb;   // bound kernel's work list (more candidates per workgroup)
     int32_t   n_work_lb, lb_stride;
     float*    lb32;        // per-candidate lower bound of the screened squared value
     int32_t*  pick_idx;    // per pair: candidate with the smallest bound (-1: no candidates)
     WorkItem* items_pick;  // one queue entry per pair with candidates
+    unsigned long long* stats;  // nullable: [1] candidates bounded in round 2, [2] candidates fully screened
     // per-pair results
     double*   best_cost;
     int32_t*  best_idx;
@@ -69,12 +71,18 @@ hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStre
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 int        max_rows_fast();
 int        max_target_points_fast();
-// bounded screen: lower bound of every candidate -> per-pair pick -> full screen of the picks ->
-// survivors -> full screen of the survivors (runs of <= 8 candidates, at most `cap` of them)
+// bounded screen: lower bound of every lb_candidate_step()-th candidate -> per-pair pick -> full screen of
+// the picks (upper bound) -> spread the bounds to the candidates in between (chord inequality) ->
+// lower bound of those still possible -> survivors -> full screen of the survivors (runs of <= 8
+// candidates, at most `cap` of them)
 hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStream_t s);
 hipError_t launch_lb_pick(const BatchDev& b, hipStream_t s);
 hipError_t launch_screen_picks(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
+hipError_t launch_lb_spread(const BatchDev& b, hipStream_t s);
+hipError_t launch_screen_lb_queued(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s);
 hipError_t launch_lb_keep(const BatchDev& b, hipStream_t s);
+int        lb_candidate_step();
+int        lb_sparse_candidates(int n);   // candidates of a list of n the first round scores
 hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s);
 int        lb_max_query_points();   // subset size the bound kernel holds in registers
 int        lb_max_points();         // largest set (either side) the bound kernel stages in LDS

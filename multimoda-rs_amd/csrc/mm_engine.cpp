@@ -200,6 +200,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         {   // expanded-form screening: |d2_f32 - d2| <= 5 u (rho_a + rho_b)^2; we use 8 u (..)^2
             const double rs = set_rho[sp.ref_set] + set_rho[sp.tgt_set];
             d.e2 = expanded ? 8.0 * 5.9604644775390625e-08 * rs * rs : 0.0;
+            d.rho_t = set_rho[sp.tgt_set];
         }
         if (nr == 0 || nt == 0) {
             // process_utils.rs:86-88: an empty set makes every cost 0.0 -> the first candidate wins;
@@ -254,19 +255,23 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     }
     W = (int)host_work.size();
     host_work_lb.clear();
-    W_lb = 0; lb_runs_cap = 0; lb_pair_evals = 0.0;
+    W_lb = 0; lb_runs_cap = 0; lb_pair_evals = 0.0; lb_sparse_total = 0;
     if (use_lb) {
         // every lb_stride-th point of either set is a query; the subset has to fit the kernel's registers
         const int qmax = lb_max_query_points();
         lb_stride = std::max(8, (std::max(max_na, max_nt) + qmax - 1) / qmax);
-        const int apb_lb = 32;   // 4 waves x 8 candidates: amortises staging the reference set
+        // first round: every lb_candidate_step()-th candidate and the last one, 32 of them per workgroup
+        // (4 waves x 8: amortises staging the reference set)
+        const int apb_lb = 32, cstep = lb_candidate_step();
         for (int p = 0; p < P; ++p) {
             const PairDesc& d = host_pairs[p];
-            for (int a0 = 0; a0 < d.n_ang; a0 += apb_lb)
-                host_work_lb.push_back(WorkItem{p, a0, std::min(apb_lb, d.n_ang - a0), 0});
+            const int ne = lb_sparse_candidates(d.n_ang);
+            for (int i0 = 0; i0 < ne; i0 += apb_lb)
+                host_work_lb.push_back(WorkItem{p, i0 * cstep, std::min(apb_lb, ne - i0), cstep});
             lb_runs_cap += (d.n_ang + 7) / 8;
             const double qa = (d.n_ref + lb_stride - 1) / lb_stride, qb = (d.n_tgt + lb_stride - 1) / lb_stride;
-            lb_pair_evals += (qa * d.n_tgt + qb * d.n_ref) * (double)d.n_ang;
+            lb_pair_evals += (qa * d.n_tgt + qb * d.n_ref) * (double)ne;
+            lb_sparse_total += ne;
         }
         W_lb = (int)host_work_lb.size();
     }
@@ -344,19 +349,25 @@ int Plan::run(bool screen_only)
     int prc;
     if (precision != MM_PRECISION_F64) {
         if (use_lb) {
-            // bound every candidate, fully screen one per pair, then only those the bound cannot rule out
+            // bound a sparse subset of the candidates, fully screen one per pair (upper bound), spread the
+            // bounds to the candidates in between, bound those still possible, screen the survivors
             MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
+            dev.stats = eng->profile ? eng->dev_stats : nullptr;
+            const int nap = (max_na + 31) & ~31, nbp = (max_nt + 31) & ~31;
             if ((prc = eng->profile_begin())) return prc;
-            e = launch_screen_lb(dev, (max_na + 31) & ~31, (max_nt + 31) & ~31, s);
-            if (e != hipSuccess) return hip_error(e, "bound kernel launch");
+            if ((e = launch_screen_lb(dev, nap, nbp, s)) != hipSuccess) return hip_error(e, "bound kernel launch");
             if ((prc = eng->profile_end(lb_pair_evals, A))) return prc;
             if ((prc = eng->profile_begin())) return prc;
             if ((e = launch_lb_pick(dev, s)) != hipSuccess) return hip_error(e, "pick kernel launch");
             if ((e = launch_screen_picks(dev, max_na, max_nbp, s)) != hipSuccess) return hip_error(e, "screen kernel launch (picks)");
+            if ((e = launch_lb_spread(dev, s)) != hipSuccess) return hip_error(e, "spread kernel launch");
+            if ((e = launch_screen_lb_queued(dev, nap, nbp, lb_runs_cap, s)) != hipSuccess)
+                return hip_error(e, "bound kernel launch (round 2)");
             if ((e = launch_lb_keep(dev, s)) != hipSuccess) return hip_error(e, "keep kernel launch");
             if ((e = launch_screen_kept(dev, max_na, max_nbp, lb_runs_cap, s)) != hipSuccess)
                 return hip_error(e, "screen kernel launch (survivors)");
             if ((prc = eng->profile_end(0.0, 0))) return prc;
+            if (eng->profile) { eng->bound_offered += A; eng->bound_round1 += lb_sparse_total; }
         } else {
             if ((prc = eng->profile_begin())) return prc;
             e = use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s);
@@ -629,6 +640,7 @@ void mm_engine_destroy(mm_engine* h)
     for (Engine::Buf* b : {&e->host_pts, &e->host_lvl}) if (b->p) (void)hipHostFree(b->p);
     for (Engine::Buf* b : {&e->dev_pts, &e->dev_lvl}) if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->dev_stats) (void)hipFree(e->dev_stats);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -648,6 +660,11 @@ int mm_engine_profile(mm_engine* h, int enable)
     MM_HIP(hipStreamSynchronize(e->stream));
     e->profile = enable != 0;
     e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0; e->launch_pair_evals.clear();
+    e->bound_offered = 0; e->bound_round1 = 0;
+    if (e->profile) {
+        if (!e->dev_stats) MM_HIP(hipMalloc((void**)&e->dev_stats, 64));
+        MM_HIP(hipMemsetAsync(e->dev_stats, 0, 64, e->stream));
+    }
     // hipEventCreate is slow (~0.5 ms): build the pool now, outside any timed region
     while (e->profile && e->events.size() < 2 * 2048) {
         hipEvent_t ev;
@@ -689,6 +706,17 @@ int mm_engine_profile_launches(mm_engine* h, int64_t cap, float* ms, double* pai
         if (pair_evals) pair_evals[k] = e->launch_pair_evals[k];
     }
     if (n_launches) *n_launches = (int64_t)e->launches;
+    return MM_OK;
+}
+
+int mm_engine_bound_stats(mm_engine* h, int64_t out[4])
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e || !out) return set_error(MM_ERR_INVALID, "engine or out == NULL");
+    unsigned long long d[8] = {0};
+    MM_HIP(hipStreamSynchronize(e->stream));
+    if (e->dev_stats) MM_HIP(hipMemcpy(d, e->dev_stats, 64, hipMemcpyDeviceToHost));
+    out[0] = e->bound_offered; out[1] = e->bound_round1; out[2] = (int64_t)d[1]; out[3] = (int64_t)d[2];
     return MM_OK;
 }
 

@@ -39,6 +39,10 @@ struct Engine {
     double prof_pair_evals = 0.0;
     std::vector<double> launch_pair_evals;   // per launch, same indexing as the event pairs
     int64_t prof_candidates = 0;
+    // bounded screen (MM_PRECISION_F32_BOUNDED) while profiling: candidates offered / bounded in round 1 (host
+    // counts), device accumulators [1] bounded in round 2, [2] fully screened
+    int64_t bound_offered = 0, bound_round1 = 0;
+    unsigned long long* dev_stats = nullptr;
     int profile_begin();
     int profile_end(double pair_evals, int64_t candidates);
 };
@@ -92,7 +96,8 @@ struct Plan {
     bool use_fast = false;                    // expanded-form screening kernel selected
     bool use_lb = false;                      // lower-bound pass in front of the screen (MM_PRECISION_F32_BOUNDED)
     int W_lb = 0, lb_stride = 0, lb_runs_cap = 0, max_nt = 1;
-    double lb_pair_evals = 0.0;               // pair-distances of the bound pass
+    double lb_pair_evals = 0.0;               // pair-distances of the first bound round
+    int64_t lb_sparse_total = 0;              // candidates the first bound round scores
     std::vector<WorkItem> host_work_lb;
 
     int stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient);

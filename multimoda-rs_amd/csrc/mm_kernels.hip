@@ -537,9 +537,12 @@ static __device__ __forceinline__ int lb_pass(const v2f (&qx)[RP], const v2f (&q
     v2f rm[RP];
 #pragma unroll
     for (int q = 0; q < RP; ++q) rm[q] = (v2f)(__int_as_float(0x7f800000));
+    float4 p0 = s_p[lj], p1 = s_p[16 + lj];
     for (int k = 0; k < n_groups; k += 2) {   // n_groups is even (sets are padded to 32 points)
-        const float4 p0 = s_p[k * 16 + lj];
-        const float4 p1 = s_p[(k + 1) * 16 + lj];
+        // the next two column groups are fetched while this pair is evaluated (the last round re-reads itself)
+        const int kn = k + 2 < n_groups ? k + 2 : k;
+        const float4 n0 = s_p[kn * 16 + lj];
+        const float4 n1 = s_p[(kn + 1) * 16 + lj];
 #pragma unroll
         for (int q = 0; q < RP; ++q) {
             const v2f t0 = __builtin_elementwise_fma(qy[q], (v2f)(p0.y), (v2f)(p0.z));
@@ -549,6 +552,7 @@ static __device__ __forceinline__ int lb_pass(const v2f (&qx)[RP], const v2f (&q
             rm[q].x = fmin3_f32(rm[q].x, e0.x, e1.x);
             rm[q].y = fmin3_f32(rm[q].y, e0.y, e1.y);
         }
+        p0 = n0; p1 = n1;
     }
     int m = 0;
 #pragma unroll
@@ -568,7 +572,8 @@ static __device__ __forceinline__ int lb_pass(const v2f (&qx)[RP], const v2f (&q
 
 template <int RP>
 __global__ void __launch_bounds__(256, 2)
-k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work, int stride,
+k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
+            int n_work_host, const int* __restrict__ n_work_dev, int stride,
             const float* __restrict__ ptx, const float* __restrict__ pty,
             const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_lb)
 {
@@ -576,6 +581,7 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lj = lane & 15, li = lane >> 4;
+    const int n_work = n_work_dev ? *n_work_dev : n_work_host;   // device queue: workgroups stride over it
 
     for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
          wi += gridDim.x) {
@@ -615,10 +621,21 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
                 else   { ax[q].x = -2.0f * x; ay[q].x = -2.0f * y; a2[q].x = n2; }
             }
         }
+        // the item's k-th candidate is a0 + k * step, clipped to the pair's last candidate (the sparse
+        // first round scores every step-th candidate and the last one); this wave takes k = wave + 4 i.
+        // Lane i fetches the i-th one's cos/sin now, so no candidate starts with a dependent global load
+        const int step = w.pad > 0 ? w.pad : 1;
+        float tab_c = 0.0f, tab_s = 0.0f;
+        if (wave + 4 * lane < w.cnt) {
+            const int al = min(w.a0 + (wave + 4 * lane) * step, pd.n_ang - 1);
+            tab_c = cosv[pd.tab_off + al];
+            tab_s = sinv[pd.tab_off + al];
+        }
         __syncthreads();
 
-        for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
-            const float c = cosv[pd.tab_off + a], s = sinv[pd.tab_off + a];
+        for (int i = 0, k = wave; k < w.cnt; ++i, k += 4) {
+            const int a = min(w.a0 + k * step, pd.n_ang - 1);
+            const float c = __shfl(tab_c, i, 64), s = __shfl(tab_s, i, 64);
             for (int j = lane; j < nbp; j += 64) {
                 const float2 t = s_tgt[j];
                 float4 b;
@@ -654,8 +671,13 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
     }
 }
 
-// Per pair: the candidate with the smallest bound (first one on ties) is queued for a full
-// screen evaluation; its value is the pair's upper bound.
+static constexpr int kLbCandStep = 8;   // first round: every 8th candidate (and the last) gets a bound
+
+// number of candidates the sparse first round scores for a list of n: 0, 8, 16, ... and n - 1
+static __host__ __device__ __forceinline__ int lb_sparse_count(int n) { return n <= 0 ? 0 : (n - 1 + kLbCandStep - 1) / kLbCandStep + 1; }
+
+// Per pair: among the candidates scored by the sparse round, the one with the smallest bound
+// (first one on ties) is queued for a full screen evaluation; its value is the pair's upper bound.
 __global__ void __launch_bounds__(256)
 k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, int32_t* __restrict__ pick_idx,
           WorkItem* __restrict__ items, int* __restrict__ n_items)
@@ -667,7 +689,9 @@ k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, in
     if (tid == 0) s_key = ~0ull;
     __syncthreads();
     unsigned long long key = ~0ull;
-    for (int a = tid; a < pd.n_ang; a += 256) {
+    const int ne = lb_sparse_count(pd.n_ang);
+    for (int i = tid; i < ne; i += 256) {
+        const int a = min(i * kLbCandStep, pd.n_ang - 1);
         const unsigned long long k = ((unsigned long long)__float_as_uint(lb32[pd.out_off + a]) << 32) | (unsigned)a;
         key = k < key ? k : key;
     }
@@ -682,19 +706,63 @@ k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, in
     }
 }
 
+// After the sparse round.  Rotating the target by a further angle D moves each of its points by the
+// chord 2 rho sin(D/2) <= rho_t * sqrt(2 - 2 cos D), so |H(c) - H(c')| <= chord(c, c'): a candidate
+// between two scored ones inherits their bounds minus the chord.  If even that exceeds the pair's
+// upper bound the candidate is ruled out without being looked at (+inf as its bound); otherwise it
+// is queued for a bound of its own, as runs inside its aligned group of 8.
+__global__ void __launch_bounds__(256)
+k_lb_spread(const PairDesc* __restrict__ pairs, float* __restrict__ lb32, const float* __restrict__ sq32,
+            const int32_t* __restrict__ pick_idx, const double* __restrict__ cos64, const double* __restrict__ sin64,
+            WorkItem* __restrict__ items, int* __restrict__ n_items, unsigned long long* __restrict__ stats)
+{
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const PairDesc pd = pairs[p];
+    if (pd.n_ang <= 0) return;
+    const int c1 = pick_idx[p], last = pd.n_ang - 1;
+    const double ub = sqrt((double)sq32[pd.out_off + c1] + pd.e2) + 2.0 * pd.delta;
+    const double* cs = cos64 + pd.tab_off;
+    const double* sn = sin64 + pd.tab_off;
+    unsigned long long queued = 0;
+    for (int g = tid; g * kLbCandStep < pd.n_ang; g += 256) {
+        const int lo = g * kLbCandStep, eR = min(lo + kLbCandStep, last);
+        const double vL = (double)lb32[pd.out_off + lo] - pd.e2, vR = (double)lb32[pd.out_off + eR] - pd.e2;
+        const double hL = sqrt(vL > 0.0 ? vL : 0.0), hR = sqrt(vR > 0.0 ? vR : 0.0);
+        int first = -1, lastp = -1;
+        for (int a = lo + 1; a < eR; ++a) {
+            const double dL = 2.0 - 2.0 * (cs[a] * cs[lo] + sn[a] * sn[lo]);
+            const double dR = 2.0 - 2.0 * (cs[a] * cs[eR] + sn[a] * sn[eR]);
+            // 4e-8: the cancellation floor of 2 - 2 cos D in f64 (sqrt of two ulps of 2)
+            const double chL = pd.rho_t * (sqrt(dL > 0.0 ? dL : 0.0) + 4e-8), chR = pd.rho_t * (sqrt(dR > 0.0 ? dR : 0.0) + 4e-8);
+            const double inherited = fmax(hL - chL, hR - chR);
+            if (inherited <= ub) { if (first < 0) first = a; lastp = a; }
+            else lb32[pd.out_off + a] = __int_as_float(0x7f800000);
+        }
+        if (first >= 0) {
+            const int slot = atomicAdd(n_items, 1);
+            WorkItem w; w.pair = p; w.a0 = first; w.cnt = lastp - first + 1; w.pad = 1;
+            items[slot] = w;
+            queued += (unsigned long long)w.cnt;
+        }
+    }
+    if (stats && queued) atomicAdd(&stats[1], queued);
+}
+
 // Per pair: a candidate survives if the smallest exact cost its bound allows does not exceed the
 // largest exact cost the picked candidate can have (same interval arithmetic as k_shortlist).
 // Survivors are queued as runs inside aligned groups of 8 candidates; every other candidate gets
 // +inf as its screened value, which k_shortlist never keeps.
 __global__ void __launch_bounds__(256)
 k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, float* __restrict__ sq32,
-          const int32_t* __restrict__ pick_idx, WorkItem* __restrict__ items, int* __restrict__ n_items)
+          const int32_t* __restrict__ pick_idx, WorkItem* __restrict__ items, int* __restrict__ n_items,
+          unsigned long long* __restrict__ stats)
 {
     const int p = blockIdx.x, tid = threadIdx.x;
     const PairDesc pd = pairs[p];
     if (pd.n_ang <= 0) return;
     const int c1 = pick_idx[p];
     const double ub = sqrt((double)sq32[pd.out_off + c1] + pd.e2) + 2.0 * pd.delta;
+    unsigned long long queued = 0;
     for (int g = tid; g * 8 < pd.n_ang; g += 256) {
         const int lo = g * 8, hi = (lo + 8 < pd.n_ang) ? lo + 8 : pd.n_ang;
         int first = -1, last = -1;
@@ -708,8 +776,10 @@ k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, fl
             const int slot = atomicAdd(n_items, 1);
             WorkItem w; w.pair = p; w.a0 = first; w.cnt = last - first + 1; w.pad = 0;
             items[slot] = w;
+            queued += (unsigned long long)w.cnt;
         }
     }
+    if (stats && queued) atomicAdd(&stats[2], queued);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1047,9 +1117,9 @@ int lb_max_query_points() { return 8 * kLbRP; }
 int lb_max_points() { return 1024; }
 size_t lds_bytes_lb(int nap, int nbp) { return (size_t)nap * 16 + (size_t)nbp * (8 + 4 * 16); }
 
-hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStream_t s)
+static hipError_t launch_lb_any(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
+                                int max_nap, int max_nbp, hipStream_t s)
 {
-    if (b.n_work_lb <= 0) return hipSuccess;
     auto kern = k_screen_lb<kLbRP>;
     const size_t lds = lds_bytes_lb(max_nap, max_nbp);
     if (lds > 48 * 1024) {
@@ -1057,9 +1127,27 @@ hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStre
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(b.n_work_lb), dim3(256), lds, s, b.pairs, b.work_lb, b.n_work_lb, b.lb_stride,
+    const int grid = n_dev ? std::min(cap, 256 * 12) : n_host;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, work, n_host, n_dev, b.lb_stride,
                        b.p32x, b.p32y, b.cos32, b.sin32, b.lb32);
     return hipGetLastError();
+}
+
+int lb_candidate_step() { return kLbCandStep; }
+int lb_sparse_candidates(int n) { return lb_sparse_count(n); }
+
+// round 1: every kLbCandStep-th candidate and the last one (host work list)
+hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStream_t s)
+{
+    if (b.n_work_lb <= 0) return hipSuccess;
+    return launch_lb_any(b, b.work_lb, b.n_work_lb, nullptr, 0, max_nap, max_nbp, s);
+}
+
+// round 2: the candidates k_lb_spread could not rule out (device queue, counter [2])
+hipError_t launch_screen_lb_queued(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s)
+{
+    if (cap <= 0) return hipSuccess;
+    return launch_lb_any(b, b.items, 0, b.n_items + 2, cap, max_nap, max_nbp, s);
 }
 
 hipError_t launch_lb_pick(const BatchDev& b, hipStream_t s)
@@ -1076,18 +1164,26 @@ hipError_t launch_screen_picks(const BatchDev& b, int max_na, int max_nbp, hipSt
     return launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, s);
 }
 
+hipError_t launch_lb_spread(const BatchDev& b, hipStream_t s)
+{
+    if (b.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lb_spread, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx, b.cos64,
+                       b.sin64, b.items, b.n_items + 2, b.stats);
+    return hipGetLastError();
+}
+
 hipError_t launch_lb_keep(const BatchDev& b, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_lb_keep, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx, b.items,
-                       b.n_items + 2);
+                       b.n_items + 3, b.stats);
     return hipGetLastError();
 }
 
 hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s)
 {
     if (cap <= 0) return hipSuccess;
-    return launch_fast_any(b, b.items, 0, b.n_items + 2, cap, max_na, max_nbp, s);
+    return launch_fast_any(b, b.items, 0, b.n_items + 3, cap, max_na, max_nbp, s);
 }
 
 template <bool FROM_QUEUE>
