@@ -94,8 +94,9 @@ int  mm_engine_profile_launches(mm_engine* e, int64_t cap, float* ms, double* pa
                                 int64_t* n_launches);
 /* MM_PRECISION_F32_BOUNDED, accumulated since mm_engine_profile(e, 1): out[0] candidates offered,
  * out[1] candidates given a lower bound in the first (sparse) round, out[2] in the second round,
- * out[3] candidates that went through the full f32 screen (the per-pair pick not counted). */
-int  mm_engine_bound_stats(mm_engine* e, int64_t out[4]);
+ * out[3] in the third (decisive-point) round, out[4] candidates that went through the full f32
+ * screen (the two per-pair picks not counted). */
+int  mm_engine_bound_stats(mm_engine* e, int64_t out[5]);
 
 /* ---- the metric: hausdorff_distance (process_utils.rs:78-82) ------------------------ */
 /* f64-exact on the device; empty set on either side -> 0.0 (process_utils.rs:86-88). */

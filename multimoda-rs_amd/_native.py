@@ -419,12 +419,12 @@ class Engine:
         return ms[:k].astype(np.float64), pe[:k]
 
     def bound_stats(self):
-        """MM_PRECISION_F32_BOUNDED since profile(True): candidates offered, lower-bounded in the sparse round,
-        lower-bounded in the second round, and fully screened."""
-        out = np.zeros(4, dtype=np.int64)
+        """MM_PRECISION_F32_BOUNDED since profile(True): candidates offered, lower-bounded in rounds 1-3 and fully
+        screened (include/mm_hausdorff.h)."""
+        out = np.zeros(5, dtype=np.int64)
         check(lib().mm_engine_bound_stats(self._h, _ptr(out)), "mm_engine_bound_stats")
         return {"offered": int(out[0]), "bounded_round1": int(out[1]), "bounded_round2": int(out[2]),
-                "screened": int(out[3])}
+                "bounded_round3": int(out[3]), "screened": int(out[4])}
 
     def profile_read(self):
         n, ms, pe, ca = C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_int64(0)

@@ -49,14 +49,19 @@ struct BatchDev {
     uint8_t*  flag;       // 1 = shortlisted (re-scored in f64)
     // shortlist queue
     WorkItem* items;      // capacity = total candidates (bounded mode: first the survivors' runs)
-    int32_t*  n_items;    // device counters: [0] re-score queue, [1] picks, [2] second bound round, [3] survivor runs
+    int32_t*  n_items;    // 8 device counters: [0] re-score queue; bounded mode: [1] picks, [2] queue 0 (round 2),
+                          // [3] queue 1 (round 3), [4] second picks, [5] queue 2 (survivors)
     // bounded screen (MM_PRECISION_F32_BOUNDED)
     const WorkItem* work_lb;   // bound kernel's work list (more candidates per workgroup)
     int32_t   n_work_lb, lb_stride;
     float*    lb32;        // per-candidate lower bound of the screened squared value
-    int32_t*  pick_idx;    // per pair: candidate with the smallest bound (-1: no candidates)
-    WorkItem* items_pick;  // one queue entry per pair with candidates
-    unsigned long long* stats;  // nullable: [1] candidates bounded in round 2, [2] candidates fully screened
+    int32_t*  pick_idx;    // [2 * n_pairs] per pair: candidate with the smallest bound after round 1 / round 3 (-1: none)
+    WorkItem* items_pick;  // [2 * n_pairs] queue entries of the two picks
+    WorkItem* items_lb;    // three queues of `runs cap` entries: round 2, round 3, survivors
+    float*    emit;        // per pair emit_rows + emit_cols: row / column minima of the first pick
+    int32_t   emit_rows, emit_cols;
+    int32_t*  qlist;       // per pair 2 * lb_list_queries(): decisive reference / target point indices
+    unsigned long long* stats;  // nullable: [1] candidates bounded in round 2, [3] in round 3, [2] fully screened
     // per-pair results
     double*   best_cost;
     int32_t*  best_idx;
@@ -76,11 +81,15 @@ int        max_target_points_fast();
 // lower bound of those still possible -> survivors -> full screen of the survivors (runs of <= 8
 // candidates, at most `cap` of them)
 hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStream_t s);
-hipError_t launch_lb_pick(const BatchDev& b, hipStream_t s);
-hipError_t launch_screen_picks(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
+hipError_t launch_lb_pick(const BatchDev& b, int round, hipStream_t s);
+hipError_t launch_screen_picks(const BatchDev& b, int round, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_lb_spread(const BatchDev& b, hipStream_t s);
 hipError_t launch_screen_lb_queued(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s);
-hipError_t launch_lb_keep(const BatchDev& b, hipStream_t s);
+hipError_t launch_lb_keep(const BatchDev& b, int final, int cap, hipStream_t s);
+// round 3: the pick's decisive points (largest row / column minima) as queries for the survivors
+hipError_t launch_lb_topk(const BatchDev& b, int max_n, hipStream_t s);
+hipError_t launch_screen_lb_list(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s);
+int        lb_list_queries();
 int        lb_candidate_step();
 int        lb_sparse_candidates(int n);   // candidates of a list of n the first round scores
 hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s);

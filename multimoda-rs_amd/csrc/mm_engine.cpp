@@ -286,9 +286,13 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     const size_t o_c64 = take((size_t)T * 8), o_s64 = take((size_t)T * 8);
     lvl_in_bytes = o;
     const size_t o_sq32 = take((size_t)A * 4), o_sq64 = take((size_t)A * 8), o_flag = take((size_t)A);
-    const size_t o_items = take((size_t)A * sizeof(WorkItem)), o_nitems = take(16);
-    const size_t o_lb32 = take(use_lb ? (size_t)A * 4 : 0), o_pick = take(use_lb ? (size_t)P * 4 : 0);
-    const size_t o_items_pick = take(use_lb ? (size_t)P * sizeof(WorkItem) : 0);
+    const size_t o_items = take((size_t)A * sizeof(WorkItem)), o_nitems = take(32);
+    const int emit_rows = (max_na + 3) & ~3, emit_cols = (max_nt + 3) & ~3;
+    const size_t o_lb32 = take(use_lb ? (size_t)A * 4 : 0), o_pick = take(use_lb ? (size_t)P * 8 : 0);
+    const size_t o_items_pick = take(use_lb ? (size_t)P * 2 * sizeof(WorkItem) : 0);
+    const size_t o_items_lb = take(use_lb ? (size_t)lb_runs_cap * 3 * sizeof(WorkItem) : 0);
+    const size_t o_emit = take(use_lb ? (size_t)P * (size_t)(emit_rows + emit_cols) * 4 : 0);
+    const size_t o_qlist = take(use_lb ? (size_t)P * 2 * (size_t)lb_list_queries() * 4 : 0);
     const size_t o_bc = take((size_t)P * 8), o_bi = take((size_t)P * 4), o_nr = take((size_t)P * 4);
     const size_t o_nc = take((size_t)P * 4), o_ni = take((size_t)P * 4 * kMaxNear);
     off_best_cost = o_bc; res_bytes = o - o_bc;
@@ -332,6 +336,8 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     dev.items = (WorkItem*)(B + o_items); dev.n_items = (int32_t*)(B + o_nitems);
     dev.work_lb = (const WorkItem*)(B + o_work_lb); dev.n_work_lb = W_lb; dev.lb_stride = lb_stride;
     dev.lb32 = (float*)(B + o_lb32); dev.pick_idx = (int32_t*)(B + o_pick); dev.items_pick = (WorkItem*)(B + o_items_pick);
+    dev.items_lb = (WorkItem*)(B + o_items_lb); dev.emit = (float*)(B + o_emit); dev.emit_rows = emit_rows; dev.emit_cols = emit_cols;
+    dev.qlist = (int32_t*)(B + o_qlist);
     dev.best_cost = (double*)(B + o_bc); dev.best_idx = (int32_t*)(B + o_bi); dev.n_rescored = (int32_t*)(B + o_nr);
     dev.near_cnt = (int32_t*)(B + o_nc); dev.near_idx = (int32_t*)(B + o_ni);
     dev.all_costs = want_costs ? (double*)(B + off_all_costs) : nullptr;
@@ -351,20 +357,25 @@ int Plan::run(bool screen_only)
         if (use_lb) {
             // bound a sparse subset of the candidates, fully screen one per pair (upper bound), spread the
             // bounds to the candidates in between, bound those still possible, screen the survivors
-            MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
+            MM_HIP(hipMemsetAsync(dev.n_items, 0, 32, s));
             dev.stats = eng->profile ? eng->dev_stats : nullptr;
-            const int nap = (max_na + 31) & ~31, nbp = (max_nt + 31) & ~31;
+            const int nap = (max_na + 31) & ~31, nbp = (max_nt + 31) & ~31, cap = lb_runs_cap;
             if ((prc = eng->profile_begin())) return prc;
             if ((e = launch_screen_lb(dev, nap, nbp, s)) != hipSuccess) return hip_error(e, "bound kernel launch");
             if ((prc = eng->profile_end(lb_pair_evals, A))) return prc;
             if ((prc = eng->profile_begin())) return prc;
-            if ((e = launch_lb_pick(dev, s)) != hipSuccess) return hip_error(e, "pick kernel launch");
-            if ((e = launch_screen_picks(dev, max_na, max_nbp, s)) != hipSuccess) return hip_error(e, "screen kernel launch (picks)");
+            if ((e = launch_lb_pick(dev, 0, s)) != hipSuccess) return hip_error(e, "pick kernel launch");
+            if ((e = launch_screen_picks(dev, 0, max_na, max_nbp, s)) != hipSuccess) return hip_error(e, "screen kernel launch (picks)");
             if ((e = launch_lb_spread(dev, s)) != hipSuccess) return hip_error(e, "spread kernel launch");
-            if ((e = launch_screen_lb_queued(dev, nap, nbp, lb_runs_cap, s)) != hipSuccess)
-                return hip_error(e, "bound kernel launch (round 2)");
-            if ((e = launch_lb_keep(dev, s)) != hipSuccess) return hip_error(e, "keep kernel launch");
-            if ((e = launch_screen_kept(dev, max_na, max_nbp, lb_runs_cap, s)) != hipSuccess)
+            if ((e = launch_screen_lb_queued(dev, nap, nbp, cap, s)) != hipSuccess) return hip_error(e, "bound kernel launch (round 2)");
+            if ((e = launch_lb_keep(dev, 0, cap, s)) != hipSuccess) return hip_error(e, "keep kernel launch");
+            // round 3: the pick's decisive points as queries, then a second pick on the sharpened bounds
+            if ((e = launch_lb_topk(dev, std::max(max_na, max_nt), s)) != hipSuccess) return hip_error(e, "top-k kernel launch");
+            if ((e = launch_screen_lb_list(dev, nap, nbp, cap, s)) != hipSuccess) return hip_error(e, "bound kernel launch (round 3)");
+            if ((e = launch_lb_pick(dev, 1, s)) != hipSuccess) return hip_error(e, "pick kernel launch (2)");
+            if ((e = launch_screen_picks(dev, 1, max_na, max_nbp, s)) != hipSuccess) return hip_error(e, "screen kernel launch (picks 2)");
+            if ((e = launch_lb_keep(dev, 1, cap, s)) != hipSuccess) return hip_error(e, "keep kernel launch (final)");
+            if ((e = launch_screen_kept(dev, max_na, max_nbp, cap, s)) != hipSuccess)
                 return hip_error(e, "screen kernel launch (survivors)");
             if ((prc = eng->profile_end(0.0, 0))) return prc;
             if (eng->profile) { eng->bound_offered += A; eng->bound_round1 += lb_sparse_total; }
@@ -709,14 +720,15 @@ int mm_engine_profile_launches(mm_engine* h, int64_t cap, float* ms, double* pai
     return MM_OK;
 }
 
-int mm_engine_bound_stats(mm_engine* h, int64_t out[4])
+int mm_engine_bound_stats(mm_engine* h, int64_t out[5])
 {
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine or out == NULL");
     unsigned long long d[8] = {0};
     MM_HIP(hipStreamSynchronize(e->stream));
     if (e->dev_stats) MM_HIP(hipMemcpy(d, e->dev_stats, 64, hipMemcpyDeviceToHost));
-    out[0] = e->bound_offered; out[1] = e->bound_round1; out[2] = (int64_t)d[1]; out[3] = (int64_t)d[2];
+    out[0] = e->bound_offered; out[1] = e->bound_round1; out[2] = (int64_t)d[1]; out[3] = (int64_t)d[3];
+    out[4] = (int64_t)d[2];
     return MM_OK;
 }
 

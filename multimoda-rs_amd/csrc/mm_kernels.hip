@@ -379,8 +379,12 @@ __global__ void __launch_bounds__(256, 3)
 k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
               int n_work_host, const int* __restrict__ n_work_dev,
               const float* __restrict__ ptx, const float* __restrict__ pty,
-              const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
+              const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq,
+              float* __restrict__ emit, int emit_rows, int emit_cols)
 {
+    // emit (nullable): per pair emit_rows + emit_cols floats; the item's LAST candidate leaves its row
+    // minima (one per reference point) and column minima (one per target point) there -- used on
+    // single-candidate items, to find the points that decide the pair's Hausdorff distance
     constexpr int NT = 256, NLI = 16;
     constexpr int RP = R / 2;
     constexpr bool ODD = (R & 1) != 0;
@@ -483,15 +487,21 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 
             // rows: min over the 16 column lanes, then max over valid rows (floor 0)
             int rowmax = 0;
+            float* const em = emit ? emit + (size_t)w.pair * (size_t)(emit_rows + emit_cols) : nullptr;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 int v = __float_as_int(rmin[r]);
                 v = dpp_min_i32<0xB1>(v); v = dpp_min_i32<0x4E>(v); v = dpp_min_i32<0x141>(v); v = dpp_min_i32<0x140>(v);
                 rowmax = v > rowmax ? v : rowmax;
+                if (em && lj == 0 && r * NLI + li < na) em[r * NLI + li] = __int_as_float(v);
             }
             __syncthreads();  // S2
             int m = rowmax;
-            for (int j = tid; j < nb; j += NT) { const int v = s_colmin[j]; m = v > m ? v : m; }
+            for (int j = tid; j < nb; j += NT) {
+                const int v = s_colmin[j];
+                m = v > m ? v : m;
+                if (em) em[emit_rows + j] = __int_as_float(v);
+            }
 #pragma unroll
             for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
             if ((tid & 63) == 0) atomicMax(&s_red[0], m);
@@ -570,10 +580,12 @@ static __device__ __forceinline__ int lb_pass(const v2f (&qx)[RP], const v2f (&q
     return m;
 }
 
-template <int RP>
+// LIST: the 8 RP queries of either side are the point indices qlist[pair * 16 RP + (0..8RP-1 reference,
+// 8RP.. target)] instead of every stride-th point, and the result is merged into out_lb by maximum.
+template <int RP, bool LIST>
 __global__ void __launch_bounds__(256, 2)
 k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
-            int n_work_host, const int* __restrict__ n_work_dev, int stride,
+            int n_work_host, const int* __restrict__ n_work_dev, int stride, const int32_t* __restrict__ qlist,
             const float* __restrict__ ptx, const float* __restrict__ pty,
             const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_lb)
 {
@@ -589,7 +601,9 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         const PairDesc pd = pairs[w.pair];
         const int na = pd.n_ref, nb = pd.n_tgt;
         const int nap = (na + 31) & ~31, nbp = (nb + 31) & ~31;
-        const int qa = (na + stride - 1) / stride, qb = (nb + stride - 1) / stride;   // <= 8 RP (host)
+        const int qa = LIST ? 8 * RP : (na + stride - 1) / stride;   // <= 8 RP (host)
+        const int qb = LIST ? 8 * RP : (nb + stride - 1) / stride;
+        const int32_t* ql = LIST ? qlist + (size_t)w.pair * (16 * RP) : nullptr;
 
         float4* s_a = reinterpret_cast<float4*>(smem);                 // (ax, ay, |a|^2, 0), shared
         float2* s_tgt = reinterpret_cast<float2*>(s_a + nap);          // unrotated target, shared
@@ -614,7 +628,7 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int row = li * (2 * RP) + 2 * q + h;
-                const int idx = (row < qa ? row : qa - 1) * stride;
+                const int idx = LIST ? ql[row] : (row < qa ? row : qa - 1) * stride;
                 const float x = ptx[pd.ref_off + idx], y = pty[pd.ref_off + idx];
                 const float n2 = __builtin_fmaf(x, x, y * y);
                 if (h) { ax[q].y = -2.0f * x; ay[q].y = -2.0f * y; a2[q].y = n2; }
@@ -658,14 +672,18 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = li * (2 * RP) + 2 * q + h;
-                    const float4 b = s_b[(row < qb ? row : qb - 1) * stride];
+                    const float4 b = s_b[LIST ? ql[8 * RP + row] : (row < qb ? row : qb - 1) * stride];
                     if (h) { bx[q].y = -2.0f * b.x; by[q].y = -2.0f * b.y; b2[q].y = b.z; }
                     else   { bx[q].x = -2.0f * b.x; by[q].x = -2.0f * b.y; b2[q].x = b.z; }
                 }
             }
             const int m2 = lb_pass<RP>(bx, by, b2, s_a, nap >> 4, lj);
 
-            if (lane == 0) out_lb[pd.out_off + a] = __int_as_float(m1 > m2 ? m1 : m2);
+            if (lane == 0) {
+                float v = __int_as_float(m1 > m2 ? m1 : m2);
+                if (LIST) { const float o = out_lb[pd.out_off + a]; v = o > v ? o : v; }   // +inf (ruled out) stays
+                out_lb[pd.out_off + a] = v;
+            }
             __builtin_amdgcn_wave_barrier();   // all reads of the slice precede the next candidate's writes
         }
     }
@@ -678,6 +696,7 @@ static __host__ __device__ __forceinline__ int lb_sparse_count(int n) { return n
 
 // Per pair: among the candidates scored by the sparse round, the one with the smallest bound
 // (first one on ties) is queued for a full screen evaluation; its value is the pair's upper bound.
+template <bool SPARSE>
 __global__ void __launch_bounds__(256)
 k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, int32_t* __restrict__ pick_idx,
           WorkItem* __restrict__ items, int* __restrict__ n_items)
@@ -689,9 +708,9 @@ k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, in
     if (tid == 0) s_key = ~0ull;
     __syncthreads();
     unsigned long long key = ~0ull;
-    const int ne = lb_sparse_count(pd.n_ang);
+    const int ne = SPARSE ? lb_sparse_count(pd.n_ang) : pd.n_ang;   // later rounds: every candidate has a bound or +inf
     for (int i = tid; i < ne; i += 256) {
-        const int a = min(i * kLbCandStep, pd.n_ang - 1);
+        const int a = SPARSE ? min(i * kLbCandStep, pd.n_ang - 1) : i;
         const unsigned long long k = ((unsigned long long)__float_as_uint(lb32[pd.out_off + a]) << 32) | (unsigned)a;
         key = k < key ? k : key;
     }
@@ -752,26 +771,31 @@ k_lb_spread(const PairDesc* __restrict__ pairs, float* __restrict__ lb32, const 
 // largest exact cost the picked candidate can have (same interval arithmetic as k_shortlist).
 // Survivors are queued as runs inside aligned groups of 8 candidates; every other candidate gets
 // +inf as its screened value, which k_shortlist never keeps.
+// pick2 (nullable): a second fully screened candidate per pair; the smaller of the two values is the bound.
+// FINAL: candidates that are not queued get +inf as their screened value; stats slot 2 counts the queued ones.
+template <bool FINAL>
 __global__ void __launch_bounds__(256)
 k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, float* __restrict__ sq32,
-          const int32_t* __restrict__ pick_idx, WorkItem* __restrict__ items, int* __restrict__ n_items,
-          unsigned long long* __restrict__ stats)
+          const int32_t* __restrict__ pick_idx, const int32_t* __restrict__ pick2, WorkItem* __restrict__ items,
+          int* __restrict__ n_items, unsigned long long* __restrict__ stats)
 {
     const int p = blockIdx.x, tid = threadIdx.x;
     const PairDesc pd = pairs[p];
     if (pd.n_ang <= 0) return;
-    const int c1 = pick_idx[p];
-    const double ub = sqrt((double)sq32[pd.out_off + c1] + pd.e2) + 2.0 * pd.delta;
+    const int c1 = pick_idx[p], c2 = pick2 ? pick2[p] : c1;
+    const float s1 = sq32[pd.out_off + c1], s2 = sq32[pd.out_off + c2];
+    const double ub = sqrt((double)(s2 < s1 ? s2 : s1) + pd.e2) + 2.0 * pd.delta;
     unsigned long long queued = 0;
     for (int g = tid; g * 8 < pd.n_ang; g += 256) {
         const int lo = g * 8, hi = (lo + 8 < pd.n_ang) ? lo + 8 : pd.n_ang;
         int first = -1, last = -1;
         for (int a = lo; a < hi; ++a) {
             const double sv = (double)lb32[pd.out_off + a] - pd.e2;
-            if (a == c1 || sqrt(sv > 0.0 ? sv : 0.0) <= ub) { if (first < 0) first = a; last = a; }
+            if (a == c1 || a == c2 || sqrt(sv > 0.0 ? sv : 0.0) <= ub) { if (first < 0) first = a; last = a; }
         }
-        for (int a = lo; a < hi; ++a)
-            if (a < first || a > last) sq32[pd.out_off + a] = __int_as_float(0x7f800000);
+        if (FINAL)
+            for (int a = lo; a < hi; ++a)
+                if (a < first || a > last) sq32[pd.out_off + a] = __int_as_float(0x7f800000);
         if (first >= 0) {
             const int slot = atomicAdd(n_items, 1);
             WorkItem w; w.pair = p; w.a0 = first; w.cnt = last - first + 1; w.pad = 0;
@@ -779,7 +803,50 @@ k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, fl
             queued += (unsigned long long)w.cnt;
         }
     }
-    if (stats && queued) atomicAdd(&stats[2], queued);
+    if (stats && queued) atomicAdd(&stats[FINAL ? 2 : 3], queued);
+}
+
+// The points that decide the picked candidate's Hausdorff distance: the kLbListQ reference points with the
+// largest row minima and the kLbListQ target points with the largest column minima (emitted by the pick's
+// screen).  Neighbouring candidates have (nearly) the same decisive points, so a bound from these few
+// queries is almost exact where the optimum lies.  Sets with fewer points repeat their last choice.
+static constexpr int kLbListRP = 1;
+static constexpr int kLbListQ = 8 * kLbListRP;
+
+__global__ void __launch_bounds__(256)
+k_lb_topk(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pick_idx, const float* __restrict__ emit,
+          int emit_rows, int emit_cols, int32_t* __restrict__ qlist)
+{
+    __shared__ unsigned long long s_best;
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* s_val = reinterpret_cast<int*>(smem);
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const PairDesc pd = pairs[p];
+    if (pd.n_ang <= 0 || pick_idx[p] < 0) return;
+    for (int side = 0; side < 2; ++side) {
+        const int n = side ? pd.n_tgt : pd.n_ref;
+        const float* src = emit + (size_t)p * (size_t)(emit_rows + emit_cols) + (side ? emit_rows : 0);
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) { const int v = __float_as_int(src[i]); s_val[i] = v > 0 ? v : 0; }
+        int lastsel = 0;
+        for (int k = 0; k < kLbListQ; ++k) {
+            if (tid == 0) s_best = 0ull;
+            __syncthreads();
+            unsigned long long key = 0ull;   // (value + 1, n - index): the first index wins ties; 0 = nothing left
+            for (int i = tid; i < n; i += 256)
+                if (s_val[i] >= 0) {
+                    const unsigned long long kk = ((unsigned long long)(unsigned)(s_val[i] + 1) << 32) | (unsigned)(n - i);
+                    key = kk > key ? kk : key;
+                }
+            atomicMax(&s_best, key);
+            __syncthreads();
+            const unsigned long long b = s_best;
+            const int sel = b ? n - (int)(b & 0xffffffffull) : lastsel;
+            lastsel = sel;
+            if (tid == 0) { qlist[(size_t)p * (2 * kLbListQ) + side * kLbListQ + k] = sel; if (b) s_val[sel] = -1; }
+            __syncthreads();
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -1081,7 +1148,7 @@ int max_target_points_fast() { return ((LDS_CAP - 16) / 28) & ~15; }
 // *n_dev (a bounded grid strides over it).
 template <int Rv>
 static hipError_t launch_fast_r(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
-                                int max_nbp, hipStream_t s)
+                                int max_nbp, bool emit, hipStream_t s)
 {
     auto kern = k_screen_fast<Rv>;
     const size_t lds = lds_bytes_fast(max_nbp);
@@ -1092,24 +1159,24 @@ static hipError_t launch_fast_r(const BatchDev& b, const WorkItem* work, int n_h
     }
     const int grid = n_dev ? std::min(cap, 256 * 12) : n_host;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, work, n_host, n_dev, b.p32x, b.p32y,
-                       b.cos32, b.sin32, b.sq32);
+                       b.cos32, b.sin32, b.sq32, emit ? b.emit : nullptr, b.emit_rows, b.emit_cols);
     return hipGetLastError();
 }
 
 static hipError_t launch_fast_any(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
-                                  int max_na, int max_nbp, hipStream_t s)
+                                  int max_na, int max_nbp, bool emit, hipStream_t s)
 {
-    if (max_na <= 16 * 8) return launch_fast_r<8>(b, work, n_host, n_dev, cap, max_nbp, s);
-    if (max_na <= 16 * 14) return launch_fast_r<14>(b, work, n_host, n_dev, cap, max_nbp, s);
-    if (max_na <= 16 * 20) return launch_fast_r<20>(b, work, n_host, n_dev, cap, max_nbp, s);
-    if (max_na <= 16 * 26) return launch_fast_r<26>(b, work, n_host, n_dev, cap, max_nbp, s);
-    return launch_fast_r<33>(b, work, n_host, n_dev, cap, max_nbp, s);
+    if (max_na <= 16 * 8) return launch_fast_r<8>(b, work, n_host, n_dev, cap, max_nbp, emit, s);
+    if (max_na <= 16 * 14) return launch_fast_r<14>(b, work, n_host, n_dev, cap, max_nbp, emit, s);
+    if (max_na <= 16 * 20) return launch_fast_r<20>(b, work, n_host, n_dev, cap, max_nbp, emit, s);
+    if (max_na <= 16 * 26) return launch_fast_r<26>(b, work, n_host, n_dev, cap, max_nbp, emit, s);
+    return launch_fast_r<33>(b, work, n_host, n_dev, cap, max_nbp, emit, s);
 }
 
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
 {
     if (b.n_work <= 0) return hipSuccess;
-    return launch_fast_any(b, b.work, b.n_work, nullptr, 0, max_na, max_nbp, s);
+    return launch_fast_any(b, b.work, b.n_work, nullptr, 0, max_na, max_nbp, false, s);
 }
 
 // ---- bounded screen (k_screen_lb -> pick -> screen the picks -> keep -> screen the survivors) ----
@@ -1117,10 +1184,11 @@ int lb_max_query_points() { return 8 * kLbRP; }
 int lb_max_points() { return 1024; }
 size_t lds_bytes_lb(int nap, int nbp) { return (size_t)nap * 16 + (size_t)nbp * (8 + 4 * 16); }
 
-static hipError_t launch_lb_any(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
-                                int max_nap, int max_nbp, hipStream_t s)
+template <int RP, bool LIST>
+static hipError_t launch_lb_t(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
+                              int max_nap, int max_nbp, hipStream_t s)
 {
-    auto kern = k_screen_lb<kLbRP>;
+    auto kern = k_screen_lb<RP, LIST>;
     const size_t lds = lds_bytes_lb(max_nap, max_nbp);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1128,62 +1196,89 @@ static hipError_t launch_lb_any(const BatchDev& b, const WorkItem* work, int n_h
         if (e != hipSuccess) return e;
     }
     const int grid = n_dev ? std::min(cap, 256 * 12) : n_host;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, work, n_host, n_dev, b.lb_stride,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, work, n_host, n_dev, b.lb_stride, b.qlist,
                        b.p32x, b.p32y, b.cos32, b.sin32, b.lb32);
     return hipGetLastError();
 }
 
 int lb_candidate_step() { return kLbCandStep; }
 int lb_sparse_candidates(int n) { return lb_sparse_count(n); }
+int lb_list_queries() { return kLbListQ; }
 
 // round 1: every kLbCandStep-th candidate and the last one (host work list)
 hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStream_t s)
 {
     if (b.n_work_lb <= 0) return hipSuccess;
-    return launch_lb_any(b, b.work_lb, b.n_work_lb, nullptr, 0, max_nap, max_nbp, s);
+    return launch_lb_t<kLbRP, false>(b, b.work_lb, b.n_work_lb, nullptr, 0, max_nap, max_nbp, s);
 }
 
-// round 2: the candidates k_lb_spread could not rule out (device queue, counter [2])
+// round 2: the candidates k_lb_spread could not rule out (queue 0, counter [2])
 hipError_t launch_screen_lb_queued(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s)
 {
     if (cap <= 0) return hipSuccess;
-    return launch_lb_any(b, b.items, 0, b.n_items + 2, cap, max_nap, max_nbp, s);
+    return launch_lb_t<kLbRP, false>(b, b.items_lb, 0, b.n_items + 2, cap, max_nap, max_nbp, s);
 }
 
-hipError_t launch_lb_pick(const BatchDev& b, hipStream_t s)
+// round 3: the survivors of round 2 (queue 1, counter [3]) against the pick's decisive points
+hipError_t launch_screen_lb_list(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s)
+{
+    if (cap <= 0) return hipSuccess;
+    return launch_lb_t<kLbListRP, true>(b, b.items_lb + cap, 0, b.n_items + 3, cap, max_nap, max_nbp, s);
+}
+
+hipError_t launch_lb_pick(const BatchDev& b, int round, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lb_pick, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.pick_idx, b.items_pick,
-                       b.n_items + 1);
+    if (round == 0)
+        hipLaunchKernelGGL(k_lb_pick<true>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.pick_idx, b.items_pick,
+                           b.n_items + 1);
+    else
+        hipLaunchKernelGGL(k_lb_pick<false>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.pick_idx + b.n_pairs,
+                           b.items_pick + b.n_pairs, b.n_items + 4);
     return hipGetLastError();
 }
 
-hipError_t launch_screen_picks(const BatchDev& b, int max_na, int max_nbp, hipStream_t s)
+// full screen of the picks; round 0 also leaves the row / column minima for k_lb_topk
+hipError_t launch_screen_picks(const BatchDev& b, int round, int max_na, int max_nbp, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
-    return launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, s);
+    if (round == 0) return launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, true, s);
+    return launch_fast_any(b, b.items_pick + b.n_pairs, 0, b.n_items + 4, b.n_pairs, max_na, max_nbp, false, s);
+}
+
+hipError_t launch_lb_topk(const BatchDev& b, int max_n, hipStream_t s)
+{
+    if (b.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lb_topk, dim3(b.n_pairs), dim3(256), (size_t)max_n * 4, s, b.pairs, b.pick_idx, b.emit,
+                       b.emit_rows, b.emit_cols, b.qlist);
+    return hipGetLastError();
 }
 
 hipError_t launch_lb_spread(const BatchDev& b, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_lb_spread, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx, b.cos64,
-                       b.sin64, b.items, b.n_items + 2, b.stats);
+                       b.sin64, b.items_lb, b.n_items + 2, b.stats);
     return hipGetLastError();
 }
 
-hipError_t launch_lb_keep(const BatchDev& b, hipStream_t s)
+// survivors of the rounds so far: round 2's go to queue 1 (for the list round), the final ones to queue 2
+hipError_t launch_lb_keep(const BatchDev& b, int final, int cap, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lb_keep, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx, b.items,
-                       b.n_items + 3, b.stats);
+    if (!final)
+        hipLaunchKernelGGL(k_lb_keep<false>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx,
+                           (const int32_t*)nullptr, b.items_lb + cap, b.n_items + 3, b.stats);
+    else
+        hipLaunchKernelGGL(k_lb_keep<true>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx,
+                           (const int32_t*)(b.pick_idx + b.n_pairs), b.items_lb + 2 * (size_t)cap, b.n_items + 5, b.stats);
     return hipGetLastError();
 }
 
 hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s)
 {
     if (cap <= 0) return hipSuccess;
-    return launch_fast_any(b, b.items, 0, b.n_items + 3, cap, max_na, max_nbp, s);
+    return launch_fast_any(b, b.items_lb + 2 * (size_t)cap, 0, b.n_items + 5, cap, max_na, max_nbp, false, s);
 }
 
 template <bool FROM_QUEUE>
