@@ -374,17 +374,18 @@ static __device__ __forceinline__ int dpp_min_i32(int v)
     return o < v ? o : v;
 }
 
-template <int R>
-__global__ void __launch_bounds__(256, 3)
+template <int R, bool EMIT>
+__global__ void __launch_bounds__(256, EMIT ? 2 : 3)
 k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
               int n_work_host, const int* __restrict__ n_work_dev,
               const float* __restrict__ ptx, const float* __restrict__ pty,
               const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq,
               float* __restrict__ emit, int emit_rows, int emit_cols)
 {
-    // emit (nullable): per pair emit_rows + emit_cols floats; the item's LAST candidate leaves its row
-    // minima (one per reference point) and column minima (one per target point) there -- used on
-    // single-candidate items, to find the points that decide the pair's Hausdorff distance
+    // EMIT: per pair emit_rows + emit_cols floats; the item's LAST candidate leaves its row minima (one
+    // per reference point) and column minima (one per target point) there -- used on single-candidate
+    // items, to find the points that decide the pair's Hausdorff distance.  A separate instantiation:
+    // the stores cost the main screen 5 % when they were a run-time branch.
     constexpr int NT = 256, NLI = 16;
     constexpr int RP = R / 2;
     constexpr bool ODD = (R & 1) != 0;
@@ -487,20 +488,20 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 
             // rows: min over the 16 column lanes, then max over valid rows (floor 0)
             int rowmax = 0;
-            float* const em = emit ? emit + (size_t)w.pair * (size_t)(emit_rows + emit_cols) : nullptr;
+            float* const em = EMIT ? emit + (size_t)w.pair * (size_t)(emit_rows + emit_cols) : nullptr;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 int v = __float_as_int(rmin[r]);
                 v = dpp_min_i32<0xB1>(v); v = dpp_min_i32<0x4E>(v); v = dpp_min_i32<0x141>(v); v = dpp_min_i32<0x140>(v);
                 rowmax = v > rowmax ? v : rowmax;
-                if (em && lj == 0 && r * NLI + li < na) em[r * NLI + li] = __int_as_float(v);
+                if (EMIT && lj == 0 && r * NLI + li < na) em[r * NLI + li] = __int_as_float(v);
             }
             __syncthreads();  // S2
             int m = rowmax;
             for (int j = tid; j < nb; j += NT) {
                 const int v = s_colmin[j];
                 m = v > m ? v : m;
-                if (em) em[emit_rows + j] = __int_as_float(v);
+                if (EMIT) em[emit_rows + j] = __int_as_float(v);
             }
 #pragma unroll
             for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
@@ -1150,7 +1151,7 @@ template <int Rv>
 static hipError_t launch_fast_r(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
                                 int max_nbp, bool emit, hipStream_t s)
 {
-    auto kern = k_screen_fast<Rv>;
+    auto kern = emit ? k_screen_fast<Rv, true> : k_screen_fast<Rv, false>;
     const size_t lds = lds_bytes_fast(max_nbp);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -160,9 +160,11 @@ def test_batch_ragged_and_empty(engine, oracle, mm):
             assert out["n_rescored"][3] < len(lists[3])   # the screen prunes almost everything
 
 
-def test_plan_slices_partition_the_candidate_axis(engine, oracle, mm):
+@pytest.mark.parametrize("prec", [1, 2, 3])
+def test_plan_slices_partition_the_candidate_axis(engine, oracle, mm, prec):
     """Sharding the candidate axis (what each rank does at N GPUs): min over slices of
-    (cost, index) == the unsharded winner."""
+    (cost, index) == the unsharded winner.  prec 3 = the bounded screen: every slice prunes against
+    its own best."""
     rng = np.random.default_rng(9)
     refs = [blob(rng, 260) for _ in range(5)]
     tgts = [blob(rng, 260) for _ in range(5)]
@@ -174,7 +176,7 @@ def test_plan_slices_partition_the_candidate_axis(engine, oracle, mm):
     best_cost = np.full(5, np.inf)
     best_idx = np.full(5, 2**31 - 1, dtype=np.int64)
     for r in range(world):
-        plan = engine.plan(batch, mm.MM_PRECISION_F32, r * per, min((r + 1) * per, len(angles)))
+        plan = engine.plan(batch, prec, r * per, min((r + 1) * per, len(angles)))
         plan.run()
         res = plan.fetch()
         plan.close()
