@@ -250,8 +250,14 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     int apb = (int)std::min<int64_t>(8, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
     host_work.clear();
     for (int p = 0; p < P; ++p) {
+        // balanced chunks: ceil(n / apb) workgroups whose sizes differ by at most one (a 90-candidate
+        // slice is 12 x 7-8 candidates, not 11 x 8 + 2: the short tail would cost a full staging)
         const PairDesc& d = host_pairs[p];
-        for (int a0 = 0; a0 < d.n_ang; a0 += apb) host_work.push_back(WorkItem{p, a0, std::min(apb, d.n_ang - a0), 0});
+        const int nw = (d.n_ang + apb - 1) / apb;
+        for (int k = 0; k < nw; ++k) {
+            const int a0 = (int)((int64_t)d.n_ang * k / nw), a1 = (int)((int64_t)d.n_ang * (k + 1) / nw);
+            host_work.push_back(WorkItem{p, a0, a1 - a0, 0});
+        }
     }
     W = (int)host_work.size();
     host_work_lb.clear();
