@@ -55,7 +55,8 @@ enum {
                              of the other (2/k of the distance matrix), one full evaluation per pair
                              gives an upper bound, and only candidates whose bound does not exceed it
                              are screened and re-scored.  Candidates ruled out are never the minimum.
-                             Falls back to MM_PRECISION_F32_FAST when per-candidate costs are requested
+                             Falls back to MM_PRECISION_F32_FAST when per-candidate costs are requested,
+                             the batch is small (mm_engine_set_bound_min_candidates)
                              or a set exceeds the bound kernel's LDS budget                          */
 };
 
@@ -97,6 +98,9 @@ int  mm_engine_profile_launches(mm_engine* e, int64_t cap, float* ms, double* pa
  * out[3] in the third (decisive-point) round, out[4] candidates that went through the full f32
  * screen (the two per-pair picks not counted). */
 int  mm_engine_bound_stats(mm_engine* e, int64_t out[5]);
+/* MM_PRECISION_F32_BOUNDED runs its bound rounds only on batches of at least n candidates (default
+ * 16384): a dozen dependent launches cost more than screening a small batch outright. 0 = always. */
+int  mm_engine_set_bound_min_candidates(mm_engine* e, int64_t n);
 
 /* ---- the metric: hausdorff_distance (process_utils.rs:78-82) ------------------------ */
 /* f64-exact on the device; empty set on either side -> 0.0 (process_utils.rs:86-88). */

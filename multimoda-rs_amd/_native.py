@@ -26,6 +26,7 @@ EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
     "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream",
     "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches", "mm_engine_bound_stats",
+    "mm_engine_set_bound_min_candidates",
     "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
     "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_create_indexed", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
@@ -142,6 +143,8 @@ def lib():
     L.mm_engine_profile_launches.argtypes = [P, I64, P, P, C.POINTER(I64)]
     L.mm_engine_bound_stats.restype = I
     L.mm_engine_bound_stats.argtypes = [P, P]
+    L.mm_engine_set_bound_min_candidates.restype = I
+    L.mm_engine_set_bound_min_candidates.argtypes = [P, I64]
     L.mm_hausdorff_2d.restype = I
     L.mm_hausdorff_2d.argtypes = [P, P, P, I, P, P, I, C.POINTER(D)]
     L.mm_hausdorff_batch.restype = I
@@ -417,6 +420,10 @@ class Engine:
         check(lib().mm_engine_profile_launches(self._h, cap, _ptr(ms), _ptr(pe), C.byref(n)), "mm_engine_profile_launches")
         k = min(int(n.value), cap)
         return ms[:k].astype(np.float64), pe[:k]
+
+    def set_bound_min_candidates(self, n: int):
+        """MM_PRECISION_F32_BOUNDED uses its bound rounds only on batches of at least n candidates (default 16384)."""
+        check(lib().mm_engine_set_bound_min_candidates(self._h, int(n)), "mm_engine_set_bound_min_candidates")
 
     def bound_stats(self):
         """MM_PRECISION_F32_BOUNDED since profile(True): candidates offered, lower-bounded in rounds 1-3 and fully

@@ -234,9 +234,11 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     use_fast = expanded && max_na <= max_rows_fast() && max_nbp <= max_target_points_fast();
     if (expanded && !use_fast)
         for (PairDesc& d : host_pairs) d.e2 = 0.0;
-    // the bound pass pays for itself on sets of a few dozen points or more; per-candidate costs need
-    // every candidate evaluated
-    use_lb = precision == MM_PRECISION_F32_BOUNDED && use_fast && !want_costs && A > 0 &&
+    // the bound rounds pay for themselves on sets of a few dozen points or more and on batches that keep
+    // the device busy for several rounds of workgroups (a dozen dependent launches cost more than
+    // screening a small batch outright: the between stage's 2 x 722 candidates are 40 % faster without);
+    // per-candidate costs need every candidate evaluated
+    use_lb = precision == MM_PRECISION_F32_BOUNDED && use_fast && !want_costs && A > 0 && A >= e->bound_min_candidates &&
              std::min(max_na, max_nt) >= 64 && std::max(max_na, max_nt) <= lb_max_points();
     if (max_nbp > max_target_points_f64() || (precision != MM_PRECISION_F64 && max_nbp > max_target_points_f32()))
         return set_error(MM_ERR_TOO_LARGE, "target set does not fit the kernel's LDS budget (" +
@@ -723,6 +725,14 @@ int mm_engine_profile_launches(mm_engine* h, int64_t cap, float* ms, double* pai
         if (pair_evals) pair_evals[k] = e->launch_pair_evals[k];
     }
     if (n_launches) *n_launches = (int64_t)e->launches;
+    return MM_OK;
+}
+
+int mm_engine_set_bound_min_candidates(mm_engine* h, int64_t n)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e || n < 0) return set_error(MM_ERR_INVALID, "engine == NULL or n < 0");
+    e->bound_min_candidates = n;
     return MM_OK;
 }
 

@@ -41,6 +41,7 @@ struct Engine {
     int64_t prof_candidates = 0;
     // bounded screen (MM_PRECISION_F32_BOUNDED) while profiling: candidates offered / bounded in round 1 (host
     // counts), device accumulators [1] bounded in round 2, [2] fully screened
+    int64_t bound_min_candidates = 16384;   // smaller batches skip the bound rounds (mm_engine_set_bound_min_candidates)
     int64_t bound_offered = 0, bound_round1 = 0;
     unsigned long long* dev_stats = nullptr;
     int profile_begin();

@@ -487,6 +487,14 @@ def test_near_ties_between_neighbouring_candidates(engine, oracle, mm, precision
 # MM_PRECISION_F32_BOUNDED: a lower bound rules candidates out before the screen; winners and costs
 # must still be the oracle's, bit for bit
 # ---------------------------------------------------------------------------------------
+@pytest.fixture(autouse=True)
+def _bound_rounds_on_every_batch(engine):
+    """The bound rounds are skipped on small batches by default; here every batch must take them."""
+    engine.set_bound_min_candidates(0)
+    yield
+    engine.set_bound_min_candidates(16384)
+
+
 @pytest.mark.parametrize("n,step,rng_deg", [(64, 1.0, 180.0), (100, 1.0, 180.0), (208, 0.5, 90.0), (320, 1.0, 180.0),
                                             (521, 0.5, 180.0), (528, 1.0, 90.0)])
 def test_bounded_screen_winner_bit_exact_and_prunes(engine, oracle, mm, n, step, rng_deg):
