@@ -326,20 +326,23 @@ def best_rotation_three_point(lumen_xyz, centroid, index_reference: int, main_re
 
 def refine_alignment_hausdorff(engine: N.Engine, geoms: Sequence[G.FlatGeometry], centerline: Centerline,
                                initial_cl_ref_idx: int, initial_rotation: float, points, angle_search_range: float,
-                               angle_step: float, index_search_range: int):
+                               angle_step: float, index_search_range: int, return_costs: bool = True):
     """refine_alignment_hausdorff (align_algorithms.rs:339-451) with the grid scored on the GPU.
-    Returns (best_angle, best_cl_ref_idx, min_hausdorff, costs of every evaluated candidate)."""
+    Returns (best_angle, best_cl_ref_idx, min_hausdorff, costs of every evaluated candidate).
+    return_costs=False asks for the winner only (what align_combined does): candidates that a lower
+    bound rules out are then not evaluated, and the last element is an empty array."""
     pk = _ClPack(geoms)
     pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
     n_ang = int(math.floor(2.0 * angle_search_range / angle_step)) + 3 if angle_step > 0 else 1
-    cap = (2 * int(index_search_range) + 1) * n_ang
+    cap = (2 * int(index_search_range) + 1) * n_ang if return_costs else 0
     costs = np.zeros(cap, dtype=np.float64)
     ba, mh, bi, ne = C.c_double(0.0), C.c_double(0.0), C.c_int64(0), C.c_int64(0)
     N.check(N.lib().mm_refine_alignment_hausdorff(engine.handle, pk.ptr, len(geoms), N._ptr(centerline.points),
                                                   len(centerline), int(initial_cl_ref_idx), float(initial_rotation),
                                                   N._ptr(pts), pts.shape[0], float(angle_search_range),
                                                   float(angle_step), int(index_search_range), C.byref(ba),
-                                                  C.byref(bi), C.byref(mh), N._ptr(costs), cap, C.byref(ne)),
+                                                  C.byref(bi), C.byref(mh), N._ptr(costs) if return_costs else None, cap,
+                                                  C.byref(ne)),
             "refine_alignment_hausdorff")
     return ba.value, int(bi.value), mh.value, costs[: min(int(ne.value), cap)].copy()
 

@@ -518,16 +518,28 @@ int refine(Engine* e, mm_cl_geometry** geoms, const mm_clpoint* cl, int64_t ncl,
         pr.push_back({cd.group, (int32_t)sets.size()});
         sets.push_back(SetRef{flat_x + cd.off, flat_y + cd.off, (int32_t)cd.n, 0.0, 0.0});
     }
-    std::vector<double> cost(cands.size());
     int rc;
-    {
-        TraceTimer tt("refine: device batch");
-        rc = hausdorff_sets(e, sets, pr, cost.data());
-    }
-    if (rc) return rc;
-    for (size_t ci = 0; ci < cands.size(); ++ci) {
-        if (all_costs && (int64_t)ci < cap) all_costs[ci] = cost[ci];
-        if (cost[ci] < min_h) { min_h = cost[ci]; best_angle = cands[ci].angle; best_idx = cands[ci].cl_idx; }  // :433-437
+    if (all_costs) {
+        std::vector<double> cost(cands.size());
+        {
+            TraceTimer tt("refine: device batch");
+            rc = hausdorff_sets(e, sets, pr, cost.data());
+        }
+        if (rc) return rc;
+        for (size_t ci = 0; ci < cands.size(); ++ci) {
+            if ((int64_t)ci < cap) all_costs[ci] = cost[ci];
+            if (cost[ci] < min_h) { min_h = cost[ci]; best_angle = cands[ci].angle; best_idx = cands[ci].cl_idx; }  // :433-437
+        }
+    } else {
+        // only the winner is asked for: the same strict-'<' first minimum, most candidates ruled out by
+        // lower bounds instead of evaluated (hausdorff_sets_first_min)
+        int32_t bi = -1; double bc = INFINITY;
+        {
+            TraceTimer tt("refine: device batch");
+            rc = hausdorff_sets_first_min(e, sets, pr, &bi, &bc, nullptr);
+        }
+        if (rc) return rc;
+        if (bi >= 0 && bc < min_h) { min_h = bc; best_angle = cands[(size_t)bi].angle; best_idx = cands[(size_t)bi].cl_idx; }
     }
     if (n_evals) *n_evals = (int64_t)cands.size();
     return MM_OK;

@@ -100,6 +100,10 @@ int        lb_max_points();         // largest set (either side) the bound kerne
 hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pairs, int n_work, const double* px,
                                   const double* py, void* colmin, long long n_col, void* rowmax, double* out,
                                   hipStream_t s);
+// lower bounds of the same pairs: two directed entries per output slot (a->b and b->a; col_off = slot,
+// pad = subset stride), out[slot] <= the pair's Hausdorff distance, computed from the same d^2 bits
+hipError_t launch_hausdorff_large_bound(const void* pairs, const void* work, int n_out, int n_work, const double* px,
+                                        const double* py, void* rowmax, double* out, hipStream_t s);
 int        large_rows_per_block();
 // 3-D nearest-neighbour squared distances (mm_nn_kernels.hip); pairs/work are device arrays of the
 // kernel's NnPair {q_off, nq, p_off, np, out_off, pad} / NnWork {pair, q0, c0, pad} records

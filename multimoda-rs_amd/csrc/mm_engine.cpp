@@ -511,56 +511,159 @@ static void scatter_costs(const Plan& plan, const double* plan_costs, const int6
 struct LargePairH { int32_t a_off, na, b_off, nb, col_off, pad; };
 struct LargeWorkH { int32_t pair, row0; };
 
+// Points of all referenced sets staged once in dev_pts ([px | py]); descriptors, scratch and results of
+// each launch go through host_lvl / dev_lvl, so several launches (bounds, then exact values of a few
+// pairs) share one upload.
+struct LargeBatch {
+    Engine* e = nullptr;
+    const std::vector<SetRef>* sets = nullptr;
+    std::vector<int64_t> set_at;      // offset of every staged set in the point pool (-1: not staged)
+    int64_t npts = 0;
+    size_t o_py = 0;
+
+    int stage(Engine* e_, const std::vector<SetRef>& sets_, const std::vector<std::array<int32_t, 2>>& pr,
+              const std::vector<int>& idx)
+    {
+        e = e_; sets = &sets_;
+        set_at.assign(sets_.size(), -1);
+        std::vector<int32_t> order;
+        npts = 0;
+        for (int k : idx)
+            for (int32_t sidx : {pr[(size_t)k][0], pr[(size_t)k][1]})
+                if (set_at[sidx] < 0) { set_at[sidx] = npts; npts += sets_[sidx].n; order.push_back(sidx); }
+        if (npts > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
+        o_py = align_up((size_t)npts * 8);
+        const size_t bytes = align_up(o_py + (size_t)npts * 8);
+        int rc = e->ensure(e->host_pts, bytes, true);
+        if (rc) return rc;
+        if ((rc = e->ensure(e->dev_pts, bytes, false))) return rc;
+        unsigned char* h = (unsigned char*)e->host_pts.p;
+        double *hx = (double*)h, *hy = (double*)(h + o_py);
+        parallel_for((int)order.size(), [&](int k) {   // tens of MB for a refinement grid: spread the copy
+            const int32_t sidx = order[(size_t)k];
+            std::memcpy(hx + set_at[sidx], sets_[sidx].x, (size_t)sets_[sidx].n * 8);
+            std::memcpy(hy + set_at[sidx], sets_[sidx].y, (size_t)sets_[sidx].n * 8);
+        });
+        MM_HIP(hipMemcpyAsync(e->dev_pts.p, h, bytes, hipMemcpyHostToDevice, e->stream));
+        return MM_OK;
+    }
+
+    // exact == true: hausdorff_distance of the pairs `which` (entries of pr).  exact == false: a lower
+    // bound of each from every stride-th point of either set against all points of the other.
+    int run(const std::vector<std::array<int32_t, 2>>& pr, const std::vector<int>& which, bool exact, int stride, double* out)
+    {
+        const int P = (int)which.size();
+        if (P == 0) return MM_OK;
+        std::vector<LargePairH> hp;
+        std::vector<LargeWorkH> hw;
+        int64_t ncol = 0;
+        const int rpb = large_rows_per_block();
+        for (int k = 0; k < P; ++k) {
+            const int32_t ia = pr[(size_t)which[(size_t)k]][0], ib = pr[(size_t)which[(size_t)k]][1];
+            const int64_t na = (*sets)[ia].n, nb = (*sets)[ib].n;
+            const int32_t oa = (int32_t)set_at[ia], ob = (int32_t)set_at[ib];
+            if (exact) {
+                if (ncol + nb > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
+                hp.push_back(LargePairH{oa, (int32_t)na, ob, (int32_t)nb, (int32_t)ncol, 0});
+                ncol += nb;
+                for (int64_t r0 = 0; r0 < na; r0 += rpb) hw.push_back(LargeWorkH{k, (int32_t)r0});
+            } else {
+                for (int dir = 0; dir < 2; ++dir) {
+                    const int64_t nq = dir ? nb : na;
+                    hp.push_back(dir ? LargePairH{ob, (int32_t)nb, oa, (int32_t)na, k, stride}
+                                     : LargePairH{oa, (int32_t)na, ob, (int32_t)nb, k, stride});
+                    for (int64_t r0 = 0; r0 < (nq + stride - 1) / stride; r0 += rpb)
+                        hw.push_back(LargeWorkH{(int32_t)hp.size() - 1, (int32_t)r0});
+                }
+            }
+        }
+        const size_t o_pairs = 0, o_work = align_up(hp.size() * sizeof(LargePairH));
+        const size_t in_bytes = align_up(o_work + hw.size() * sizeof(LargeWorkH));
+        const size_t o_col = in_bytes, o_row = align_up(o_col + (size_t)ncol * 8), o_out = align_up(o_row + (size_t)P * 8);
+        const size_t total = align_up(o_out + (size_t)P * 8);
+        int rc = e->ensure(e->host_lvl, std::max(in_bytes, (size_t)P * 8), true);
+        if (rc) return rc;
+        if ((rc = e->ensure(e->dev_lvl, total, false))) return rc;
+        unsigned char* h = (unsigned char*)e->host_lvl.p;
+        std::memcpy(h + o_pairs, hp.data(), hp.size() * sizeof(LargePairH));
+        std::memcpy(h + o_work, hw.data(), hw.size() * sizeof(LargeWorkH));
+        unsigned char* d = (unsigned char*)e->dev_lvl.p;
+        const double *dx = (const double*)e->dev_pts.p, *dy = (const double*)((unsigned char*)e->dev_pts.p + o_py);
+        MM_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, e->stream));
+        hipError_t he = exact ? launch_hausdorff_large(d + o_pairs, d + o_work, P, (int)hw.size(), dx, dy, d + o_col, ncol,
+                                                       d + o_row, (double*)(d + o_out), e->stream)
+                              : launch_hausdorff_large_bound(d + o_pairs, d + o_work, P, (int)hw.size(), dx, dy, d + o_row,
+                                                             (double*)(d + o_out), e->stream);
+        if (he != hipSuccess) return hip_error(he, "large-set hausdorff launch");
+        MM_HIP(hipMemcpyAsync(out, d + o_out, (size_t)P * 8, hipMemcpyDeviceToHost, e->stream));
+        MM_HIP(hipStreamSynchronize(e->stream));   // also: the pinned descriptor buffer is free again
+        return MM_OK;
+    }
+};
+
 static int hausdorff_large(Engine* e, const std::vector<SetRef>& sets, const std::vector<std::array<int32_t, 2>>& pr,
                            const std::vector<int>& idx, double* out)
 {
-    const int P = (int)idx.size();
-    std::vector<LargePairH> hp(P);
-    std::vector<LargeWorkH> hw;
-    std::vector<int64_t> set_at(sets.size(), -1);   // every set is uploaded once, however many pairs share it
-    std::vector<int32_t> order;
-    int64_t npts = 0, ncol = 0;
-    const int rpb = large_rows_per_block();
-    auto place = [&](int32_t sidx) {
-        if (set_at[sidx] < 0) { set_at[sidx] = npts; npts += sets[sidx].n; order.push_back(sidx); }
-        return set_at[sidx];
-    };
-    for (int k = 0; k < P; ++k) {
-        const int32_t ia = pr[idx[k]][0], ib = pr[idx[k]][1];
-        const int64_t na = sets[ia].n, nb = sets[ib].n;
-        const int64_t oa = place(ia), ob = place(ib);
-        if (npts > (int64_t)1 << 30 || ncol + nb > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
-        hp[k] = LargePairH{(int32_t)oa, (int32_t)na, (int32_t)ob, (int32_t)nb, (int32_t)ncol, 0};
-        ncol += nb;
-        for (int64_t r0 = 0; r0 < na; r0 += rpb) hw.push_back(LargeWorkH{k, (int32_t)r0});
-    }
-    const size_t o_px = 0, o_py = align_up((size_t)npts * 8), o_pairs = align_up(o_py + (size_t)npts * 8);
-    const size_t o_work = align_up(o_pairs + (size_t)P * sizeof(LargePairH));
-    const size_t in_bytes = align_up(o_work + hw.size() * sizeof(LargeWorkH));
-    const size_t o_col = in_bytes, o_row = align_up(o_col + (size_t)ncol * 8), o_out = align_up(o_row + (size_t)P * 8);
-    const size_t total = align_up(o_out + (size_t)P * 8);
-    int rc = e->ensure(e->host_pts, in_bytes, true);
+    LargeBatch lb;
+    int rc = lb.stage(e, sets, pr, idx);
     if (rc) return rc;
-    if ((rc = e->ensure(e->dev_pts, total, false))) return rc;
-    unsigned char* h = (unsigned char*)e->host_pts.p;
-    double *hx = (double*)(h + o_px), *hy = (double*)(h + o_py);
-    parallel_for((int)order.size(), [&](int k) {   // tens of MB for a refinement grid: spread the copy
-        const int32_t sidx = order[(size_t)k];
-        std::memcpy(hx + set_at[sidx], sets[sidx].x, (size_t)sets[sidx].n * 8);
-        std::memcpy(hy + set_at[sidx], sets[sidx].y, (size_t)sets[sidx].n * 8);
-    });
-    std::memcpy(h + o_pairs, hp.data(), (size_t)P * sizeof(LargePairH));
-    std::memcpy(h + o_work, hw.data(), hw.size() * sizeof(LargeWorkH));
-    unsigned char* d = (unsigned char*)e->dev_pts.p;
-    MM_HIP(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, e->stream));
-    hipError_t he = launch_hausdorff_large(d + o_pairs, d + o_work, P, (int)hw.size(), (const double*)(d + o_px),
-                                           (const double*)(d + o_py), d + o_col, ncol, d + o_row, (double*)(d + o_out),
-                                           e->stream);
-    if (he != hipSuccess) return hip_error(he, "large-set hausdorff launch");
-    std::vector<double> res(P);
-    MM_HIP(hipMemcpyAsync(res.data(), d + o_out, (size_t)P * 8, hipMemcpyDeviceToHost, e->stream));
-    MM_HIP(hipStreamSynchronize(e->stream));
-    for (int k = 0; k < P; ++k) out[idx[k]] = res[k];
+    std::vector<double> res(idx.size());
+    if ((rc = lb.run(pr, idx, true, 1, res.data()))) return rc;
+    for (size_t k = 0; k < idx.size(); ++k) out[idx[k]] = res[k];
+    return MM_OK;
+}
+
+// First index of minimal hausdorff_distance over the pairs (strict '<' scan in pair order, the
+// reference's refinement loop, align_algorithms.rs:433-437), without evaluating every pair: a lower
+// bound of each (every 16th point of either set against all of the other: the same squared distances
+// as the exact kernel, so bound <= exact holds bit for bit), the exact value of the pair with the
+// smallest bound as an upper bound, and exact values only for the pairs whose bound does not exceed it.
+// A pair that is skipped costs strictly more than the upper bound, so it is neither the minimum nor tied.
+// Needs every pair on the streaming kernel (both sets beyond the LDS kernel's budget) and no empty set;
+// otherwise, and for short lists, everything is evaluated.
+int hausdorff_sets_first_min(Engine* e, const std::vector<SetRef>& sets, const std::vector<std::array<int32_t, 2>>& pr,
+                             int32_t* best, double* best_cost, int64_t* n_exact)
+{
+    const int P = (int)pr.size();
+    *best = -1; *best_cost = INFINITY;
+    if (n_exact) *n_exact = 0;
+    if (P == 0) return MM_OK;
+    const int cap = max_target_points_f64();
+    bool all_large = P >= 8;
+    for (int p = 0; p < P && all_large; ++p) {
+        const int32_t ia = pr[(size_t)p][0], ib = pr[(size_t)p][1];
+        if (ia < 0 || ib < 0 || (size_t)ia >= sets.size() || (size_t)ib >= sets.size())
+            return set_error(MM_ERR_INVALID, "hausdorff_sets_first_min: set index out of range");
+        all_large = sets[ia].n > cap && sets[ib].n > cap;
+    }
+    std::vector<double> cost((size_t)P, INFINITY);
+    if (!all_large) {
+        int rc = hausdorff_sets(e, sets, pr, cost.data());
+        if (rc) return rc;
+        if (n_exact) *n_exact = P;
+    } else {
+        std::vector<int> all((size_t)P);
+        for (int p = 0; p < P; ++p) all[(size_t)p] = p;
+        LargeBatch lb;
+        int rc = lb.stage(e, sets, pr, all);
+        if (rc) return rc;
+        std::vector<double> bound((size_t)P);
+        if ((rc = lb.run(pr, all, false, 16, bound.data()))) return rc;
+        int pick = 0;
+        for (int p = 1; p < P; ++p) if (bound[(size_t)p] < bound[(size_t)pick]) pick = p;
+        std::vector<int> one{pick};
+        double ub = 0.0;
+        if ((rc = lb.run(pr, one, true, 1, &ub))) return rc;
+        cost[(size_t)pick] = ub;
+        std::vector<int> rest;
+        for (int p = 0; p < P; ++p) if (p != pick && bound[(size_t)p] <= ub) rest.push_back(p);
+        std::vector<double> res(rest.size());
+        if ((rc = lb.run(pr, rest, true, 1, res.data()))) return rc;
+        for (size_t k = 0; k < rest.size(); ++k) cost[(size_t)rest[k]] = res[k];
+        if (n_exact) *n_exact = 1 + (int64_t)rest.size();
+    }
+    for (int p = 0; p < P; ++p)
+        if (cost[(size_t)p] < *best_cost) { *best_cost = cost[(size_t)p]; *best = p; }
     return MM_OK;
 }
 

@@ -122,4 +122,9 @@ int run_batch(Engine* e, const std::vector<SetRef>& sets, const std::vector<Pair
 int hausdorff_sets(Engine* e, const std::vector<SetRef>& sets, const std::vector<std::array<int32_t, 2>>& pairs,
                    double* out);
 
+// First index of minimal hausdorff_distance over the pairs (strict '<' in pair order) and its value, with
+// lower bounds ruling pairs out where every pair runs on the streaming kernel; n_exact = pairs evaluated.
+int hausdorff_sets_first_min(Engine* e, const std::vector<SetRef>& sets, const std::vector<std::array<int32_t, 2>>& pairs,
+                             int32_t* best, double* best_cost, int64_t* n_exact);
+
 }  // namespace mm

@@ -994,7 +994,12 @@ k_large_init(unsigned long long* __restrict__ colmin, long long n_col, unsigned 
 // 7*R fp64 VALU operations, so more rows per lane amortise it (R = 8 -> 16: 6.4 -> see DESIGN 6a)
 static constexpr int kLargeR = 16;
 
-template <int R>
+// DIRECTED: the rows are every pd.pad-th point of set a only (row r of the subset = point r * pad), no
+// column minima are kept, and the block's row maximum goes to g_rowmax[pd.col_off]: the directed
+// Hausdorff distance of a SUBSET of a to all of b.  Two such entries per pair (a->b, b->a) give a lower
+// bound of the pair's Hausdorff distance in exactly the full kernel's arithmetic (same d^2 bits), at
+// 2/pad of its work.
+template <int R, bool DIRECTED>
 __global__ void __launch_bounds__(256)
 k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restrict__ work,
                   const double* __restrict__ px, const double* __restrict__ py,
@@ -1002,18 +1007,20 @@ k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restri
 {
     constexpr int NT = 256, NLI = 16, CH = 1024;
     __shared__ double2 s_b[CH];
-    __shared__ unsigned long long s_colmin[CH];
+    __shared__ unsigned long long s_colmin[DIRECTED ? 1 : CH];
     __shared__ unsigned long long s_red;
     const int tid = threadIdx.x, lj = tid & 15, li = tid >> 4;
     const LargeWork w = work[xcd_work_index(blockIdx.x, gridDim.x)];   // a pair's row blocks share one XCD's L2
     const LargePair pd = pairs[w.pair];
-    const int na = pd.na, nb = pd.nb;
+    const int nb = pd.nb;
+    const int rstep = DIRECTED ? pd.pad : 1;
+    const int na = DIRECTED ? (pd.na + rstep - 1) / rstep : pd.na;   // rows of this entry
 
     double ax[R], ay[R], rmin[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {   // padding rows duplicate the last point (see k_search)
         const int row = w.row0 + r * NLI + li;
-        const int rc = row < na ? row : na - 1;
+        const int rc = (row < na ? row : na - 1) * rstep;
         ax[r] = px[pd.a_off + rc]; ay[r] = py[pd.a_off + rc];
         rmin[r] = __longlong_as_double(0x7ff0000000000000ll);
     }
@@ -1026,7 +1033,7 @@ k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restri
         for (int j = tid; j < np; j += NT) {
             const int jc = j < n ? j : n - 1;
             s_b[j] = make_double2(px[pd.b_off + c0 + jc], py[pd.b_off + c0 + jc]);
-            s_colmin[j] = 0x7ff0000000000000ull;
+            if (!DIRECTED) s_colmin[j] = 0x7ff0000000000000ull;
         }
         __syncthreads();
         for (int k = 0; k < (np >> 4); ++k) {
@@ -1037,10 +1044,11 @@ k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restri
                 const double dx = ax[r] - b0.x, dy = ay[r] - b0.y;   // process_utils.rs:105-107
                 const double d = dx * dx + dy * dy;
                 rmin[r] = dmin2(rmin[r], d);
-                cm = dmin2(cm, d);
+                if (!DIRECTED) cm = dmin2(cm, d);
             }
-            atomicMin(&s_colmin[k * 16 + lj], (unsigned long long)__double_as_longlong(cm));
+            if (!DIRECTED) atomicMin(&s_colmin[k * 16 + lj], (unsigned long long)__double_as_longlong(cm));
         }
+        if (DIRECTED) continue;   // uniform: the barrier at the top of the next chunk orders the LDS reuse
         __syncthreads();
         // merge into the pair's column minima.  The global values only ever decrease, so a (possibly
         // stale) plain read that is already <= ours proves the atomic would change nothing; after the
@@ -1059,7 +1067,14 @@ k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restri
     rowmax = wave_max(rowmax);
     if ((tid & 63) == 0) atomicMax(&s_red, (unsigned long long)__double_as_longlong(rowmax));
     __syncthreads();
-    if (tid == 0) atomicMax(&g_rowmax[w.pair], s_red);
+    if (tid == 0) atomicMax(&g_rowmax[DIRECTED ? pd.col_off : w.pair], s_red);
+}
+
+__global__ void __launch_bounds__(256)
+k_large_finish_directed(const unsigned long long* __restrict__ g_rowmax, double* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = sqrt(__longlong_as_double((long long)g_rowmax[i]));
 }
 
 __global__ void __launch_bounds__(256)
@@ -1086,12 +1101,27 @@ hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pai
     hipLaunchKernelGGL(k_large_init, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s,
                        (unsigned long long*)colmin, n_col, (unsigned long long*)rowmax, n_pairs);
     if (n_work > 0)
-        hipLaunchKernelGGL(k_hausdorff_large<kLargeR>, dim3(n_work), dim3(256), 0, s, (const LargePair*)pairs,
+        hipLaunchKernelGGL((k_hausdorff_large<kLargeR, false>), dim3(n_work), dim3(256), 0, s, (const LargePair*)pairs,
                            (const LargeWork*)work, px, py, (unsigned long long*)colmin, (unsigned long long*)rowmax);
     hipLaunchKernelGGL(k_large_finish, dim3(n_pairs), dim3(256), 0, s, (const LargePair*)pairs,
                        (const unsigned long long*)colmin, (const unsigned long long*)rowmax, out);
     return hipGetLastError();
 }
+// Lower bounds: `pairs` holds two directed entries per output slot (col_off = slot, pad = stride);
+// out[slot] = sqrt(max of the two subset-directed squared distances).
+hipError_t launch_hausdorff_large_bound(const void* pairs, const void* work, int n_out, int n_work, const double* px,
+                                        const double* py, void* rowmax, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_large_init, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s,
+                       (unsigned long long*)rowmax, 0ll, (unsigned long long*)rowmax, n_out);
+    if (n_work > 0)
+        hipLaunchKernelGGL((k_hausdorff_large<kLargeR, true>), dim3(n_work), dim3(256), 0, s, (const LargePair*)pairs,
+                           (const LargeWork*)work, px, py, (unsigned long long*)nullptr, (unsigned long long*)rowmax);
+    hipLaunchKernelGGL(k_large_finish_directed, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned long long*)rowmax, out, n_out);
+    return hipGetLastError();
+}
+
 int large_rows_per_block() { return 16 * kLargeR; }
 
 // -------------------------------------------------------------------------------------

@@ -47,6 +47,29 @@ def test_refine_grid_matches_oracle(engine, oracle, ocl, mm, n_frames, n_points,
     assert np.array_equal(costs, ocosts)                      # bit-exact f64 Hausdorff of every candidate
     assert (ba, bi, mh) == (oba, obi, omh)
     assert np.array_equal(aligned.lumen, og.lumen)            # the target is not modified by the search
+    # winner only (what align_combined asks for): lower bounds rule candidates out on the streaming
+    # kernel's sets, everything is evaluated on the others -- the same first minimum either way
+    wa, wi, wh, none = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, idx0, 0.0, case["points"],
+                                                                rng_, step, idx_range, return_costs=False)
+    assert (wa, wi, wh) == (oba, obi, omh) and len(none) == 0
+
+
+def test_refine_winner_only_prunes_and_agrees_on_large_sets(engine, mm):
+    """Both sets far above the LDS budget (the bench's shape, scaled down): the winner-only path must
+    return exactly what the evaluate-everything path returns (that one is checked against the oracle above
+    and, at full size, by tools/bench_refine.py against the CPU restatement)."""
+    case = mm.synth.synthetic_centerline_case(n_frames=40, n_points=300, n_ccta=16000, seed=5,
+                                              true_rotation_deg=-31.0, true_index=10, clutter_frac=0.05)
+    aligned, rcl, idx0 = _aligned(mm, case)
+    for rng_deg, step_deg, idx_range in ((12.0, 1.0, 2), (4.0, 0.5, 3)):
+        full = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, idx0, 0.0, case["points"],
+                                                        math.radians(rng_deg), math.radians(step_deg), idx_range)
+        win = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, idx0, 0.0, case["points"],
+                                                       math.radians(rng_deg), math.radians(step_deg), idx_range,
+                                                       return_costs=False)
+        assert len(full[3]) >= 8 and win[:3] == full[:3]
+        k = int(np.argmin(full[3]))
+        assert full[2] == full[3][k]
 
 
 def test_refine_grid_edge_cases(engine, oracle, ocl, mm):
