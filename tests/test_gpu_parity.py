@@ -522,7 +522,8 @@ def test_bounded_screen_mixed_batch(engine, oracle, mm):
     a2, _, _ = mm.search_angles(0.5, 45.0)
     refs, tgts, angs, cs = [], [], [], []
     for n, m, ang, shuffle in [(521, 521, a1, False), (70, 400, a2, False), (400, 70, a1, False), (300, 300, a2, True),
-                               (128, 0, a1, False), (9, 12, a2, False), (528, 100, a1, True)]:
+                               (128, 0, a1, False), (9, 12, a2, False), (528, 100, a1, True), (5, 300, a2, False),
+                               (300, 3, a1, False), (1, 1, a2, False)]:
         r = blob(rng, n)
         t = blob(rng, m) if m else np.zeros((0, 2))
         if shuffle:
