@@ -603,3 +603,17 @@ def test_shift_rotation_extension_vs_oracle(engine, oracle, mm):
     p0 = [p for p, (gi, i, sh, j) in enumerate(srs.meta) if gi == 0 and i == 1 and sh == 0][0]
     assert math.degrees(res["best_angle"][p0]) == logs[0][2]
     srs.close()
+
+
+def test_shift_rotation_extension_bounded_equals_full_screen(engine, mm):
+    """The extension grid through the bounded screen (winner only, no per-candidate costs): same best
+    candidate, cost and winners as the expanded-form screen of every candidate."""
+    geoms = [mm.synthetic_pullback(12, 501, pullback_id=i) for i in range(2)]
+    out = []
+    for prec in (mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+        srs = mm.ShiftRotationSearch(engine, geoms, -3, 3, 1.0, 180.0, 501, precision=prec)
+        out.append(srs.run())
+        srs.close()
+    a, b = out
+    assert np.array_equal(a["best_idx"], b["best_idx"]) and np.array_equal(a["best_cost"], b["best_cost"])
+    assert np.array_equal(a["best_angle"], b["best_angle"]) and a["winners"] == b["winners"]
