@@ -355,7 +355,7 @@ def main():
                 "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": committed_traffic(args.workload, args.precision),
-                "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33>",
+                "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
                            "bounded": "mm::k_screen_lb<5>",
                            "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
