@@ -71,6 +71,49 @@ def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     return logs, rot, evals + e2, unresolved
 
 
+def run_steps(ks, search, finish, pipelined):
+    """Run steps `ks`: search(k) then finish(k).  pipelined: steps are independent cases, so the search of
+    step k+1 (the GPU-heavy half, and the only half with collectives) overlaps the chain walk and between
+    alignment of step k on a second host thread; every step's work still completes inside the call."""
+    if not pipelined:
+        return [(search(k), finish(k))[1] for k in ks]
+    import queue
+    import threading
+    ks = list(ks)
+    q, out, err = queue.Queue(), {}, []
+    done = {k: threading.Event() for k in ks}
+
+    def worker():
+        while True:
+            k = q.get()
+            if k is None:
+                return
+            try:
+                out[k] = finish(k)
+            except BaseException as ex:   # surfaced on the main thread
+                err.append(ex)
+                return
+            finally:
+                done[k].set()
+
+    th = threading.Thread(target=worker, name="bench-finish")
+    th.start()
+    try:
+        for i, k in enumerate(ks):
+            if i >= 2:
+                done[ks[i - 2]].wait()    # step k shares its engine with step k-2: that one must be finished
+            if err:
+                break
+            search(k)
+            q.put(k)
+    finally:
+        q.put(None)
+        th.join()
+    if err:
+        raise err[0]
+    return [out[k] for k in ks]
+
+
 def committed_traffic(workload, precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/, tools/gpu_pmc.sh): FETCH_SIZE + WRITE_SIZE in KiB, raw (on gfx950 FETCH_SIZE can
@@ -186,7 +229,11 @@ def main():
     PREC = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED,
             "f64": mm.MM_PRECISION_F64}[args.precision]
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
-    eng = mm.Engine(local_rank)
+    # two engines (stream + staging buffers each): step k lives on engine k % 2, so the search of step k+1
+    # and the walk + between alignment of step k never share one (run_steps)
+    engs = [mm.Engine(local_rank), mm.Engine(local_rank)]
+    eng = engs[0]
+    pipelined = mode == 1 and cfg.get("shift") is None and not os.environ.get("MM_BENCH_SEQUENTIAL")
 
     # Every step works on a fresh copy of the case.  In decoupled mode the copies are staged
     # into HBM (mm.WithinPlan) before the timed region: inputs resident, as the contract asks;
@@ -212,58 +259,74 @@ def main():
         cases.append(geoms)
         plan = None
         if mode == 1:
-            plan = mm.WithinPlan(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"], precision=PREC)
+            plan = mm.WithinPlan(engs[len(plans) % 2], geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                 precision=PREC)
             if world > 1:
                 plan.set_shard(rank, world)
         plans.append(plan)
-    eng.synchronize()
+    for e in engs:
+        e.synchronize()
     t_stage = (time.perf_counter() - t_stage0) / n_total
-    it = iter(range(n_total))
 
-    def one_step():
-        k = next(it)
-        geoms = cases[k]
-        if ext is not None:
-            r = plans[k].run()
-            return r["winners"], None, plans[k].pose_evals, 0
-        if world == 1:
-            return full_alignment(mm, eng, geoms, cfg, plans[k], PREC)
-        logs, evals, unres = plans[k].run_sharded()
-        rot, e2 = between_stage(mm, eng, geoms, cfg, PREC)
-        return logs, rot, evals + e2, unres
+    def make_steps(cases_, plans_, prec):
+        """(search, finish) of step k: decoupled mode splits at the exchange (everything that needs the other
+        ranks is in search); the faithful chain and the extension grid are one piece."""
+        def search(k):
+            if plans_[k] is not None and ext is None:
+                plans_[k].search()                       # levels: local search -> exchange -> merge -> commit
+        def finish(k):
+            if ext is not None:
+                r = plans_[k].run()
+                return r["winners"], None, plans_[k].pose_evals, 0
+            if plans_[k] is None:
+                return full_alignment(mm, eng, cases_[k], cfg, None, prec)
+            logs, ev, unres = plans_[k].walk()
+            rot, e2 = between_stage(mm, engs[k % 2], cases_[k], cfg, prec)
+            return logs, rot, ev + e2, unres
+        return search, finish
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        eng.synchronize()
+        for e in engs:
+            e.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    def read_profiles():
+        ms, pe, tot, bound_ = [], [], {"launches": 0, "ms": 0.0, "pair_evals": 0.0, "candidates": 0}, None
+        for e in engs:
+            a, b = e.profile_launches()
+            ms.append(a); pe.append(b)
+            bs = e.bound_stats()
+            bound_ = bs if bound_ is None else {k: bound_[k] + bs[k] for k in bs}
+            p = e.profile_read()
+            for k in tot:
+                tot[k] += p[k]
+            e.profile(False)
+        return np.concatenate(ms), np.concatenate(pe), tot, bound_
+
+    search, finish = make_steps(cases, plans, PREC)
+    run_steps(range(args.warmup), search, finish, pipelined)
     barrier()
-    eng.profile(True)
+    for e in engs:
+        e.profile(True)
     # keep the interpreter's cyclic GC (tens of ms per full collection) out of the timed steps
     import gc
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
-    evals, unresolved = 0, 0
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        res = one_step()
-        evals += res[2]
-        unresolved += res[3]
-        if os.environ.get("MM_TRACE"):
-            print(f"[bench trace] step {1e3 * (time.perf_counter() - ts):.3f} ms", file=sys.stderr)
+    results = run_steps(range(args.warmup, n_total), search, finish, pipelined)
     tb = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    res = results[-1]
+    evals = sum(r[2] for r in results)
+    unresolved = sum(r[3] for r in results)
     if os.environ.get("MM_TRACE"):
         print(f"[bench trace] final barrier {1e3 * (time.perf_counter() - tb):.3f} ms, total {1e3 * dt:.3f} ms", file=sys.stderr)
-    launch_ms, launch_pe = eng.profile_launches()
-    bound = eng.bound_stats() if args.precision == "bounded" else None
-    prof = eng.profile_read()
-    eng.profile(False)
+    launch_ms, launch_pe, prof, bound = read_profiles()
+    if args.precision != "bounded":
+        bound = None
 
     if world > 1:
         t = torch.tensor([dt, float(evals)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -281,32 +344,25 @@ def main():
         for _ in range(1 + args.steps):
             geoms = [g.copy() for g in base]
             cases2.append(geoms)
-            plan = mm.WithinPlan(eng, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"], precision=BND)
+            plan = mm.WithinPlan(engs[len(plans2) % 2], geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                 precision=BND)
             if world > 1:
                 plan.set_shard(rank, world)
             plans2.append(plan)
-        eng.synchronize()
-
-        def bounded_step(k):
-            if world == 1:
-                return full_alignment(mm, eng, cases2[k], cfg, plans2[k], BND)
-            logs, ev, unres = plans2[k].run_sharded()
-            rot, e2 = between_stage(mm, eng, cases2[k], cfg, BND)
-            return logs, rot, ev + e2, unres
-
-        bounded_step(0)
+        for e in engs:
+            e.synchronize()
+        search2, finish2 = make_steps(cases2, plans2, BND)
+        run_steps(range(1), search2, finish2, pipelined)
         barrier()
-        eng.profile(True)
+        for e in engs:
+            e.profile(True)
         tb0 = time.perf_counter()
-        ev2 = 0
-        for k in range(1, 1 + args.steps):
-            res2 = bounded_step(k)
-            ev2 += res2[2]
+        results2 = run_steps(range(1, 1 + args.steps), search2, finish2, pipelined)
         barrier()
         dt2 = time.perf_counter() - tb0
-        stats = eng.bound_stats()
-        eng.profile_read()
-        eng.profile(False)
+        res2 = results2[-1]
+        ev2 = sum(r[2] for r in results2)
+        _ms, _pe, _tot, stats = read_profiles()
         if world > 1:
             t = torch.tensor([dt2], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,7 +406,10 @@ def main():
                                    f"bruteforce grid", "mode": args.mode, "pose_evals_per_step": evals // max(args.steps, 1),
                        "chain_steps_researched_on_chain_state": unresolved,
                        "value_incl_host_staging": evals / (dt + t_stage * args.steps),
-                       "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU",
+                       "step_pipeline": ("2-stage over consecutive (independent) steps: search of step k+1 || chain walk + "
+                                         "between alignment of step k (second host thread, second engine); every step "
+                                         "completes inside the timed region") if pipelined else "sequential"},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
@@ -414,7 +473,8 @@ def main():
         if not torch.equal(lo, hi):
             raise SystemExit("ranks disagree on the alignment result")
         dist.destroy_process_group()
-    eng.close()
+    for e in engs:
+        e.close()
 
 
 if __name__ == "__main__":

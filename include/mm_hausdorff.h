@@ -16,6 +16,11 @@
  *
  * There is NO CPU fallback behind this ABI: without a HIP device every compute entry
  * point fails with MM_ERR_NO_DEVICE.
+ *
+ * Threads: an engine (its stream and staging buffers) serves one call at a time; a host that
+ * works from several threads (the reference's crossbeam scopes, entry.rs:140-277) gives each its
+ * own engine.  Every entry point selects the engine's device for the calling thread, so engines
+ * and plans may be used from a thread other than the one that created them.
  */
 #ifndef MM_HAUSDORFF_H
 #define MM_HAUSDORFF_H

@@ -771,6 +771,7 @@ int mm_engine_synchronize(mm_engine* h)
 {
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    MM_HIP(hipSetDevice(e->device));
     MM_HIP(hipStreamSynchronize(e->stream));
     return MM_OK;
 }
@@ -779,6 +780,7 @@ int mm_engine_profile(mm_engine* h, int enable)
 {
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    MM_HIP(hipSetDevice(e->device));
     MM_HIP(hipStreamSynchronize(e->stream));
     e->profile = enable != 0;
     e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0; e->launch_pair_evals.clear();
@@ -801,6 +803,7 @@ int mm_engine_profile_read(mm_engine* h, int64_t* n_launches, double* ms_total, 
 {
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    MM_HIP(hipSetDevice(e->device));
     MM_HIP(hipStreamSynchronize(e->stream));
     double ms = 0.0;
     for (size_t k = 0; k < e->launches; ++k) {
@@ -820,6 +823,7 @@ int mm_engine_profile_launches(mm_engine* h, int64_t cap, float* ms, double* pai
 {
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    MM_HIP(hipSetDevice(e->device));
     MM_HIP(hipStreamSynchronize(e->stream));
     for (size_t k = 0; k < e->launches && (int64_t)k < cap; ++k) {
         float t = 0.f;
@@ -843,6 +847,7 @@ int mm_engine_bound_stats(mm_engine* h, int64_t out[5])
 {
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine or out == NULL");
+    MM_HIP(hipSetDevice(e->device));
     unsigned long long d[8] = {0};
     MM_HIP(hipStreamSynchronize(e->stream));
     if (e->dev_stats) MM_HIP(hipMemcpy(d, e->dev_stats, 64, hipMemcpyDeviceToHost));
@@ -1031,6 +1036,7 @@ int mm_plan_run(mm_plan* h)
 {
     PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
+    MM_HIP(hipSetDevice(p->plan.eng->device));
     return p->plan.run(false);
 }
 
@@ -1038,6 +1044,7 @@ int mm_plan_run_screen_only(mm_plan* h)
 {
     PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
+    MM_HIP(hipSetDevice(p->plan.eng->device));
     return p->plan.run(true);
 }
 
@@ -1047,6 +1054,7 @@ int mm_plan_fetch(mm_plan* h, int32_t* best_idx, double* best_angle, double* bes
     PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return set_error(MM_ERR_INVALID, "plan == NULL");
     Plan& plan = p->plan;
+    MM_HIP(hipSetDevice(plan.eng->device));
     BatchResult res;
     std::vector<double> costs(all_costs ? (size_t)plan.A : 0);
     int rc = plan.fetch(res, all_costs ? costs.data() : nullptr);
@@ -1075,6 +1083,7 @@ int mm_plan_time(mm_plan* h, int iters, int screen_only, float* ms_avg)
     PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p || !ms_avg || iters <= 0) return set_error(MM_ERR_INVALID, "mm_plan_time: bad arguments");
     Plan& plan = p->plan;
+    MM_HIP(hipSetDevice(plan.eng->device));
     hipEvent_t t0, t1;
     MM_HIP(hipEventCreate(&t0));
     MM_HIP(hipEventCreate(&t1));

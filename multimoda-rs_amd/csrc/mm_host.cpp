@@ -577,6 +577,14 @@ int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresol
 
 using namespace mm;
 
+// The HIP device is a per-thread setting: a host that calls from several threads (the reference's
+// crossbeam scopes, a pipelined driver) must get the engine's device whichever thread it is on.
+static int select_device(Engine* e)
+{
+    const hipError_t he = hipSetDevice(e->device);
+    return he == hipSuccess ? MM_OK : hip_error(he, "hipSetDevice");
+}
+
 extern "C" {
 
 int64_t mm_search_angles(double step_deg, double range_deg, int has_center, double center, double limes_deg,
@@ -701,6 +709,7 @@ int mm_align_within(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     if (n_geoms <= 0 || !geoms) return set_error(MM_ERR_INVALID, "no geometries");
     if (mode != 0 && mode != 1) return set_error(MM_ERR_INVALID, "mm_align_within: mode must be 0 (chain) or 1 (decoupled)");
+    if (int drc = select_device(e)) return drc;
     if (mode == 1) {
         mm_within_plan* wp = nullptr;
         int rc = mm_within_plan_create(eh, n_geoms, geoms, step_deg, range_deg, bruteforce, sample_size, precision, &wp);
@@ -767,6 +776,7 @@ int mm_within_plan_create(mm_engine* eh, int n_geoms, mm_geometry** geoms, doubl
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine/out == NULL");
     *out = nullptr;
     if (n_geoms <= 0 || !geoms) return set_error(MM_ERR_INVALID, "no geometries");
+    if (int drc = select_device(e)) return drc;
     WithinPlan* wp = new WithinPlan();
     wp->e = e; wp->n_geoms = n_geoms; wp->geoms.assign(geoms, geoms + n_geoms);
     wp->step_deg = step_deg; wp->range_deg = range_deg; wp->bruteforce = bruteforce != 0;
@@ -783,6 +793,7 @@ int mm_within_plan_run(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_eval
     if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
     if (pose_evals) *pose_evals = 0;
     if (n_unresolved) *n_unresolved = 0;
+    if (int drc = select_device(wp->e)) return drc;
     int rc = wp->search();
     if (rc) return rc;
     return wp->walk(logs, pose_evals, n_unresolved);
@@ -793,6 +804,7 @@ int mm_within_plan_set_shard(mm_within_plan* h, int rank, int world)
     WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
     if (!wp || world <= 0 || rank < 0 || rank >= world) return set_error(MM_ERR_INVALID, "bad shard");
     if (wp->searched) return set_error(MM_ERR_INVALID, "shard must be set before the first level");
+    if (int drc = select_device(wp->e)) return drc;
     if (rank != wp->rank || world != wp->world) {
         wp->rank = rank; wp->world = world; wp->level0_staged = false;
         if (wp->level0_ok) {  // re-stage level 0 for the new slice now, not inside the search
@@ -822,6 +834,7 @@ int mm_within_plan_level_local(mm_within_plan* h, int level, double* cost, int32
 {
     WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
     if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
+    if (int drc = select_device(wp->e)) return drc;
     return wp->level_local((size_t)level, cost, uniform, angle, idx, active);
 }
 
@@ -838,6 +851,7 @@ int mm_within_plan_walk(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_eva
     if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
     if (pose_evals) *pose_evals = 0;
     if (n_unresolved) *n_unresolved = 0;
+    if (int drc = select_device(wp->e)) return drc;   // unresolved steps search on the chain state
     return wp->walk(logs, pose_evals, n_unresolved);
 }
 
@@ -887,6 +901,7 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     if (n_pairs <= 0 || !a || !b) return set_error(MM_ERR_INVALID, "no geometry pairs");
     if (pose_evals) *pose_evals = 0;
+    if (int drc = select_device(e)) return drc;
     TraceTimer t0("between: total");
     std::vector<SearchJob> jobs(n_pairs);
     std::vector<std::array<double, 3>> a_ref(n_pairs);

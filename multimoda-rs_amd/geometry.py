@@ -285,16 +285,22 @@ class WithinPlan:
         logs = [AlignLogs(b, g.n_frames - 1) for b, g in zip(log_bufs, self.geoms)]
         return logs, int(pe.value), int(nu.value)
 
-    def run_sharded(self, group=None):
-        """run() with the candidate axis sharded over the ranks of a torch.distributed group
-        (set_shard must have been called): per level, local search -> exchange -> merge ->
-        commit; then every rank walks the chain.  Same return value as run()."""
+    def search(self, group=None):
+        """The search half of run(): per level, local search (this rank's share of the candidate axis if
+        set_shard was called) -> exchange over the torch.distributed group -> merge -> commit.  Without a
+        process group this is the single-rank search.  walk() is the other half; a driver may overlap it
+        with the search of the next, independent case (bench.py)."""
         from . import distributed as D
         n_jobs, n_levels, tol = self.dims()
         for l in range(n_levels):
             local = self.level_local(l, n_jobs)
             ok, angle, _idx, _cost = D.merge_level(local, tol, group)
             self.level_commit(l, ok, angle)
+
+    def run_sharded(self, group=None):
+        """run() with the candidate axis sharded over the ranks of a torch.distributed group
+        (set_shard must have been called); every rank then walks the chain.  Same return value as run()."""
+        self.search(group)
         return self.walk()
 
     def close(self):
