@@ -1,0 +1,73 @@
+"""bench.py's two-stage step pipeline (run_steps): ordering guarantees, results and error propagation.
+Pure host logic, no GPU."""
+import importlib.util
+import os
+import threading
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def run_steps():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.run_steps
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_every_step_is_searched_then_finished_in_order(run_steps, pipelined):
+    log, lock = [], threading.Lock()
+
+    def search(k):
+        with lock:
+            log.append(("s", k))
+
+    def finish(k):
+        time.sleep(0.002 * (k % 3))
+        with lock:
+            log.append(("f", k))
+        return k * k
+
+    out = run_steps(range(2, 9), search, finish, pipelined)
+    assert out == [k * k for k in range(2, 9)]
+    pos = {e: i for i, e in enumerate(log)}
+    for k in range(2, 9):
+        assert pos[("s", k)] < pos[("f", k)]                       # a step is finished after its search
+        if k + 1 < 9:
+            assert pos[("s", k)] < pos[("s", k + 1)] and pos[("f", k)] < pos[("f", k + 1)]
+        if k + 2 < 9:
+            assert pos[("f", k)] < pos[("s", k + 2)]               # steps k and k+2 share an engine
+    if not pipelined:
+        assert [e for e in log] == [x for k in range(2, 9) for x in (("s", k), ("f", k))]
+
+
+def test_search_of_the_next_step_overlaps_the_finish_of_this_one(run_steps):
+    overlap = []
+    busy = threading.Event()
+
+    def search(k):
+        overlap.append(busy.is_set())
+        time.sleep(0.01)
+
+    def finish(k):
+        busy.set()
+        time.sleep(0.02)
+        busy.clear()
+        return k
+
+    run_steps(range(4), search, finish, True)
+    assert any(overlap[1:])
+
+
+def test_an_error_in_the_finishing_thread_reaches_the_caller(run_steps):
+    def finish(k):
+        if k == 1:
+            raise ValueError("boom")
+        return k
+
+    with pytest.raises(ValueError, match="boom"):
+        run_steps(range(5), lambda k: time.sleep(0.001), finish, True)
