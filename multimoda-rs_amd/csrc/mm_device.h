@@ -105,12 +105,15 @@ hipError_t launch_hausdorff_large(const void* pairs, const void* work, int n_pai
 hipError_t launch_hausdorff_large_bound(const void* pairs, const void* work, int n_out, int n_work, const double* px,
                                         const double* py, void* rowmax, double* out, hipStream_t s);
 int        large_rows_per_block();
-// 3-D nearest-neighbour squared distances (mm_nn_kernels.hip); pairs/work are device arrays of the
-// kernel's NnPair {q_off, nq, p_off, np, out_off, pad} / NnWork {pair, q0, c0, pad} records
-hipError_t launch_nn3_min(const void* pairs, const void* work, int n_work, const double* px, const double* py,
-                          const double* pz, double* out, long long n_out, hipStream_t s);
+// 3-D nearest-neighbour squared distances (mm_nn_kernels.hip); pairs/work are device arrays of the kernel's
+// NnPair {q_off, nq, p_off, np, out_off, qperm_off} / NnWork {pair, q0, c0, n_chunks, lb2 (f64)} records:
+// work_a always runs, work_b items first check their bound against their queries' current minima
+hipError_t launch_nn3_min(const void* pairs, const void* work_a, int n_a, const void* work_b, int n_b, const double* px,
+                          const double* py, const double* pz, const int32_t* qperm, double* out, long long n_out,
+                          hipStream_t s);
 int        nn_queries_per_block();
-int        nn_points_per_chunk();
+int        nn_chunk_points();
+int        nn_span_chunks();
 hipError_t launch_exact_all(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_shortlist(const BatchDev& b, hipStream_t s);
 hipError_t launch_rescore(const BatchDev& b, int max_na, int max_nbp, int total_candidates, hipStream_t s);

@@ -7,26 +7,34 @@
 // calculate_squared_distance: src/ccta/adjust_mesh.rs:7-12).  min is exact, so the result does not
 // depend on the traversal order.
 //
-// Mapping: one work item = 256 lanes x QPT queries of one pair against a SPAN of kNnSpan chunks of CH
-// points; a chunk is staged in LDS as (x, y, z, 0) so that a point is two ds_read broadcasts (all lanes
-// read the same address: conflict-free).  The span minima are merged into the output with a 64-bit
-// atomicMin on the bit pattern (order-preserving for values >= 0; the output is pre-filled with +inf):
-// one atomic per query and 5 120 points, so a search of 82 pairs x 20 000 queries is 13 120 equal items
-// (short tail) at 4 atomics per query.  The work list is pair-major and dealt to the XCDs in contiguous
-// eighths (xcd order as in mm_kernels.hip), so a pair's sets are fetched from HBM by one XCD.
+// Mapping: one work item = 256 lanes x QPT queries of one pair against a SPAN of chunks of CH points; a
+// chunk is staged in LDS as (x, y, z, 0) so that a point is two ds_read broadcasts (all lanes read the
+// same address: conflict-free).  The span minima are merged into the output with a 64-bit atomicMin on the
+// bit pattern (order-preserving for values >= 0; the output is pre-filled with +inf).
 // Per (query, point): 3 sub + 3 mul + 2 add + 1 min = 9 fp64 VALU operations against 2/QPT LDS reads
 // -> fp64-VALU bound.  Sets are SoA f64 in HBM (L2-resident: a set is a few hundred KB).
+//
+// Pruning (large sets, staged in slabs across their longest axis by the host so that a block of queries and a chunk of points
+// are each spatially compact): the host hands every (query block, chunk) item a lower bound lb2 of the
+// squared distance between their bounding boxes.  Pass A runs, per query block, the chunk with the smallest
+// bound; pass B runs all the others, and an item starts by reading its queries' current minima: if none
+// exceeds lb2, no point of the chunk can lower any of them and the item is skipped.  The minimum is exact
+// and order-independent, so the result is bit-identical to scanning everything; only work is saved.
+// The work lists are pair-major and dealt to the XCDs in contiguous eighths (as in mm_kernels.hip).
 #include <hip/hip_runtime.h>
 
 #include "mm_device.h"
 
 namespace mm {
 
-struct NnPair { int32_t q_off, nq, p_off, np, out_off, pad; };   // offsets into the point pool / output
-struct NnWork { int32_t pair, q0, c0, pad; };                     // queries [q0, q0+256*QPT) x points [c0, c0+kNnSpan*CH)
+// q_off / p_off: into the point pool; out_off: into the output; qperm_off: into the permutation pool (the
+// staged position j of the query set holds original point qperm[qperm_off + j]; -1 = staged in original order)
+struct NnPair { int32_t q_off, nq, p_off, np, out_off, qperm_off; };
+// queries [q0, q0 + 256 QPT) x points [c0, c0 + n_chunks CH); lb2: see "Pruning" above (pass B only)
+struct NnWork { int32_t pair, q0, c0, n_chunks; double lb2; };
 
-static constexpr int kNnChunk = 1024;
-static constexpr int kNnSpan = 5;
+static constexpr int kNnChunk = 512;
+static constexpr int kNnSpan = 10;
 
 static __device__ __forceinline__ int nn_xcd_work_index(int b, int n)   // see xcd_work_index in mm_kernels.hip
 {
@@ -41,19 +49,39 @@ k_nn3_fill(unsigned long long* __restrict__ out, long long n)
     if (i < n) out[i] = 0x7ff0000000000000ull;   // +inf
 }
 
-template <int QPT>
+template <int QPT, bool CHECK>
 __global__ void __launch_bounds__(256)
 k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int n_work,
           const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
-          unsigned long long* __restrict__ out)
+          const int32_t* __restrict__ qperm, unsigned long long* __restrict__ out)
 {
     constexpr int NT = 256, CH = kNnChunk;
     __shared__ double4 s_p[CH];
+    __shared__ unsigned long long s_max;
     const int tid = threadIdx.x;
     for (int wi = (int)gridDim.x == n_work ? nn_xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
          wi += gridDim.x) {
         const NnWork w = work[wi];
         const NnPair pd = pairs[w.pair];
+        int oi[QPT];   // where this lane's queries report: their original index in the query set
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const int q = w.q0 + k * NT + tid;
+            oi[k] = q < pd.nq ? (pd.qperm_off >= 0 ? qperm[pd.qperm_off + q] : q) : -1;
+        }
+        if (CHECK) {
+            // largest current minimum of this block's queries (a stale, larger value only costs work)
+            unsigned long long mx = 0ull;
+#pragma unroll
+            for (int k = 0; k < QPT; ++k)
+                if (oi[k] >= 0) { const unsigned long long v = out[pd.out_off + oi[k]]; mx = v > mx ? v : mx; }
+            __syncthreads();   // s_max of the previous item is no longer read
+            if (tid == 0) s_max = 0ull;
+            __syncthreads();
+            atomicMax(&s_max, mx);
+            __syncthreads();
+            if (w.lb2 >= __longlong_as_double((long long)s_max)) continue;   // uniform: nothing here can improve
+        }
         double qx[QPT], qy[QPT], qz[QPT], m[QPT];
 #pragma unroll
         for (int k = 0; k < QPT; ++k) {
@@ -62,7 +90,7 @@ k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int
             qx[k] = px[pd.q_off + qc]; qy[k] = py[pd.q_off + qc]; qz[k] = pz[pd.q_off + qc];
             m[k] = __builtin_inf();
         }
-        const int c_end = pd.np - w.c0 < kNnSpan * CH ? pd.np : w.c0 + kNnSpan * CH;
+        const int c_end = pd.np - w.c0 < w.n_chunks * CH ? pd.np : w.c0 + w.n_chunks * CH;
         for (int c0 = w.c0; c0 < c_end; c0 += CH) {
             const int n = c_end - c0 < CH ? c_end - c0 : CH;
             __syncthreads();   // previous chunk fully consumed
@@ -81,10 +109,8 @@ k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int
             }
         }
 #pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            const int q = w.q0 + k * NT + tid;
-            if (q < pd.nq) atomicMin(&out[pd.out_off + q], (unsigned long long)__double_as_longlong(m[k]));
-        }
+        for (int k = 0; k < QPT; ++k)
+            if (oi[k] >= 0) atomicMin(&out[pd.out_off + oi[k]], (unsigned long long)__double_as_longlong(m[k]));
     }
 }
 
@@ -92,17 +118,23 @@ k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int
 // 3.3e10-pair search of tools/bench_ccta.py): the kernel is bound by fp64 VALU issue, not by the LDS reads
 static constexpr int kNnQpt = 2;
 int nn_queries_per_block() { return 256 * kNnQpt; }
-int nn_points_per_chunk() { return kNnChunk * kNnSpan; }   // points one work item covers
+int nn_chunk_points() { return kNnChunk; }
+int nn_span_chunks() { return kNnSpan; }   // chunks per work item where nothing is pruned
 
-hipError_t launch_nn3_min(const void* pairs, const void* work, int n_work, const double* px, const double* py,
-                          const double* pz, double* out, long long n_out, hipStream_t s)
+// work_a: items that always run (n_a of them); work_b: items that first check their bound (n_b)
+hipError_t launch_nn3_min(const void* pairs, const void* work_a, int n_a, const void* work_b, int n_b, const double* px,
+                          const double* py, const double* pz, const int32_t* qperm, double* out, long long n_out,
+                          hipStream_t s)
 {
     if (n_out > 0)
         hipLaunchKernelGGL(k_nn3_fill, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s,
                            (unsigned long long*)out, n_out);
-    if (n_work > 0)
-        hipLaunchKernelGGL(k_nn3_min<kNnQpt>, dim3((unsigned)n_work), dim3(256), 0, s, (const NnPair*)pairs,
-                           (const NnWork*)work, n_work, px, py, pz, (unsigned long long*)out);
+    if (n_a > 0)
+        hipLaunchKernelGGL((k_nn3_min<kNnQpt, false>), dim3((unsigned)n_a), dim3(256), 0, s, (const NnPair*)pairs,
+                           (const NnWork*)work_a, n_a, px, py, pz, qperm, (unsigned long long*)out);
+    if (n_b > 0)
+        hipLaunchKernelGGL((k_nn3_min<kNnQpt, true>), dim3((unsigned)n_b), dim3(256), 0, s, (const NnPair*)pairs,
+                           (const NnWork*)work_b, n_b, px, py, pz, qperm, (unsigned long long*)out);
     return hipGetLastError();
 }
 
