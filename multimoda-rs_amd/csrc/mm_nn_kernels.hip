@@ -108,9 +108,14 @@ k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int
                 }
             }
         }
+        // the stored values only ever decrease, so a (possibly stale) plain read that is already <= ours
+        // proves the atomic would change nothing: most chunks of pass B improve few of their queries
 #pragma unroll
         for (int k = 0; k < QPT; ++k)
-            if (oi[k] >= 0) atomicMin(&out[pd.out_off + oi[k]], (unsigned long long)__double_as_longlong(m[k]));
+            if (oi[k] >= 0) {
+                const unsigned long long v = (unsigned long long)__double_as_longlong(m[k]);
+                if (v < out[pd.out_off + oi[k]]) atomicMin(&out[pd.out_off + oi[k]], v);
+            }
     }
 }
 
