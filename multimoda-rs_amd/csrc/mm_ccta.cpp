@@ -20,7 +20,17 @@ namespace {
 
 struct NnPairH { int32_t q_off, nq, p_off, np, out_off, qperm_off; };
 struct NnWorkH { int32_t pair, q0, c0, n_chunks; double lb2; };
-struct Set3 { const double* xyz; int64_t n; };   // AoS triples
+// AoS triples.  A derived set (unit != nullptr) is xyz moved by adj along per-point unit vectors where has[i]
+// (centerline_based_diameter_morphing, scale_coronary.rs:236-239): it is never materialised on the host --
+// the device computes it from the base points and the unit vectors staged once for all scalings.
+struct Set3 {
+    const double* xyz; int64_t n;
+    const double* unit = nullptr; const uint8_t* has = nullptr; double adj = 0.0;
+    double at(int64_t i, int a) const {
+        return (unit && has[i]) ? xyz[3 * i + a] + unit[3 * i + a] * adj : xyz[3 * i + a];   // :236 p + unit * x
+    }
+};
+struct NnMorphH { int32_t dst_off, n, aux_off, pad; double adj; };   // device: pool[dst_off + j] = aux point j moved by adj
 
 inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -36,19 +46,20 @@ inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 // radial, i.e. in the same or the next slab; boxes of compact 3-D patches (k-d leaves, Morton runs) overlap
 // their neighbours and the opposite wall and prune far less (measured on the bench case: pass B 6.1 ms
 // with Morton runs, 3.5 ms with k-d leaves, 2.5 ms with slabs).  Any permutation gives the same minima.
-void slab_order(const double* xyz, int64_t n, std::vector<int32_t>& perm)
+void slab_order(const Set3& st, std::vector<int32_t>& perm)
 {
+    const int64_t n = st.n;
     perm.resize((size_t)n);
     double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
     for (int64_t i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], xyz[3 * i + a]); hi[a] = std::max(hi[a], xyz[3 * i + a]); }
+        for (int a = 0; a < 3; ++a) { const double v = st.at(i, a); lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
     int ax = 0;
     for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
     const double sc = hi[ax] > lo[ax] ? 1048575.0 / (hi[ax] - lo[ax]) : 0.0;
     std::vector<uint32_t> key((size_t)n), key2((size_t)n);
     std::vector<int32_t> idx2((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
-        const double t = (xyz[3 * i + ax] - lo[ax]) * sc;
+        const double t = (st.at(i, ax) - lo[ax]) * sc;
         key[(size_t)i] = t > 0.0 ? (t < 1048575.0 ? (uint32_t)t : 1048575u) : 0u;   // NaN-safe clamp
         perm[(size_t)i] = (int32_t)i;
     }
@@ -100,7 +111,7 @@ int nn_batch_view(Engine* e, const std::vector<Set3>& sets, const std::vector<st
     std::vector<std::vector<int32_t>> perms(bases.size());
     TraceTimer tt_all("nn: batch total");
     { TraceTimer tt("nn: slab order");
-    parallel_for((int)bases.size(), [&](int k) { slab_order(sets[(size_t)bases[(size_t)k]].xyz, sets[(size_t)bases[(size_t)k]].n, perms[(size_t)k]); });
+    parallel_for((int)bases.size(), [&](int k) { slab_order(sets[(size_t)bases[(size_t)k]], perms[(size_t)k]); });
     }
     std::vector<int64_t> perm_off(bases.size() + 1, 0);
     for (size_t k = 0; k < bases.size(); ++k) perm_off[k + 1] = perm_off[k] + (int64_t)perms[k].size();
@@ -127,34 +138,71 @@ int nn_batch_view(Engine* e, const std::vector<Set3>& sets, const std::vector<st
     if (npts > (int64_t)1 << 30 || nout > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "nn batch exceeds 2^30 points");
 
     // ---- stage the points (permuted where sorted) and the bounding box of every group of qpb points ---
+    // derived sets: only their boxes are computed here; their coordinates are produced on the device from
+    // an auxiliary pool (base point, unit vector, flag per point; one entry per distinct base + order)
+    struct Aux { const double* xyz; const double* unit; const uint8_t* has; int32_t perm; int64_t n, off; };
+    std::vector<Aux> aux;
+    std::vector<int32_t> aux_of(S, -1);
+    int64_t naux = 0;
+    for (size_t s = 0; s < S; ++s) {
+        const Set3& st = sets[s];
+        if (!st.unit || st.n == 0) continue;
+        size_t k = 0;
+        for (; k < aux.size(); ++k)
+            if (aux[k].xyz == st.xyz && aux[k].unit == st.unit && aux[k].has == st.has && aux[k].perm == perm_of[s] && aux[k].n == st.n) break;
+        if (k == aux.size()) { aux.push_back(Aux{st.xyz, st.unit, st.has, perm_of[s], st.n, naux}); naux += st.n; }
+        aux_of[s] = (int32_t)k;
+    }
+    std::vector<NnMorphH> morphs;
+    for (size_t s = 0; s < S; ++s)
+        if (aux_of[s] >= 0) morphs.push_back(NnMorphH{(int32_t)soff[s], (int32_t)sets[s].n, (int32_t)aux[(size_t)aux_of[s]].off, 0, sets[s].adj});
     const size_t o_x = 0, o_y = up256((size_t)npts * 8), o_z = up256(o_y + (size_t)npts * 8);
-    const size_t o_perm = up256(o_z + (size_t)npts * 8), o_pairs = up256(o_perm + (size_t)perm_off.back() * 4);
+    const size_t o_perm = up256(o_z + (size_t)npts * 8), o_aux = up256(o_perm + (size_t)perm_off.back() * 4);
+    const size_t o_morph = up256(o_aux + (size_t)naux * 7 * 8), o_pairs = up256(o_morph + morphs.size() * sizeof(NnMorphH));
     const size_t pts_bytes = o_pairs;   // the work lists follow once they are known
     int rc = e->ensure(e->host_pts, pts_bytes, true);
     if (rc) return rc;
     unsigned char* h = (unsigned char*)e->host_pts.p;
     double *hx = (double*)(h + o_x), *hy = (double*)(h + o_y), *hz = (double*)(h + o_z);
+    double* haux = (double*)(h + o_aux);   // 7 planes of naux: bx by bz ux uy uz flag
     std::vector<int64_t> goff(S + 1, 0);
     for (size_t s = 0; s < S; ++s) goff[s + 1] = goff[s] + (sets[s].n + qpb - 1) / qpb;
     std::vector<double> box((size_t)goff.back() * 6);   // lo xyz, hi xyz
     { TraceTimer tt("nn: stage points + boxes");
-    parallel_for((int)S, [&](int si) {
+    parallel_for((int)(S + aux.size()), [&](int job) {
+        if ((size_t)job >= S) {   // one auxiliary pool entry
+            const Aux& ax = aux[(size_t)job - S];
+            const int32_t* pm = ax.perm >= 0 ? perms[(size_t)ax.perm].data() : nullptr;
+            for (int64_t j = 0; j < ax.n; ++j) {
+                const int64_t i = pm ? (int64_t)pm[j] : j;
+                for (int a = 0; a < 3; ++a) {
+                    haux[(size_t)a * (size_t)naux + (size_t)(ax.off + j)] = ax.xyz[3 * i + a];
+                    haux[(size_t)(3 + a) * (size_t)naux + (size_t)(ax.off + j)] = ax.unit[3 * i + a];
+                }
+                haux[(size_t)6 * (size_t)naux + (size_t)(ax.off + j)] = ax.has[i] ? 1.0 : 0.0;
+            }
+            return;
+        }
+        const int si = job;
         const Set3& st = sets[(size_t)si];
+        const bool derived = aux_of[(size_t)si] >= 0;
         double *dx = hx + soff[(size_t)si], *dy = hy + soff[(size_t)si], *dz = hz + soff[(size_t)si];
         const int32_t* pm = perm_of[(size_t)si] >= 0 ? perms[(size_t)perm_of[(size_t)si]].data() : nullptr;
         for (int64_t g0 = 0, g = goff[(size_t)si]; g0 < st.n; g0 += qpb, ++g) {
             double* b = box.data() + (size_t)g * 6;
             b[0] = b[1] = b[2] = DBL_MAX; b[3] = b[4] = b[5] = -DBL_MAX;
             for (int64_t j = g0; j < std::min(st.n, g0 + qpb); ++j) {
-                const double* src = st.xyz + 3 * (pm ? (int64_t)pm[j] : j);
-                dx[j] = src[0]; dy[j] = src[1]; dz[j] = src[2];
-                for (int a = 0; a < 3; ++a) { b[a] = std::min(b[a], src[a]); b[3 + a] = std::max(b[3 + a], src[a]); }
+                const int64_t i = pm ? (int64_t)pm[j] : j;
+                const double v[3] = {st.at(i, 0), st.at(i, 1), st.at(i, 2)};
+                if (!derived) { dx[j] = v[0]; dy[j] = v[1]; dz[j] = v[2]; }
+                for (int a = 0; a < 3; ++a) { b[a] = std::min(b[a], v[a]); b[3 + a] = std::max(b[3 + a], v[a]); }
             }
         }
     });
     }
     for (size_t k = 0; k < perms.size(); ++k)
         std::memcpy(h + o_perm + (size_t)perm_off[k] * 4, perms[k].data(), perms[k].size() * 4);
+    if (!morphs.empty()) std::memcpy(h + o_morph, morphs.data(), morphs.size() * sizeof(NnMorphH));
 
     // ---- work lists -------------------------------------------------------------------------------
     // squared distance between two boxes, shaved so that rounding can never overstate it
@@ -220,7 +268,21 @@ int nn_batch_view(Engine* e, const std::vector<Set3>& sets, const std::vector<st
     std::memcpy(hl + (o_wa - o_pairs), wa.data(), wa.size() * sizeof(NnWorkH));
     std::memcpy(hl + (o_wb - o_pairs), wb.data(), wb.size() * sizeof(NnWorkH));
     unsigned char* d = (unsigned char*)e->dev_pts.p;
-    MM_TRY_HIP(hipMemcpyAsync(d, h, pts_bytes, hipMemcpyHostToDevice, e->stream));
+    if (morphs.empty()) {
+        MM_TRY_HIP(hipMemcpyAsync(d, h, pts_bytes, hipMemcpyHostToDevice, e->stream));
+    } else {
+        // only the sets that exist on the host travel; the derived ones are written by the device
+        for (size_t s2 = 0; s2 < S; ++s2) {
+            if (aux_of[s2] >= 0 || sets[s2].n == 0) continue;
+            for (size_t o : {o_x, o_y, o_z})
+                MM_TRY_HIP(hipMemcpyAsync(d + o + (size_t)soff[s2] * 8, h + o + (size_t)soff[s2] * 8, (size_t)sets[s2].n * 8,
+                                          hipMemcpyHostToDevice, e->stream));
+        }
+        MM_TRY_HIP(hipMemcpyAsync(d + o_perm, h + o_perm, o_pairs - o_perm, hipMemcpyHostToDevice, e->stream));
+        const hipError_t hm = launch_nn3_morph(d + o_morph, (int)morphs.size(), (const double*)(d + o_aux), naux,
+                                               (double*)(d + o_x), (double*)(d + o_y), (double*)(d + o_z), e->stream);
+        if (hm != hipSuccess) return hip_error(hm, "morph launch");
+    }
     MM_TRY_HIP(hipMemcpyAsync(d + o_pairs, hl, in_bytes - o_pairs, hipMemcpyHostToDevice, e->stream));
     const hipError_t he = launch_nn3_min(d + o_pairs, d + o_wa, (int)wa.size(), d + o_wb, (int)wb.size(),
                                          (const double*)(d + o_x), (const double*)(d + o_y), (const double*)(d + o_z),
@@ -312,21 +374,15 @@ int scaling_search(Engine* e, const double* pts, int64_t n, const double* ref, i
         if (ncl <= 0) return set_error(MM_ERR_INVALID, "diameter search: empty centerline");
         std::vector<double> unit; std::vector<uint8_t> has;
         { TraceTimer tt("ccta: radial units"); radial_units(cl, ncl, pts, n, unit, has); }
-        double* moved = e->scratch_f64(0, (size_t)(steps + 1) * (size_t)n * 3);   // grow-only (a fresh 20 MB vector costs ms)
         std::vector<Set3> sets;
         std::vector<std::array<int32_t, 2>> pr;
         sets.push_back(Set3{ref, nr});
         for (int i = 0; i <= steps; ++i) {
-            sets.push_back(Set3{moved + (size_t)i * (size_t)n * 3, n});
+            const double x = start + (double)i * step;                        // :79
+            sets.push_back(Set3{pts, n, unit.data(), has.data(), x});         // :80, computed where it is used
             pr.push_back({0, i + 1});                                         // reference -> moved
             pr.push_back({i + 1, 0});                                         // moved -> reference
         }
-        TraceTimer tt_m("ccta: morph");
-        parallel_for(steps + 1, [&](int i) {
-            const double x = start + (double)i * step;                        // :79
-            morph(pts, unit, has, n, x, moved + (size_t)i * (size_t)n * 3);   // :80
-        });
-        tt_m.stop();
         // every morphed copy shares the spatial order of the first (points move by at most 2 mm)
         std::vector<int32_t> order_like(sets.size(), 1);
         order_like[0] = 0;

@@ -49,6 +49,28 @@ k_nn3_fill(unsigned long long* __restrict__ out, long long n)
     if (i < n) out[i] = 0x7ff0000000000000ull;   // +inf
 }
 
+// A derived set: pool[dst_off + j] = base point j moved by adj along its unit vector where its flag is set,
+// p + unit * x with one rounding for the product and one for the sum (no contraction: this file is built
+// with -ffp-contract=off), exactly centerline_based_diameter_morphing (scale_coronary.rs:236-239).
+// aux: 7 planes of n_aux doubles -- bx by bz ux uy uz flag.
+struct NnMorph { int32_t dst_off, n, aux_off, pad; double adj; };
+
+__global__ void __launch_bounds__(256)
+k_nn3_morph(const NnMorph* __restrict__ items, const double* __restrict__ aux, long long n_aux,
+            double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz)
+{
+    const NnMorph it = items[blockIdx.y];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= it.n) return;
+    const long long a = it.aux_off + j;
+    const bool mv = aux[6 * n_aux + a] != 0.0;
+    const double bx = aux[a], by = aux[n_aux + a], bz = aux[2 * n_aux + a];
+    const double ux = aux[3 * n_aux + a], uy = aux[4 * n_aux + a], uz = aux[5 * n_aux + a];
+    px[it.dst_off + j] = mv ? bx + ux * it.adj : bx;
+    py[it.dst_off + j] = mv ? by + uy * it.adj : by;
+    pz[it.dst_off + j] = mv ? bz + uz * it.adj : bz;
+}
+
 template <int QPT, bool CHECK>
 __global__ void __launch_bounds__(256)
 k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int n_work,
@@ -125,6 +147,16 @@ static constexpr int kNnQpt = 2;
 int nn_queries_per_block() { return 256 * kNnQpt; }
 int nn_chunk_points() { return kNnChunk; }
 int nn_span_chunks() { return kNnSpan; }   // chunks per work item where nothing is pruned
+
+hipError_t launch_nn3_morph(const void* items, int n_items, const double* aux, long long n_aux, double* px, double* py,
+                            double* pz, hipStream_t s)
+{
+    if (n_items <= 0) return hipSuccess;
+    // grid.x covers the largest set; blocks past a set's end exit
+    hipLaunchKernelGGL(k_nn3_morph, dim3((unsigned)((n_aux + 255) / 256), (unsigned)n_items), dim3(256), 0, s,
+                       (const NnMorph*)items, aux, n_aux, px, py, pz);
+    return hipGetLastError();
+}
 
 // work_a: items that always run (n_a of them); work_b: items that first check their bound (n_b)
 hipError_t launch_nn3_min(const void* pairs, const void* work_a, int n_a, const void* work_b, int n_b, const double* px,
