@@ -26,7 +26,7 @@ def ocl(oracle):
 
 
 @pytest.mark.parametrize("na,nb", [(1, 1), (3, 1), (1, 700), (511, 513), (512, 1024), (513, 1025), (2500, 3333),
-                                   (20000, 77)])
+                                   (20000, 77), (5000, 4500), (4096, 9000)])   # last two: slab order + pruned chunks
 def test_nn_min_sq_matches_oracle(engine, mm, occ, na, nb):
     rng = np.random.default_rng(na * 7919 + nb)
     a = rng.normal(0, 4, size=(na, 3)) + [10.0, -190.0, 1700.0]
@@ -81,6 +81,24 @@ def test_aortic_scaling_matches_oracle_and_truth(engine, mm, occ, ocl):
     b2, d2 = mm.find_aortic_scaling(np.zeros((0, 3)), case["reference"], case["centerline"], engine=engine,
                                     return_distances=True)
     assert b2 == np.finfo(np.float64).max and np.isinf(d2).all()
+
+
+def test_aortic_scaling_large_sets_pruned_path(engine, mm, occ, ocl):
+    """Both clouds above the sorting threshold: slab order, device-side scaled clouds, pass A / pass B with
+    skipped chunks -- all 41 distances and the winner must still be the oracle's bits.  Also with the points
+    shuffled (the staging order is the engine's business, results come back in the caller's order)."""
+    case = mm.synth.synthetic_tube_case(n_points=6000, n_reference=5000, true_scaling_mm=-0.4, seed=8)
+    ocl_ = to_oracle_cl(ocl, case["centerline"])
+    rng = np.random.default_rng(1)
+    for pts in (case["points"], case["points"][rng.permutation(len(case["points"]))]):
+        best, d = mm.find_aortic_scaling(pts, case["reference"], case["centerline"], engine=engine, return_distances=True)
+        obest, od = occ.aortic_diameter_optimization(pts, case["reference"], ocl_)
+        assert best == obest and np.array_equal(d, od)
+    assert best == pytest.approx(-0.4, abs=1e-12)
+    # the per-point minima of one scaled cloud, both directions, against the oracle
+    moved = mm.adjust_diameter_centerline_morphing_simple(case["centerline"], case["points"], 1.3)
+    assert np.array_equal(mm.ccta.nn_min_sq(moved, case["reference"], engine=engine), occ.nn_min_sq(moved, case["reference"]))
+    assert np.array_equal(mm.ccta.nn_min_sq(case["reference"], moved, engine=engine), occ.nn_min_sq(case["reference"], moved))
 
 
 def test_proximal_distal_scaling_matches_oracle(engine, mm, occ, ocl):
