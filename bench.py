@@ -337,8 +337,7 @@ def main():
     # The same workload through MM_PRECISION_F32_BOUNDED (lower bounds rule most candidates out before
     # the screen; winners identical).  Reported beside the headline, never as `value`: a candidate that
     # is ruled out is resolved, not evaluated, so these are not pose-evals in SURVEY 8(d)'s sense.
-    bounded_leg = None
-    if args.precision == "fast" and ext is None and mode == 1:
+    def bounded_search_leg():
         BND = mm.MM_PRECISION_F32_BOUNDED
         cases2, plans2 = [], []
         for _ in range(1 + args.steps):
@@ -370,13 +369,20 @@ def main():
         same = (list(res2[0]) == list(res[0]) and np.array_equal(res2[1], res[1]) and
                 all(np.array_equal(g.lumen, h.lumen) and np.array_equal(g.cath, h.cath) and np.array_equal(g.centroids, h.centroids)
                     for g, h in zip(cases2[-1], cases[n_total - 1])))
-        bounded_leg = {"candidates_resolved_per_s": ev2 / dt2, "ms_per_step": dt2 / args.steps * 1e3,
-                       "identical_to_bruteforce_result": bool(same), "counts": stats,
-                       "note": "MM_PRECISION_F32_BOUNDED on the same workload and steps: every candidate of the grid is "
-                               "either ruled out by a lower bound of its Hausdorff distance or evaluated; same winners, "
-                               "logs and coordinates as the brute-force run above (compared here)"}
         for pl in plans2:
-            pl.close() if hasattr(pl, "close") else None
+            pl.close()
+        return {"candidates_resolved_per_s": ev2 / dt2, "ms_per_step": dt2 / args.steps * 1e3,
+                "identical_to_bruteforce_result": bool(same), "counts": stats,
+                "note": "MM_PRECISION_F32_BOUNDED on the same workload and steps: every candidate of the grid is "
+                        "either ruled out by a lower bound of its Hausdorff distance or evaluated; same winners, "
+                        "logs and coordinates as the brute-force run above (compared here)"}
+
+    bounded_leg = None
+    if args.precision == "fast" and ext is None and mode == 1:
+        try:
+            bounded_leg = bounded_search_leg()
+        except Exception as ex:   # the extra leg must never take the headline line down with it
+            bounded_leg = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         na = nb = cfg["sample_size"] + 20
