@@ -574,6 +574,37 @@ def test_bounded_precision_ties_and_identical_sets(engine, oracle, mm):
     assert out[0] == int(np.argmin(oc)) and out[2] == oc.min()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_bounded_vs_full_screen_randomised(engine, mm, seed):
+    """Differential test on random cases (sizes, steps, torsion, near-circular frames that flatten the cost
+    curve): the bounded search and the full expanded-form screen -- itself checked against the oracle above --
+    must agree on every log entry and every output coordinate."""
+    rng = np.random.default_rng(9000 + seed)
+    n_frames = int(rng.integers(6, 40))
+    n_points = int(rng.choice([64, 120, 200, 333, 501]))
+    step = float(rng.choice([0.5, 1.0, 2.0]))
+    rng_deg = float(rng.choice([45.0, 90.0, 180.0]))
+    ss = int(rng.choice([n_points, max(60, n_points // 2), 501]))
+    sigma = float(rng.choice([0.5, 3.0, 25.0]))
+    outs = []
+    for prec in (mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+        geoms = [mm.synthetic_pullback(n_frames, n_points, pullback_id=i, seed=500 + seed, torsion_sigma_deg=sigma)
+                 for i in range(2)]
+        if seed % 3 == 0:   # flatten frame shapes towards circles: many near-ties
+            for g in geoms:
+                c = g.centroids[np.repeat(np.arange(g.n_frames), np.diff(g.lumen_off)), :2]
+                d = g.lumen[:, :2] - c
+                r = np.hypot(d[:, 0], d[:, 1])[:, None]
+                g.lumen[:, :2] = c + d * (0.15 + 0.85 * (2.0 / r))
+        logs, _ = mm.align_within(engine, geoms, step, rng_deg, True, ss, precision=prec, mode=1)
+        outs.append((logs, geoms))
+    (la, ga), (lb, gb) = outs
+    for x, y in zip(la, lb):
+        assert x == y
+    for x, y in zip(ga, gb):
+        assert np.array_equal(x.lumen, y.lumen) and np.array_equal(x.cath, y.cath) and np.array_equal(x.centroids, y.centroids)
+
+
 # ---------------------------------------------------------------------------------------
 # EXTENSION (not in the reference's 4-phase path): rotation x frame-shift grid
 # ---------------------------------------------------------------------------------------
