@@ -821,10 +821,11 @@ k_lb_topk(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pick_i
     __shared__ unsigned long long s_best;
     extern __shared__ __align__(16) unsigned char smem[];
     int* s_val = reinterpret_cast<int*>(smem);
-    const int p = blockIdx.x, tid = threadIdx.x;
+    const int p = blockIdx.x >> 1, tid = threadIdx.x;   // two workgroups per pair: reference side, target side
     const PairDesc pd = pairs[p];
     if (pd.n_ang <= 0 || pick_idx[p] < 0) return;
-    for (int side = 0; side < 2; ++side) {
+    {
+        const int side = blockIdx.x & 1;
         const int n = side ? pd.n_tgt : pd.n_ref;
         const float* src = emit + (size_t)p * (size_t)(emit_rows + emit_cols) + (side ? emit_rows : 0);
         __syncthreads();
@@ -1280,7 +1281,7 @@ hipError_t launch_screen_picks(const BatchDev& b, int round, int max_na, int max
 hipError_t launch_lb_topk(const BatchDev& b, int max_n, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lb_topk, dim3(b.n_pairs), dim3(256), (size_t)max_n * 4, s, b.pairs, b.pick_idx, b.emit,
+    hipLaunchKernelGGL(k_lb_topk, dim3(2 * b.n_pairs), dim3(256), (size_t)max_n * 4, s, b.pairs, b.pick_idx, b.emit,
                        b.emit_rows, b.emit_cols, b.qlist);
     return hipGetLastError();
 }
