@@ -524,11 +524,16 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 // unchanged; L only decides what is NOT evaluated, under the same error bounds (PairDesc::delta,
 // e2) that relate every f32 squared distance to its f64 value.
 //
-// One wave scores one candidate at a time (no workgroup barrier in the candidate loop): it rotates
-// the target into its own LDS slice, then runs two passes of the same primitive -- a small query
-// set in registers (16 column lanes x 4 row groups x 2 RP rows) against a large set in LDS:
+// One wave scores one candidate at a time (no workgroup barrier in the candidate loop) with the same
+// primitive run twice -- a small query set in registers (16 column lanes x 4 row groups x 2 RP rows) against
+// a large set that stays in LDS for the whole work item:
 //     e(q,p) = |p|^2 - 2 q.p   (2 v_pk_fma_f32 + 1 v_min3_f32 per two distances; + |q|^2 after the min)
-// pass 1: queries A' (fixed per work item), points = rotated B; pass 2: queries = rotated B', points A.
+// Only the <= 8 RP queries are rotated per candidate, never the large set: d(a, R b) = d(R^-1 a, b), so
+// pass 1 takes the queries R^-1 A' against the unrotated target (whose |b|^2 does not depend on the
+// angle) and pass 2 the queries R B' against the reference.  Rotating the reference instead of the target
+// swaps the roles of rho_r and rho_t in the rounding analysis of section 5 of DESIGN.md; PairDesc::delta
+// (24 u (rho_r + rho_t)) covers both.  (Tried: two candidates per wave sharing every LDS read -- 20 % fewer
+// instructions, 202 instead of 146 VGPRs, one wave per SIMD less: no gain.)
 // -------------------------------------------------------------------------------------
 static constexpr int kLbRP = 5;   // row PAIRS per row group: query sets up to 8 * kLbRP points
 
@@ -584,7 +589,7 @@ static __device__ __forceinline__ int lb_pass(const v2f (&qx)[RP], const v2f (&q
 // LIST: the 8 RP queries of either side are the point indices qlist[pair * 16 RP + (0..8RP-1 reference,
 // 8RP.. target)] instead of every stride-th point, and the result is merged into out_lb by maximum.
 template <int RP, bool LIST>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
             int n_work_host, const int* __restrict__ n_work_dev, int stride, const int32_t* __restrict__ qlist,
             const float* __restrict__ ptx, const float* __restrict__ pty,
@@ -606,9 +611,8 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         const int qb = LIST ? 8 * RP : (nb + stride - 1) / stride;
         const int32_t* ql = LIST ? qlist + (size_t)w.pair * (16 * RP) : nullptr;
 
-        float4* s_a = reinterpret_cast<float4*>(smem);                 // (ax, ay, |a|^2, 0), shared
-        float2* s_tgt = reinterpret_cast<float2*>(s_a + nap);          // unrotated target, shared
-        float4* s_b = reinterpret_cast<float4*>(s_tgt + nbp) + (size_t)wave * nbp;   // this wave's rotated target
+        float4* s_a = reinterpret_cast<float4*>(smem);   // (ax, ay, |a|^2, 0)
+        float4* s_t = s_a + nap;                          // (tx, ty, |t|^2, 0): the target as staged, never rotated
 
         __syncthreads();   // the previous item's readers are done
         // padding entries duplicate the last point: no effect on a minimum over the set
@@ -619,28 +623,31 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         }
         for (int j = tid; j < nbp; j += NT) {
             const int jc = j < nb ? j : nb - 1;
-            s_tgt[j] = make_float2(ptx[pd.tgt_off + jc], pty[pd.tgt_off + jc]);
+            const float x = ptx[pd.tgt_off + jc], y = pty[pd.tgt_off + jc];
+            s_t[j] = make_float4(x, y, __builtin_fmaf(x, x, y * y), 0.0f);
         }
-        // pass-1 queries: every stride-th reference point; rows past the subset repeat its last point
-        // (no effect on the maximum over the subset)
-        v2f ax[RP], ay[RP], a2[RP];
+        // the queries as staged: every stride-th point of either set (or the listed ones); rows past the subset
+        // repeat its last point (no effect on the maximum over the subset)
+        v2f ax[RP], ay[RP], a2[RP], bx[RP], by[RP], b2[RP];
 #pragma unroll
         for (int q = 0; q < RP; ++q) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int row = li * (2 * RP) + 2 * q + h;
-                const int idx = LIST ? ql[row] : (row < qa ? row : qa - 1) * stride;
-                const float x = ptx[pd.ref_off + idx], y = pty[pd.ref_off + idx];
-                const float n2 = __builtin_fmaf(x, x, y * y);
-                if (h) { ax[q].y = -2.0f * x; ay[q].y = -2.0f * y; a2[q].y = n2; }
-                else   { ax[q].x = -2.0f * x; ay[q].x = -2.0f * y; a2[q].x = n2; }
+                const int ia = LIST ? ql[row] : (row < qa ? row : qa - 1) * stride;
+                const int ib = LIST ? ql[8 * RP + row] : (row < qb ? row : qb - 1) * stride;
+                const float xa = ptx[pd.ref_off + ia], ya = pty[pd.ref_off + ia];
+                const float xb = ptx[pd.tgt_off + ib], yb = pty[pd.tgt_off + ib];
+                const float na2 = __builtin_fmaf(xa, xa, ya * ya), nb2 = __builtin_fmaf(xb, xb, yb * yb);
+                if (h) { ax[q].y = xa; ay[q].y = ya; a2[q].y = na2; bx[q].y = xb; by[q].y = yb; b2[q].y = nb2; }
+                else   { ax[q].x = xa; ay[q].x = ya; a2[q].x = na2; bx[q].x = xb; by[q].x = yb; b2[q].x = nb2; }
             }
         }
-        // the item's k-th candidate is a0 + k * step, clipped to the pair's last candidate (the sparse
-        // first round scores every step-th candidate and the last one); this wave takes k = wave + 4 i.
-        // Lane i fetches the i-th one's cos/sin now, so no candidate starts with a dependent global load
+        // the item's k-th candidate is a0 + k * step, clipped to the pair's last candidate (the sparse first
+        // round scores every step-th candidate and the last one); this wave takes k = wave + 4 i.  Lane i
+        // fetches the i-th one's cos/sin now, so no candidate starts with a dependent global load
         const int step = w.pad > 0 ? w.pad : 1;
-        float tab_c = 0.0f, tab_s = 0.0f;
+        float tab_c = 1.0f, tab_s = 0.0f;
         if (wave + 4 * lane < w.cnt) {
             const int al = min(w.a0 + (wave + 4 * lane) * step, pd.n_ang - 1);
             tab_c = cosv[pd.tab_off + al];
@@ -650,42 +657,31 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
 
         for (int i = 0, k = wave; k < w.cnt; ++i, k += 4) {
             const int a = min(w.a0 + k * step, pd.n_ang - 1);
-            const float c = __shfl(tab_c, i, 64), s = __shfl(tab_s, i, 64);
-            for (int j = lane; j < nbp; j += 64) {
-                const float2 t = s_tgt[j];
-                float4 b;
-                b.x = __builtin_fmaf(t.x, c, -(t.y * s));
-                b.y = __builtin_fmaf(t.x, s, t.y * c);
-                b.z = __builtin_fmaf(b.x, b.x, b.y * b.y);
-                b.w = 0.0f;
-                s_b[j] = b;
-            }
-            // the slice is private to this wave: its LDS writes only have to land before its own reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-            const int m1 = lb_pass<RP>(ax, ay, a2, s_b, nbp >> 4, lj);
-
-            v2f bx[RP], by[RP], b2[RP];
+            const float c = __shfl(tab_c, i, 64), sn = __shfl(tab_s, i, 64);
+            int m1, m2;
+            {   // pass 1: R^-1 A' against the target as staged.  x' = x c + y s, y' = y c - x s
+                v2f qx[RP], qy[RP];
 #pragma unroll
-            for (int q = 0; q < RP; ++q) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = li * (2 * RP) + 2 * q + h;
-                    const float4 b = s_b[LIST ? ql[8 * RP + row] : (row < qb ? row : qb - 1) * stride];
-                    if (h) { bx[q].y = -2.0f * b.x; by[q].y = -2.0f * b.y; b2[q].y = b.z; }
-                    else   { bx[q].x = -2.0f * b.x; by[q].x = -2.0f * b.y; b2[q].x = b.z; }
+                for (int q = 0; q < RP; ++q) {
+                    qx[q] = -2.0f * __builtin_elementwise_fma(ax[q], (v2f)(c), ay[q] * sn);
+                    qy[q] = -2.0f * __builtin_elementwise_fma(ay[q], (v2f)(c), -(ax[q] * sn));
                 }
+                m1 = lb_pass<RP>(qx, qy, a2, s_t, nbp >> 4, lj);
             }
-            const int m2 = lb_pass<RP>(bx, by, b2, s_a, nap >> 4, lj);
-
+            {   // pass 2: R B' (the full screen's rotation, bit for bit) against the reference
+                v2f qx[RP], qy[RP];
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                    qx[q] = -2.0f * __builtin_elementwise_fma(bx[q], (v2f)(c), -(by[q] * sn));
+                    qy[q] = -2.0f * __builtin_elementwise_fma(bx[q], (v2f)(sn), by[q] * c);
+                }
+                m2 = lb_pass<RP>(qx, qy, b2, s_a, nap >> 4, lj);
+            }
             if (lane == 0) {
                 float v = __int_as_float(m1 > m2 ? m1 : m2);
                 if (LIST) { const float o = out_lb[pd.out_off + a]; v = o > v ? o : v; }   // +inf (ruled out) stays
                 out_lb[pd.out_off + a] = v;
             }
-            __builtin_amdgcn_wave_barrier();   // all reads of the slice precede the next candidate's writes
         }
     }
 }
@@ -1213,8 +1209,8 @@ hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStr
 
 // ---- bounded screen (k_screen_lb -> pick -> screen the picks -> keep -> screen the survivors) ----
 int lb_max_query_points() { return 8 * kLbRP; }
-int lb_max_points() { return 1024; }
-size_t lds_bytes_lb(int nap, int nbp) { return (size_t)nap * 16 + (size_t)nbp * (8 + 4 * 16); }
+int lb_max_points() { return 4096; }
+size_t lds_bytes_lb(int nap, int nbp) { return ((size_t)nap + (size_t)nbp) * 16; }
 
 template <int RP, bool LIST>
 static hipError_t launch_lb_t(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
