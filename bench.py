@@ -189,7 +189,10 @@ def main():
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
     ap.add_argument("--precision", default="fast", choices=["f32", "fast", "bounded", "f64"],
                     help="candidate scoring: f32 = direct-form f32 screen + exact f64 re-score; fast = expanded-form "
-                         "f32 screen + exact f64 re-score (default); f64 = every candidate in exact f64")
+                         "f32 screen + exact f64 re-score (default; the same workload through the bounded search is "
+                         "reported beside it); bounded = lower bounds rule candidates out before the screen (not "
+                         "pose-evals in SURVEY 8(d)'s sense: for measurements of that path, never the headline); "
+                         "f64 = every candidate in exact f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the CPU baseline (default: the GPU box's CPU share per GPU, 16, or fewer cores)")
@@ -421,7 +424,7 @@ def main():
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": committed_traffic(args.workload, args.precision),
                 "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
-                           "bounded": "mm::k_screen_lb<5>",
+                           "bounded": "mm::k_screen_lb<5, false>",
                            "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "dominant_launch": dominant_launch(launch_ms, launch_pe),
