@@ -439,6 +439,8 @@ def main():
         }
         if bound is not None:
             out["config"]["bounded_screen"] = bound
+            out["unit"] = "candidates resolved/s"
+            out["metric"] += " -- BOUNDED SEARCH: candidates ruled out by a lower bound or evaluated (same winners), not pose-evals"
         if bounded_leg is not None:
             out["bounded_search"] = bounded_leg
         if not args.no_cpu_baseline and world == 1:
