@@ -87,9 +87,13 @@ void slab_order(const Set3& st, std::vector<int32_t>& perm)
 // exact and order-independent: pruned or not, sorted or not, the results are the same bits.
 struct MinView { const double* p; int64_t n; };
 
+// sums (nullable): if given, only the per-pair sums of the minima (sequential, index order) come back
+// -- sums[k] for pair k, NaN where the pair has no minima -- and view[k].p stays null.
 int nn_batch_view(Engine* e, const std::vector<Set3>& sets, const std::vector<std::array<int32_t, 2>>& pr,
-                  std::vector<MinView>& view, const std::vector<int32_t>* order_like = nullptr)
+                  std::vector<MinView>& view, const std::vector<int32_t>* order_like = nullptr,
+                  std::vector<double>* sums = nullptr)
 {
+    if (sums) sums->assign(pr.size(), NAN);
     view.assign(pr.size(), MinView{nullptr, 0});
     const size_t S = sets.size();
     std::vector<int64_t> soff(S + 1, 0);
@@ -258,7 +262,7 @@ int nn_batch_view(Engine* e, const std::vector<Set3>& sets, const std::vector<st
 
     const size_t o_wa = up256(o_pairs + hp.size() * sizeof(NnPairH)), o_wb = up256(o_wa + wa.size() * sizeof(NnWorkH));
     const size_t in_bytes = up256(o_wb + wb.size() * sizeof(NnWorkH));
-    const size_t o_out = in_bytes, total = up256(o_out + (size_t)nout * 8);
+    const size_t o_out = in_bytes, o_sums = up256(o_out + (size_t)nout * 8), total = up256(o_sums + hp.size() * 8);
     // descriptors and results go through the level buffers (the point staging above is still in flight-free
     // pinned memory of its own), so nothing staged so far moves
     if ((rc = e->ensure(e->host_lvl, std::max(in_bytes - o_pairs, (size_t)nout * 8), true))) return rc;
@@ -288,6 +292,14 @@ int nn_batch_view(Engine* e, const std::vector<Set3>& sets, const std::vector<st
                                          (const double*)(d + o_x), (const double*)(d + o_y), (const double*)(d + o_z),
                                          (const int32_t*)(d + o_perm), (double*)(d + o_out), nout, e->stream);
     if (he != hipSuccess) return hip_error(he, "nearest-neighbour launch");
+    if (sums) {
+        const hipError_t hs = launch_nn3_sums(d + o_pairs, (int)hp.size(), (const double*)(d + o_out), (double*)(d + o_sums), e->stream);
+        if (hs != hipSuccess) return hip_error(hs, "sum launch");
+        MM_TRY_HIP(hipMemcpyAsync(hl, d + o_sums, hp.size() * 8, hipMemcpyDeviceToHost, e->stream));
+        MM_TRY_HIP(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < hp.size(); ++i) (*sums)[(size_t)owner[i]] = ((const double*)hl)[i];
+        return MM_OK;
+    }
     MM_TRY_HIP(hipMemcpyAsync(hl, d + o_out, (size_t)nout * 8, hipMemcpyDeviceToHost, e->stream));
     MM_TRY_HIP(hipStreamSynchronize(e->stream));
     const double* res = (const double*)hl;
@@ -321,6 +333,13 @@ double symmetric_from_minima(const MinView& a_to_b, const MinView& b_to_a)
     for (int64_t i = 0; i < b_to_a.n; ++i) sb += b_to_a.p[i];                 // :204-211
     const double avg_b = sb / (double)b_to_a.n;                              // :213
     return std::sqrt((avg_a + avg_b) / 2.0);                                  // :215
+}
+
+// the same from the two sums of minima (sequential folds done on the device)
+double symmetric_from_sums(double sa, int64_t na, double sb, int64_t nb)
+{
+    if (na == 0 || nb == 0) return INFINITY;                                  // :189-191
+    return std::sqrt((sa / (double)na + sb / (double)nb) / 2.0);              // :202, :213, :215
 }
 
 // unit vector from the closest centerline point to each point (:226-235); has[i] = 0 when the point sits
@@ -387,11 +406,11 @@ int scaling_search(Engine* e, const double* pts, int64_t n, const double* ref, i
         std::vector<int32_t> order_like(sets.size(), 1);
         order_like[0] = 0;
         std::vector<MinView> mins;
-        int rc = nn_batch_view(e, sets, pr, mins, &order_like);
+        std::vector<double> sums;   // the 82 sequential sums are taken on the device: 82 numbers come back, not 13 MB
+        int rc = nn_batch_view(e, sets, pr, mins, &order_like, &sums);
         if (rc) return rc;
-        // the 82 sums are independent: one job each, every sum sequential in index order
-        TraceTimer tt_s("ccta: sums");
-        parallel_for(steps + 1, [&](int i) { dist[(size_t)i] = symmetric_from_minima(mins[2 * (size_t)i], mins[2 * (size_t)i + 1]); });  // :81
+        for (int i = 0; i <= steps; ++i)
+            dist[(size_t)i] = symmetric_from_sums(sums[2 * (size_t)i], mins[2 * (size_t)i].n, sums[2 * (size_t)i + 1], mins[2 * (size_t)i + 1].n);  // :81
     }
     for (int i = 0; i <= steps; ++i) {
         if (all_dist) all_dist[i] = dist[(size_t)i];

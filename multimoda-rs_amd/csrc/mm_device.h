@@ -115,6 +115,8 @@ hipError_t launch_nn3_min(const void* pairs, const void* work_a, int n_a, const 
 // from 7 planes of n_aux doubles (bx by bz ux uy uz flag), written into the SoA point pool
 hipError_t launch_nn3_morph(const void* items, int n_items, const double* aux, long long n_aux, double* px, double* py,
                             double* pz, hipStream_t s);
+// sums[p] = the minima of pair p added up in index order (sequential f64 fold)
+hipError_t launch_nn3_sums(const void* pairs, int n_pairs, const double* out, double* sums, hipStream_t s);
 int        nn_queries_per_block();
 int        nn_chunk_points();
 int        nn_span_chunks();

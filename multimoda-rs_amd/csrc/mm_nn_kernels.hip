@@ -148,6 +148,43 @@ int nn_queries_per_block() { return 256 * kNnQpt; }
 int nn_chunk_points() { return kNnChunk; }
 int nn_span_chunks() { return kNnSpan; }   // chunks per work item where nothing is pruned
 
+// Per pair: the sum of its minima in index order, one addition at a time -- the sequential fold of
+// symmetric_nn_distance (scale_coronary.rs:193-211), so that a search only has to bring 82 numbers back
+// instead of every minimum.  One wave per pair: all lanes fetch a tile into LDS (coalesced), lane 0 folds it
+// (the chain of dependent adds is the cost: ~20 k x a few cycles; the LDS reads run ahead of it).
+__global__ void __launch_bounds__(64)
+k_nn3_sums(const NnPair* __restrict__ pairs, int n_pairs, const double* __restrict__ out, double* __restrict__ sums)
+{
+    constexpr int T = 2048;
+    __shared__ double s_v[T];
+    const NnPair pd = pairs[blockIdx.x];
+    const double* v = out + pd.out_off;
+    double s = 0.0;
+    for (int i0 = 0; i0 < pd.nq; i0 += T) {
+        const int n = pd.nq - i0 < T ? pd.nq - i0 : T;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 64) s_v[j] = v[i0 + j];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int j = 0;
+            for (; j + 8 <= n; j += 8) {
+                const double a0 = s_v[j], a1 = s_v[j + 1], a2 = s_v[j + 2], a3 = s_v[j + 3];
+                const double a4 = s_v[j + 4], a5 = s_v[j + 5], a6 = s_v[j + 6], a7 = s_v[j + 7];
+                s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
+            }
+            for (; j < n; ++j) s += s_v[j];
+        }
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = s;
+}
+
+hipError_t launch_nn3_sums(const void* pairs, int n_pairs, const double* out, double* sums, hipStream_t s)
+{
+    if (n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_nn3_sums, dim3((unsigned)n_pairs), dim3(64), 0, s, (const NnPair*)pairs, n_pairs, out, sums);
+    return hipGetLastError();
+}
+
 hipError_t launch_nn3_morph(const void* items, int n_items, const double* aux, long long n_aux, double* px, double* py,
                             double* pz, hipStream_t s)
 {
