@@ -270,6 +270,11 @@ def main():
     for e in engs:
         e.synchronize()
     t_stage = (time.perf_counter() - t_stage0) / n_total
+    if pipelined:
+        # setup, not a step: let both engines grow the transient buffers of the between stage now (the W warm-up
+        # steps alone would leave the second engine's first allocations inside the timed region when W = 1)
+        for e in engs:
+            between_stage(mm, e, [g.copy() for g in base], cfg, PREC)
 
     def make_steps(cases_, plans_, prec):
         """(search, finish) of step k: decoupled mode splits at the exchange (everything that needs the other
