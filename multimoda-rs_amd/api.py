@@ -314,9 +314,11 @@ def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
 
 def align_frames_in_geometries(geoms: Sequence[G.FlatGeometry], step_deg: float, range_deg: float, smooth: bool,
                                bruteforce: bool, sample_size: int, engine: Optional[N.Engine] = None,
-                               precision: int = N.MM_PRECISION_F32, mode: int = 1):
+                               precision: int = N.MM_PRECISION_F32_BOUNDED, mode: int = 1):
     """``align_frames_in_geometry`` (align_within.rs:24-171) for several pullbacks at once (the
-    reference's crossbeam scope, entry.rs:140-203).  In place; returns (logs, anomalous flags)."""
+    reference's crossbeam scope, entry.rs:140-203).  In place; returns (logs, anomalous flags).
+    The default precision resolves large candidate grids by bounds (small batches are
+    screened outright) -- same winners, logs and coordinates as any other precision."""
     eng = engine or default_engine()
     for g in geoms:                                      # align_within.rs:32-40
         if g.n_frames == 0:
