@@ -605,6 +605,53 @@ def test_bounded_vs_full_screen_randomised(engine, mm, seed):
         assert np.array_equal(x.lumen, y.lumen) and np.array_equal(x.cath, y.cath) and np.array_equal(x.centroids, y.centroids)
 
 
+def test_four_concurrent_callers_each_with_its_own_engine(oracle, mm):
+    """the library has to serve >= 4 concurrent callers (the reference's crossbeam scopes).  The
+    model is one engine per host thread; every entry point selects the engine's device for the calling thread.
+    Four threads run searches, chains and between alignments at once and each must get the oracle's result."""
+    import threading
+    geoms_by_thread, results, errors = {}, {}, []
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+
+    def work(t):
+        try:
+            eng = mm.Engine()
+            rng = np.random.default_rng(700 + t)
+            out = []
+            for rep in range(3):
+                ref, tgt = blob(rng, 200 + 40 * t), blob(rng, 180 + 30 * t)
+                prec = (mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED, mm.MM_PRECISION_F64)[(t + rep) % 4]
+                out.append((ref, tgt, eng.best_rotation(ref, tgt, angles, (4.5, 4.5), precision=prec)))
+            geoms = [mm.synthetic_pullback(6 + t, 160, pullback_id=t), mm.synthetic_pullback(7, 160, pullback_id=t + 1)]
+            logs, _ = mm.align_within(eng, geoms, 1.0, 90.0, True, 160, mode=t % 2)
+            rot, _ = mm.align_between(eng, [(geoms[0], geoms[1])], 90.0, 1.0, 160)
+            results[t] = (out, logs, rot)
+            geoms_by_thread[t] = geoms
+            eng.close()
+        except BaseException as ex:
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        out, logs, rot = results[t]
+        for ref, tgt, got in out:
+            oc = oracle.costs_over_angles(ref, tgt, angles, 4.5, 4.5)
+            assert got[0] == int(np.argmin(oc)) and got[2] == oc.min()
+        fresh = [mm.synthetic_pullback(6 + t, 160, pullback_id=t), mm.synthetic_pullback(7, 160, pullback_id=t + 1)]
+        og = [to_oracle(oracle, g) for g in fresh]
+        for lg, o in zip(logs, og):
+            assert lg == oracle.align_within_chain(o, 1.0, 90.0, True, 160, n_threads=2)
+        orot = oracle.align_between(og[0], og[1], 90.0, 1.0, 160, n_threads=2)
+        assert rot[0] == orot
+        for g, o in zip(geoms_by_thread[t], og):
+            assert geoms_equal(g, o)
+
+
 # ---------------------------------------------------------------------------------------
 # EXTENSION (not in the reference's 4-phase path): rotation x frame-shift grid
 # ---------------------------------------------------------------------------------------
