@@ -317,6 +317,15 @@ int64_t mm_extract_between_points(const mm_geometry* g, int64_t sample_size,
 void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double dz);
 void mm_frame_rotate(mm_geometry* g, int32_t i, double angle, double cx, double cy);
 
+/* read_contour_data (src/intravascular/io/input.rs:172-194) for the regular case: headerless rows of
+ * exactly four plain decimal numbers `frame<delim>x<delim>y<delim>z`, LF or CRLF line ends, the first a
+ * non-negative integer below 2^32.  Every number is converted with correct rounding (what Rust's
+ * str::parse::<f64> and the csv crate deliver).  Returns the number of rows written to out (4 doubles
+ * each, at most cap rows are stored), or -1 if the text is not of that regular form (quotes, blank or
+ * ragged lines, other characters, non-finite values): the caller then reads it row by row, skipping
+ * invalid rows like the reference.  Host only, no device. */
+int64_t mm_parse_contour_table(const char* text, int64_t len, char delim, double* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@ EXPORTS = [
     "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy",
     "mm_within_plan_set_shard", "mm_within_plan_dims", "mm_within_plan_level_local", "mm_within_plan_level_commit",
     "mm_within_plan_walk", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
-    "mm_frame_translate", "mm_frame_rotate",
+    "mm_frame_translate", "mm_frame_rotate", "mm_parse_contour_table",
 ]
 # include/mm_centerline.h
 EXPORTS_CENTERLINE = [
@@ -143,6 +143,8 @@ def lib():
     L.mm_engine_profile_launches.argtypes = [P, I64, P, P, C.POINTER(I64)]
     L.mm_engine_bound_stats.restype = I
     L.mm_engine_bound_stats.argtypes = [P, P]
+    L.mm_parse_contour_table.restype = I64
+    L.mm_parse_contour_table.argtypes = [C.c_char_p, I64, C.c_char, P, I64]
     L.mm_engine_set_bound_min_candidates.restype = I
     L.mm_engine_set_bound_min_candidates.argtypes = [P, I64]
     L.mm_hausdorff_2d.restype = I

@@ -642,6 +642,81 @@ int64_t mm_refine_downsample_count(int64_t n_filtered, int64_t n_points_per_fram
 }
 
 // frame.rs:17-38
+// One plain decimal number [+-]digits[.digits][(e|E)[+-]digits] starting at p (end = text end); on success
+// *val is its correctly rounded double and the position after it is returned, else nullptr.
+// Clinger's fast path: a mantissa below 2^53 times or divided by an exactly representable power of ten
+// (10^0..10^22) is ONE correctly rounded IEEE operation; everything else goes through strtod.
+static const char* parse_decimal(const char* p, const char* end, double* val)
+{
+    static const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                      1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* start = p;
+    bool neg = false;
+    if (p < end && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
+    uint64_t m = 0;
+    int digits = 0, sig = 0, e10 = 0;
+    bool exact = true;
+    auto take = [&](char c, bool frac) {
+        ++digits;
+        if (sig < 19) { m = m * 10 + (uint64_t)(c - '0'); if (m) ++sig; if (frac) --e10; }
+        else { if (c != '0') exact = false; if (!frac) ++e10; }
+    };
+    while (p < end && *p >= '0' && *p <= '9') take(*p++, false);
+    if (p < end && *p == '.') {
+        ++p;
+        while (p < end && *p >= '0' && *p <= '9') take(*p++, true);
+    }
+    if (digits == 0) return nullptr;
+    if (p < end && (*p == 'e' || *p == 'E')) {
+        const char* q = p + 1;
+        bool eneg = false;
+        if (q < end && (*q == '+' || *q == '-')) { eneg = *q == '-'; ++q; }
+        if (q >= end || *q < '0' || *q > '9') return nullptr;
+        int ex = 0;
+        while (q < end && *q >= '0' && *q <= '9') { if (ex < 100000) ex = ex * 10 + (*q - '0'); ++q; }
+        e10 += eneg ? -ex : ex;
+        p = q;
+    }
+    if (exact && m <= ((uint64_t)1 << 53) && e10 >= -22 && e10 <= 22) {
+        double v = (double)m;
+        v = e10 < 0 ? v / kPow10[-e10] : v * kPow10[e10];
+        *val = neg ? -v : v;
+        return p;
+    }
+    char buf[128];
+    const size_t n = (size_t)(p - start);
+    if (n >= sizeof(buf)) return nullptr;
+    std::memcpy(buf, start, n);
+    buf[n] = 0;
+    char* stop = nullptr;
+    *val = std::strtod(buf, &stop);
+    return stop == buf + n ? p : nullptr;
+}
+
+int64_t mm_parse_contour_table(const char* text, int64_t len, char delim, double* out, int64_t cap)
+{
+    if (!text || len < 0 || (cap > 0 && !out)) { set_error(MM_ERR_INVALID, "mm_parse_contour_table: bad arguments"); return -1; }
+    const char *p = text, *end = text + len;
+    int64_t rows = 0;
+    while (p < end) {
+        double v[4];
+        for (int f = 0; f < 4; ++f) {
+            p = parse_decimal(p, end, &v[f]);
+            if (!p || !std::isfinite(v[f])) return -1;
+            if (f < 3) { if (p >= end || *p != delim) return -1; ++p; }
+        }
+        if (p < end) {                      // line end: LF or CRLF
+            if (*p == '\r') { ++p; if (p >= end || *p != '\n') return -1; }
+            if (*p != '\n') return -1;
+            ++p;
+        }
+        if (v[0] < 0.0 || v[0] != std::floor(v[0]) || v[0] > 4294967295.0) return -1;   // frame index: u32
+        if (rows < cap) { out[4 * rows] = v[0]; out[4 * rows + 1] = v[1]; out[4 * rows + 2] = v[2]; out[4 * rows + 3] = v[3]; }
+        ++rows;
+    }
+    return rows;
+}
+
 void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double dz)
 {
     span_translate(g->lumen, g->lumen_off[i], g->lumen_off[i + 1], dx, dy, dz);

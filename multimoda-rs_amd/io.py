@@ -91,10 +91,34 @@ def _detect_delimiter(path: str) -> str:
     return "\t" if first.count("\t") > first.count(",") else ","
 
 
+def _read_numeric_table_native(path: str, delim: str) -> Optional[np.ndarray]:
+    """The same fast path in the native library (``mm_parse_contour_table``, include/mm_hausdorff.h): one pass
+    over the bytes, correctly rounded conversions, no interpreter lock while it runs -- the pullbacks' files are
+    read by parallel threads.  None if the file is not of the regular form or the library is unavailable."""
+    try:
+        from . import _native as N
+        lib = N.lib()
+    except Exception:
+        return None
+    with open(path, "rb") as f:
+        raw = f.read()
+    if not raw:
+        return None
+    cap = raw.count(b"\n") + 1
+    out = np.empty((cap, 4), dtype=np.float64)
+    rows = lib.mm_parse_contour_table(raw, len(raw), delim.encode("ascii"), N._ptr(out), cap)
+    if rows < 0 or rows > cap:
+        return None
+    return out[:rows]
+
+
 def _read_numeric_table(path: str, delim: str) -> Optional[np.ndarray]:
     """Fast path of read_contour_data for the regular case -- every line is exactly four plain numbers,
     the first a non-negative integer.  Same values as the row-by-row reader (both parse with correctly
     rounded strtod); anything irregular returns None and the robust reader decides row by row."""
+    native = _read_numeric_table_native(path, delim)
+    if native is not None:
+        return native
     with open(path, "r", newline="") as f:
         text = f.read()
     if not text or '"' in text:

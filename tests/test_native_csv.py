@@ -1,0 +1,91 @@
+"""mm_parse_contour_table (include/mm_hausdorff.h): the native fast path of read_contour_data must give the
+same doubles as Python's correctly rounded float() and reject everything that is not the regular form, so that
+the row-by-row reader (which skips invalid rows like the reference, input.rs:172-194) takes over.  Host only."""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def io():
+    import __graft_entry__ as ge
+    ge.build()
+    return importlib.import_module("multimoda_rs_amd.io")
+
+
+def _write(tmp_path, text, name="c.csv"):
+    p = tmp_path / name
+    p.write_bytes(text.encode("utf-8") if isinstance(text, str) else text)
+    return str(p)
+
+
+def test_golden_files_equal_the_python_readers(io):
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "**", "*.csv"), recursive=True))
+    files = [f for f in files if "records" not in os.path.basename(f) and "manual" not in os.path.basename(f)]
+    assert len(files) >= 12
+    for f in files:
+        d = io._detect_delimiter(f)
+        a = io._read_numeric_table_native(f, d)
+        assert a is not None, f
+        rows = []
+        with open(f, newline="") as fh:
+            for line in fh.read().replace("\r\n", "\n").splitlines():
+                rec = line.split(d)
+                rows.append((float(int(rec[0])), float(rec[1]), float(rec[2]), float(rec[3])))
+        assert np.array_equal(a, np.array(rows).reshape(-1, 4)), f
+
+
+def test_random_numbers_in_every_accepted_notation(io, tmp_path):
+    rng = np.random.default_rng(11)
+    toks, vals = [], []
+    for k in range(4000):
+        kind = k % 8
+        if kind == 0:
+            t = repr(float(rng.normal(0, 100)))                       # shortest repr, 17 significant digits at most
+        elif kind == 1:
+            t = "%.3f" % rng.uniform(-10, 10)
+        elif kind == 2:
+            t = "%.12e" % rng.uniform(-1, 1)
+        elif kind == 3:
+            t = "%+.6E" % (rng.uniform(1, 9) * 10.0 ** int(rng.integers(-300, 300)))
+        elif kind == 4:
+            t = "".join(rng.choice(list("0123456789"), size=int(rng.integers(1, 30)))) + "." + \
+                "".join(rng.choice(list("0123456789"), size=int(rng.integers(0, 30))))   # > 19 digits: strtod path
+        elif kind == 5:
+            t = ["-0", "0.0", "+0.000", "-0.0e5", "00012.50", ".5", "5.", "1e22", "1e23", "9007199254740993"][k // 8 % 10]
+        elif kind == 6:
+            t = "%d" % int(rng.integers(-10**9, 10**9))
+        else:
+            t = "2.2250738585072014e-308" if k % 16 == 7 else "4.9e-324"   # smallest normal / subnormal
+        toks.append(t)
+        vals.append(float(t))
+    for delim, eol, final in ((",", "\n", True), ("\t", "\r\n", True), (",", "\n", False)):
+        lines = [delim.join([str(i)] + toks[3 * i:3 * i + 3]) for i in range(len(toks) // 3)]
+        text = eol.join(lines) + (eol if final else "")
+        a = io._read_numeric_table_native(_write(tmp_path, text), delim)
+        assert a is not None and a.shape == (len(lines), 4)
+        exp = np.array([[float(i)] + vals[3 * i:3 * i + 3] for i in range(len(lines))])
+        assert np.array_equal(a, exp) and np.array_equal(np.signbit(a), np.signbit(exp))
+
+
+@pytest.mark.parametrize("text", [
+    '1,"2.0",3,4\n', "1,2,3\n", "1,2,3,4,5\n", "1,2,3,4\n\n5,6,7,8\n", "1,2,abc,4\n", "1,2,3,4\r5,6,7,8\n",
+    "-1,2,3,4\n", "1.5,2,3,4\n", "4294967296,2,3,4\n", "1,inf,3,4\n", "1,nan,3,4\n", "1,1e999,3,4\n", "1, 2,3,4\n",
+    "1,2,3,4 \n", "1,0x10,3,4\n", "1,1_0,3,4\n", "1,2e,3,4\n", "1,.,3,4\n", "\n", "1,2,3,4\n5,6,7\n"])
+def test_irregular_text_is_left_to_the_row_reader(io, tmp_path, text):
+    assert io._read_numeric_table_native(_write(tmp_path, text), ",") is None
+    # and the public reader still does what the reference does: skip the rows it cannot parse
+    got = io.read_contour_data(_write(tmp_path, text, "d.csv"))
+    assert got.shape[1] == 4 and got.shape[0] <= text.count("\n") + 1
+
+
+def test_empty_file_and_read_contour_data_dispatch(io, tmp_path):
+    assert io._read_numeric_table_native(_write(tmp_path, ""), ",") is None
+    assert io.read_contour_data(_write(tmp_path, "", "e.csv")).shape == (0, 4)
+    a = io.read_contour_data(_write(tmp_path, "3\t1.25\t-2.5\t7\r\n4\t0.1\t0.2\t0.3", "t.csv"))
+    assert np.array_equal(a, np.array([[3.0, 1.25, -2.5, 7.0], [4.0, 0.1, 0.2, 0.3]]))
