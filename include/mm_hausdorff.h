@@ -79,9 +79,12 @@ int         mm_device_count(void);
 const char* mm_last_error(void);
 const char* mm_version(void);
 
-/* device < 0 -> current device.  stream == NULL -> the engine creates its own stream;
- * otherwise `stream` is a hipStream_t the caller owns (e.g. torch's current stream), and
- * every kernel of this engine is launched on it. */
+/* device < 0 -> current device.  stream == NULL -> the engine creates its own two streams: a main stream for
+ * the searches of device-resident plans (the long launches) and a high-priority side stream for everything short
+ * (staging, the between-pullback searches, the per-step searches of the faithful chain), so that a driver which
+ * overlaps consecutive cases on two engines does not queue a 20 us kernel behind the other engine's 30 ms launch.
+ * Otherwise `stream` is a hipStream_t the caller owns (e.g. torch's current stream), and every kernel of this
+ * engine is launched on it.  mm_engine_stream returns the main stream. */
 int  mm_engine_create(int device, void* stream, mm_engine** out);
 void mm_engine_destroy(mm_engine* e);
 int  mm_engine_synchronize(mm_engine* e);
@@ -291,6 +294,27 @@ int  mm_within_plan_level_local(mm_within_plan* p, int level, double* cost, int3
 int  mm_within_plan_level_commit(mm_within_plan* p, int level, const uint8_t* ok, const double* angle);
 int  mm_within_plan_walk(mm_within_plan* p, mm_alignlog** logs, int64_t* pose_evals,
                          int64_t* n_unresolved);
+/* The exchange on the DEVICE (all-reduce(MIN) of the per-shard best score, then all-reduce(MIN) of
+ * the index masked by score == global min).  level_launch enqueues the level on this rank's slice and leaves the
+ * per-pair results in HBM; the two export calls write job-indexed records into caller-owned DEVICE buffers with
+ * small kernels on the engine's stream (mm_engine_stream: issue the collectives stream-ordered after them, e.g.
+ * torch.cuda.ExternalStream); commit_dev copies the two REDUCED records to the host once and commits the level.
+ *   export_cost  cost_dev[n_jobs] f64: exact first-minimum cost of the slice, +inf if it holds no candidate
+ *                                                                          -> all_reduce(MIN) -> gcost_dev
+ *   export_keys  keys_dev[3 * n_jobs] i64, given gcost_dev:
+ *                  [j]            first-minimum index if this rank attains gcost[j], else INT64_MAX
+ *                  [n+j], [2n+j]  angle bits and ~angle bits of this rank's winner if its minimum lies within
+ *                                 the tie tolerance of gcost[j] and all its near-ties are one angle value;
+ *                                 INT64_MIN twice if they are not; INT64_MAX twice if it is not near
+ *                                                                          -> ONE all_reduce(MIN) of all 3n
+ *   commit_dev   winner = candidate keys[j] (the first index of minimal cost over the whole axis,
+ *                process_utils.rs:72); decided iff keys[n+j] == ~keys[2n+j] (every near rank uniform, all of one
+ *                angle value) -- the rule of mm_merge_shards; otherwise the step is re-searched on the chain
+ *                state in walk.  Identical on every rank. */
+int  mm_within_plan_level_launch(mm_within_plan* p, int level);
+int  mm_within_plan_level_export_cost(mm_within_plan* p, int level, double* cost_dev);
+int  mm_within_plan_level_export_keys(mm_within_plan* p, int level, const double* gcost_dev, int64_t* keys_dev);
+int  mm_within_plan_level_commit_dev(mm_within_plan* p, int level, const double* gcost_dev, const int64_t* keys_dev);
 /* arrays cost/uniform/angle/idx are [world][n] rank-major; tol [n] (nullable); outputs [n] */
 int  mm_merge_shards(int world, int n, const double* cost, const int32_t* uniform,
                      const double* angle, const int32_t* idx, const double* tol,

@@ -33,7 +33,8 @@ EXPORTS = [
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
     "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy",
     "mm_within_plan_set_shard", "mm_within_plan_dims", "mm_within_plan_level_local", "mm_within_plan_level_commit",
-    "mm_within_plan_walk", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
+    "mm_within_plan_walk", "mm_within_plan_level_launch", "mm_within_plan_level_export_cost",
+    "mm_within_plan_level_export_keys", "mm_within_plan_level_commit_dev", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
     "mm_frame_translate", "mm_frame_rotate", "mm_parse_contour_table",
 ]
 # include/mm_centerline.h
@@ -199,6 +200,14 @@ def lib():
     L.mm_within_plan_level_local.argtypes = [P, I, P, P, P, P, P]
     L.mm_within_plan_level_commit.restype = I
     L.mm_within_plan_level_commit.argtypes = [P, I, P, P]
+    L.mm_within_plan_level_launch.restype = I
+    L.mm_within_plan_level_launch.argtypes = [P, I]
+    L.mm_within_plan_level_export_cost.restype = I
+    L.mm_within_plan_level_export_cost.argtypes = [P, I, P]
+    L.mm_within_plan_level_export_keys.restype = I
+    L.mm_within_plan_level_export_keys.argtypes = [P, I, P, P]
+    L.mm_within_plan_level_commit_dev.restype = I
+    L.mm_within_plan_level_commit_dev.argtypes = [P, I, P, P]
     L.mm_within_plan_walk.restype = I
     L.mm_within_plan_walk.argtypes = [P, P, C.POINTER(I64), C.POINTER(I64)]
     L.mm_merge_shards.restype = I

@@ -19,6 +19,8 @@ struct PairDesc {
     int32_t flags;            // MM_SEARCH_SKIP_ZERO
     int32_t ang_full;         // length of the pair's full candidate list (>= n_ang)
     int32_t ang_begin;        // first candidate of the slice this plan owns
+    int32_t n_slice;          // candidates in the slice (== n_ang, except for empty-set pairs: n_ang = 0 there)
+    int32_t pad0;
     double  cx, cy;           // rotation centre (exact kernel)
     double  delta;            // f32 screening error bound (same unit as the costs)
     double  tol2;             // candidates within tol2 of the exact minimum are reported as near-ties
@@ -43,6 +45,7 @@ struct BatchDev {
     // candidate tables
     const float *cos32, *sin32;
     const double *cos64, *sin64;
+    const double *ang64;      // the candidate angles themselves (same indexing): device-side exchange records
     // per-candidate outputs
     float*    sq32;       // squared Hausdorff from the screening kernel
     double*   sq64;       // exact squared Hausdorff (valid where flag != 0 or in exact mode)
@@ -124,6 +127,19 @@ hipError_t launch_exact_all(const BatchDev& b, int max_na, int max_nbp, hipStrea
 hipError_t launch_shortlist(const BatchDev& b, hipStream_t s);
 hipError_t launch_rescore(const BatchDev& b, int max_na, int max_nbp, int total_candidates, hipStream_t s);
 hipError_t launch_finalize(const BatchDev& b, int use_flags, hipStream_t s);
+// Device-side exchange records of a sharded search (candidate axis split over ranks), indexed by JOB
+// (pair_of_job[j] = this level's pair of job j, or -1 when the job takes no part in the level):
+//   export_cost  cost[j] = exact first-minimum cost inside this rank's slice, +inf if it holds no candidate
+//                -> all-reduce(MIN) over the ranks gives the global best cost
+//   export_keys  given the reduced costs g: keys[j] = first-minimum index if this rank attains g[j], else
+//                INT64_MAX; keys[n+j], keys[2n+j] = (angle bits, ~angle bits) of the rank's winner if its
+//                minimum lies within the pair's tie tolerance of g[j] and all its near-ties are one angle
+//                value, (INT64_MIN, INT64_MIN) if they are not, (INT64_MAX, INT64_MAX) if it is not near
+//                -> ONE all-reduce(MIN) of the 3n keys gives the first index of minimal cost over the whole
+//                axis (process_utils.rs:72) and min / ~max of the near ranks' angle bits (equal <=> decided)
+hipError_t launch_export_cost(const BatchDev& b, const int32_t* pair_of_job, int n_jobs, double* cost, hipStream_t s);
+hipError_t launch_export_keys(const BatchDev& b, const int32_t* pair_of_job, int n_jobs, const double* gcost,
+                              long long* keys, hipStream_t s);
 size_t     lds_bytes_f32(int nbp);
 size_t     lds_bytes_f64(int nbp);
 int        max_target_points_f32();

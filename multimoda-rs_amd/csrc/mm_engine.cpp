@@ -55,6 +55,7 @@ int Engine::ensure(Buf& b, size_t bytes, bool host)
     if (bytes <= b.cap) return MM_OK;
     if (b.p) {
         MM_HIP(hipStreamSynchronize(stream));  // a copy may still read the old buffer
+        if (aux && aux != stream) MM_HIP(hipStreamSynchronize(aux));
         if (host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
     }
     b.p = nullptr; b.cap = 0;
@@ -66,7 +67,14 @@ int Engine::ensure(Buf& b, size_t bytes, bool host)
     return MM_OK;
 }
 
-int Engine::profile_begin()
+int Engine::sync_all()
+{
+    MM_HIP(hipStreamSynchronize(stream));
+    if (aux && aux != stream) MM_HIP(hipStreamSynchronize(aux));
+    return MM_OK;
+}
+
+int Engine::profile_begin(hipStream_t stream)
 {
     if (!profile) return MM_OK;
     while (events.size() < 2 * (launches + 1)) {
@@ -78,7 +86,7 @@ int Engine::profile_begin()
     return MM_OK;
 }
 
-int Engine::profile_end(double pair_evals, int64_t candidates)
+int Engine::profile_end(hipStream_t stream, double pair_evals, int64_t candidates)
 {
     if (!profile) return MM_OK;
     MM_HIP(hipEventRecord(events[2 * launches + 1], stream));
@@ -92,10 +100,12 @@ int Engine::profile_end(double pair_evals, int64_t candidates)
 // -------------------------------------------------------------------------------------
 // plan: point pool
 // -------------------------------------------------------------------------------------
-int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_)
+int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_, hipStream_t st)
 {
     eng = e;
     transient = transient_;
+    stream = transient ? e->aux : e->stream;
+    if (!st) st = stream;
     const size_t S = sets.size();
     set_off.assign(S, 0); set_len.assign(S, 0);
     set_rho.assign(S, 0.0);
@@ -134,8 +144,8 @@ int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_
         MM_HIP(hipMalloc((void**)&pts_blob, std::max<size_t>(pts_bytes, 256)));
         own_pts = true;
     }
-    if (pts_bytes) MM_HIP(hipMemcpyAsync(pts_blob, h, pts_bytes, hipMemcpyHostToDevice, e->stream));
-    if (!transient) MM_HIP(hipStreamSynchronize(e->stream));
+    if (pts_bytes) MM_HIP(hipMemcpyAsync(pts_blob, h, pts_bytes, hipMemcpyHostToDevice, st));
+    if (!transient) MM_HIP(hipStreamSynchronize(st));
     dev.p32x = (const float*)(pts_blob + o32x); dev.p32y = (const float*)(pts_blob + o32y);
     dev.p64x = (const double*)(pts_blob + o64x); dev.p64y = (const double*)(pts_blob + o64y);
     return MM_OK;
@@ -154,9 +164,10 @@ static inline double screen_delta(double rho_r, double rho_t)
 }
 
 int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_t angle_begin, int32_t angle_end,
-                      bool want_costs_)
+                      bool want_costs_, hipStream_t st)
 {
     Engine* e = eng;
+    if (!st) st = stream;
     precision = precision_;
     want_costs = want_costs_;
     slice_end = angle_end;
@@ -192,6 +203,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         d.tgt_off = set_off[sp.tgt_set]; d.n_tgt = nt;
         d.out_off = (int32_t)A; d.n_ang = na;
         d.ang_full = sp.n_angles; d.ang_begin = b;
+        d.n_slice = na; d.pad0 = 0;
         d.flags = sp.flags;
         d.cx = sp.cx; d.cy = sp.cy;
         d.tol2 = sp.tie_tol;
@@ -291,7 +303,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     const size_t o_work = take((size_t)W * sizeof(WorkItem));
     const size_t o_work_lb = take((size_t)W_lb * sizeof(WorkItem));
     const size_t o_c32 = take((size_t)T * 4), o_s32 = take((size_t)T * 4);
-    const size_t o_c64 = take((size_t)T * 8), o_s64 = take((size_t)T * 8);
+    const size_t o_c64 = take((size_t)T * 8), o_s64 = take((size_t)T * 8), o_a64 = take((size_t)T * 8);
     lvl_in_bytes = o;
     const size_t o_sq32 = take((size_t)A * 4), o_sq64 = take((size_t)A * 8), o_flag = take((size_t)A);
     const size_t o_items = take((size_t)A * sizeof(WorkItem)), o_nitems = take(32);
@@ -314,6 +326,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     unsigned char* h = (unsigned char*)e->host_lvl.p;
     float *c32 = (float*)(h + o_c32), *s32 = (float*)(h + o_s32);
     double *c64 = (double*)(h + o_c64), *s64 = (double*)(h + o_s64);
+    if (T) std::memcpy(h + o_a64, host_tables.data(), (size_t)T * 8);
     for (int64_t t = 0; t < T; ++t) {
         double co, si;
         ::sincos(host_tables[(size_t)t], &si, &co);   // one glibc sincos, like the reference's per-point cos()/sin() pair
@@ -328,18 +341,19 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         if (rc) return rc;
         lvl_blob = (unsigned char*)e->dev_lvl.p; own_lvl = false;
     } else if (lvl_bytes > lvl_cap) {
-        if (lvl_blob) { MM_HIP(hipStreamSynchronize(e->stream)); (void)hipFree(lvl_blob); lvl_blob = nullptr; }
+        if (lvl_blob) { MM_HIP(hipStreamSynchronize(stream)); MM_HIP(hipStreamSynchronize(st)); (void)hipFree(lvl_blob); lvl_blob = nullptr; }
         MM_HIP(hipMalloc((void**)&lvl_blob, lvl_bytes));
         lvl_cap = lvl_bytes; own_lvl = true;
     }
-    MM_HIP(hipMemcpyAsync(lvl_blob, h, lvl_in_bytes, hipMemcpyHostToDevice, e->stream));
-    if (!transient) MM_HIP(hipStreamSynchronize(e->stream));  // host staging buffer is reused
+    MM_HIP(hipMemcpyAsync(lvl_blob, h, lvl_in_bytes, hipMemcpyHostToDevice, st));
+    if (!transient) MM_HIP(hipStreamSynchronize(st));  // host staging buffer is reused
 
     unsigned char* B = lvl_blob;
     dev.pairs = (const PairDesc*)(B + o_pairs); dev.work = (const WorkItem*)(B + o_work);
     dev.n_pairs = P; dev.n_work = W;
     dev.cos32 = (const float*)(B + o_c32); dev.sin32 = (const float*)(B + o_s32);
     dev.cos64 = (const double*)(B + o_c64); dev.sin64 = (const double*)(B + o_s64);
+    dev.ang64 = (const double*)(B + o_a64);
     dev.sq32 = (float*)(B + o_sq32); dev.sq64 = (double*)(B + o_sq64); dev.flag = (uint8_t*)(B + o_flag);
     dev.items = (WorkItem*)(B + o_items); dev.n_items = (int32_t*)(B + o_nitems);
     dev.work_lb = (const WorkItem*)(B + o_work_lb); dev.n_work_lb = W_lb; dev.lb_stride = lb_stride;
@@ -354,7 +368,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
 
 int Plan::run(bool screen_only)
 {
-    hipStream_t s = eng->stream;
+    hipStream_t s = stream;
     if (W == 0) {
         if (!screen_only && P > 0) { hipError_t e = launch_finalize(dev, 0, s); if (e != hipSuccess) return hip_error(e, "finalize"); }
         return MM_OK;
@@ -368,10 +382,10 @@ int Plan::run(bool screen_only)
             MM_HIP(hipMemsetAsync(dev.n_items, 0, 32, s));
             dev.stats = eng->profile ? eng->dev_stats : nullptr;
             const int nap = (max_na + 31) & ~31, nbp = (max_nt + 31) & ~31, cap = lb_runs_cap;
-            if ((prc = eng->profile_begin())) return prc;
+            if ((prc = eng->profile_begin(s))) return prc;
             if ((e = launch_screen_lb(dev, nap, nbp, s)) != hipSuccess) return hip_error(e, "bound kernel launch");
-            if ((prc = eng->profile_end(lb_pair_evals, A))) return prc;
-            if ((prc = eng->profile_begin())) return prc;
+            if ((prc = eng->profile_end(s, lb_pair_evals, A))) return prc;
+            if ((prc = eng->profile_begin(s))) return prc;
             if ((e = launch_lb_pick(dev, 0, s)) != hipSuccess) return hip_error(e, "pick kernel launch");
             if ((e = launch_screen_picks(dev, 0, max_na, max_nbp, s)) != hipSuccess) return hip_error(e, "screen kernel launch (picks)");
             if ((e = launch_lb_spread(dev, s)) != hipSuccess) return hip_error(e, "spread kernel launch");
@@ -385,13 +399,13 @@ int Plan::run(bool screen_only)
             if ((e = launch_lb_keep(dev, 1, cap, s)) != hipSuccess) return hip_error(e, "keep kernel launch (final)");
             if ((e = launch_screen_kept(dev, max_na, max_nbp, cap, s)) != hipSuccess)
                 return hip_error(e, "screen kernel launch (survivors)");
-            if ((prc = eng->profile_end(0.0, 0))) return prc;
+            if ((prc = eng->profile_end(s, 0.0, 0))) return prc;
             if (eng->profile) { eng->bound_offered += A; eng->bound_round1 += lb_sparse_total; }
         } else {
-            if ((prc = eng->profile_begin())) return prc;
+            if ((prc = eng->profile_begin(s))) return prc;
             e = use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s);
             if (e != hipSuccess) return hip_error(e, "screen kernel launch");
-            if ((prc = eng->profile_end(pair_evals, A))) return prc;
+            if ((prc = eng->profile_end(s, pair_evals, A))) return prc;
         }
         if (screen_only) return MM_OK;
         MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
@@ -402,10 +416,10 @@ int Plan::run(bool screen_only)
         e = launch_finalize(dev, 1, s);
         if (e != hipSuccess) return hip_error(e, "finalize kernel launch");
     } else {
-        if ((prc = eng->profile_begin())) return prc;
+        if ((prc = eng->profile_begin(s))) return prc;
         e = launch_exact_all(dev, max_na, max_nbp, s);
         if (e != hipSuccess) return hip_error(e, "exact kernel launch");
-        if ((prc = eng->profile_end(pair_evals, A))) return prc;
+        if ((prc = eng->profile_end(s, pair_evals, A))) return prc;
         if (screen_only) return MM_OK;
         e = launch_finalize(dev, 0, s);
         if (e != hipSuccess) return hip_error(e, "finalize kernel launch");
@@ -417,10 +431,10 @@ int Plan::fetch(BatchResult& out, double* all_costs_plan_order)
 {
     const size_t cost_bytes = (all_costs_plan_order && dev.all_costs) ? (size_t)A * 8 : 0;
     unsigned char* h = (unsigned char*)eng->host_lvl.p;  // sized in stage_level
-    if (P > 0) MM_HIP(hipMemcpyAsync(h, lvl_blob + off_best_cost, res_bytes, hipMemcpyDeviceToHost, eng->stream));
+    if (P > 0) MM_HIP(hipMemcpyAsync(h, lvl_blob + off_best_cost, res_bytes, hipMemcpyDeviceToHost, stream));
     if (cost_bytes)
-        MM_HIP(hipMemcpyAsync(all_costs_plan_order, dev.all_costs, cost_bytes, hipMemcpyDeviceToHost, eng->stream));
-    MM_HIP(hipStreamSynchronize(eng->stream));
+        MM_HIP(hipMemcpyAsync(all_costs_plan_order, dev.all_costs, cost_bytes, hipMemcpyDeviceToHost, stream));
+    MM_HIP(hipStreamSynchronize(stream));
     const double* hc = (const double*)h;
     const int32_t* hi = (const int32_t*)(h + r_best_idx);
     const int32_t* hn = (const int32_t*)(h + r_n_rescored);
@@ -743,11 +757,17 @@ int mm_engine_create(int device, void* stream, mm_engine** out)
     MM_HIP(hipSetDevice(device));
     Engine* en = new Engine();
     en->device = device;
-    if (stream) { en->stream = (hipStream_t)stream; en->own_stream = false; }
+    if (stream) { en->stream = (hipStream_t)stream; en->own_stream = false; en->aux = en->stream; }
     else {
-        hipError_t e2 = hipStreamCreateWithFlags(&en->stream, hipStreamNonBlocking);
-        if (e2 != hipSuccess) { delete en; return hip_error(e2, "hipStreamCreate"); }
+        // main stream at the lowest priority, side stream at the highest (numerically: least >= greatest)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        hipError_t e2 = hipStreamCreateWithPriority(&en->stream, hipStreamNonBlocking, least);
+        if (e2 != hipSuccess) { delete en; return hip_error(e2, "hipStreamCreateWithPriority"); }
         en->own_stream = true;
+        e2 = hipStreamCreateWithPriority(&en->aux, hipStreamNonBlocking, greatest);
+        if (e2 != hipSuccess) { (void)hipStreamDestroy(en->stream); delete en; return hip_error(e2, "hipStreamCreateWithPriority"); }
+        en->own_aux = true;
     }
     *out = reinterpret_cast<mm_engine*>(en);
     return MM_OK;
@@ -758,11 +778,12 @@ void mm_engine_destroy(mm_engine* h)
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
+    (void)e->sync_all();
     for (Engine::Buf* b : {&e->host_pts, &e->host_lvl}) if (b->p) (void)hipHostFree(b->p);
     for (Engine::Buf* b : {&e->dev_pts, &e->dev_lvl}) if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->dev_stats) (void)hipFree(e->dev_stats);
+    if (e->own_aux) (void)hipStreamDestroy(e->aux);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -772,7 +793,7 @@ int mm_engine_synchronize(mm_engine* h)
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     MM_HIP(hipSetDevice(e->device));
-    MM_HIP(hipStreamSynchronize(e->stream));
+    if (int src = e->sync_all()) return src;
     return MM_OK;
 }
 
@@ -781,7 +802,7 @@ int mm_engine_profile(mm_engine* h, int enable)
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     MM_HIP(hipSetDevice(e->device));
-    MM_HIP(hipStreamSynchronize(e->stream));
+    if (int src = e->sync_all()) return src;
     e->profile = enable != 0;
     e->launches = 0; e->prof_pair_evals = 0.0; e->prof_candidates = 0; e->launch_pair_evals.clear();
     e->bound_offered = 0; e->bound_round1 = 0;
@@ -804,7 +825,7 @@ int mm_engine_profile_read(mm_engine* h, int64_t* n_launches, double* ms_total, 
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     MM_HIP(hipSetDevice(e->device));
-    MM_HIP(hipStreamSynchronize(e->stream));
+    if (int src = e->sync_all()) return src;
     double ms = 0.0;
     for (size_t k = 0; k < e->launches; ++k) {
         float t = 0.f;
@@ -824,7 +845,7 @@ int mm_engine_profile_launches(mm_engine* h, int64_t cap, float* ms, double* pai
     Engine* e = reinterpret_cast<Engine*>(h);
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     MM_HIP(hipSetDevice(e->device));
-    MM_HIP(hipStreamSynchronize(e->stream));
+    if (int src = e->sync_all()) return src;
     for (size_t k = 0; k < e->launches && (int64_t)k < cap; ++k) {
         float t = 0.f;
         MM_HIP(hipEventElapsedTime(&t, e->events[2 * k], e->events[2 * k + 1]));
@@ -849,7 +870,7 @@ int mm_engine_bound_stats(mm_engine* h, int64_t out[5])
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine or out == NULL");
     MM_HIP(hipSetDevice(e->device));
     unsigned long long d[8] = {0};
-    MM_HIP(hipStreamSynchronize(e->stream));
+    if (int src = e->sync_all()) return src;
     if (e->dev_stats) MM_HIP(hipMemcpy(d, e->dev_stats, 64, hipMemcpyDeviceToHost));
     out[0] = e->bound_offered; out[1] = e->bound_round1; out[2] = (int64_t)d[1]; out[3] = (int64_t)d[3];
     out[4] = (int64_t)d[2];
@@ -1028,7 +1049,7 @@ void mm_plan_destroy(mm_plan* h)
     PlanHandle* p = reinterpret_cast<PlanHandle*>(h);
     if (!p) return;
     (void)hipSetDevice(p->plan.eng->device);
-    (void)hipStreamSynchronize(p->plan.eng->stream);
+    (void)p->plan.eng->sync_all();
     delete p;
 }
 
@@ -1089,10 +1110,10 @@ int mm_plan_time(mm_plan* h, int iters, int screen_only, float* ms_avg)
     MM_HIP(hipEventCreate(&t1));
     int rc = plan.run(screen_only != 0);  // warm-up
     if (rc) return rc;
-    MM_HIP(hipEventRecord(t0, plan.eng->stream));
+    MM_HIP(hipEventRecord(t0, plan.stream));
     for (int i = 0; i < iters; ++i)
         if ((rc = plan.run(screen_only != 0))) return rc;
-    MM_HIP(hipEventRecord(t1, plan.eng->stream));
+    MM_HIP(hipEventRecord(t1, plan.stream));
     MM_HIP(hipEventSynchronize(t1));
     float ms = 0.f;
     MM_HIP(hipEventElapsedTime(&ms, t0, t1));

@@ -23,11 +23,18 @@ int hip_error(hipError_t e, const char* what);
 struct Engine {
     struct Buf { void* p = nullptr; size_t cap = 0; };
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // main stream: the searches of device-resident plans (the long launches)
     bool own_stream = false;
+    // high-priority side stream for everything short: staging of resident plans, transient batches (the
+    // between-pullback searches, the per-step searches of the faithful chain).  Two engines share one GPU in a
+    // pipelined driver; without the priority a 23 us between-stage kernel queues behind the other engine's
+    // 30 ms launch.  Equals `stream` when the caller supplied the stream.
+    hipStream_t aux = nullptr;
+    bool own_aux = false;
     Buf host_pts, host_lvl;   // pinned staging: point pool / level (+ results)
     Buf dev_pts, dev_lvl;     // device buffers of transient plans
     int ensure(Buf& b, size_t bytes, bool host);
+    int sync_all();                 // both streams
     // grow-only pageable scratch for host-side set construction (refinement grid): a fresh 50 MB
     // std::vector per call costs ~10 ms of zero-fill and page faults
     std::vector<double> scratch[3];
@@ -44,8 +51,8 @@ struct Engine {
     int64_t bound_min_candidates = 16384;   // smaller batches skip the bound rounds (mm_engine_set_bound_min_candidates)
     int64_t bound_offered = 0, bound_round1 = 0;
     unsigned long long* dev_stats = nullptr;
-    int profile_begin();
-    int profile_end(double pair_evals, int64_t candidates);
+    int profile_begin(hipStream_t s);
+    int profile_end(hipStream_t s, double pair_evals, int64_t candidates);
 };
 
 // ---- internal batch description (the C ABI wrappers translate into this) --------------
@@ -71,6 +78,7 @@ struct BatchResult {
 struct Plan {
     Engine* eng = nullptr;
     bool transient = false;
+    hipStream_t stream = nullptr;   // run / fetch: the engine's aux stream for transient plans, its main stream otherwise
     int precision = MM_PRECISION_F32;
     // sets
     std::vector<int32_t> set_off, set_len;
@@ -101,9 +109,10 @@ struct Plan {
     int64_t lb_sparse_total = 0;              // candidates the first bound round scores
     std::vector<WorkItem> host_work_lb;
 
-    int stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient);
+    // `st` (nullable -> this->stream): the stream the staging copies go to
+    int stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient, hipStream_t st = nullptr);
     int stage_level(const std::vector<PairSpec>& pairs, int precision, int32_t angle_begin, int32_t angle_end,
-                    bool want_costs);
+                    bool want_costs, hipStream_t st = nullptr);
     int run(bool screen_only);
     int fetch(BatchResult& out, double* all_costs_plan_order);
     size_t hbm_bytes() const { return pts_bytes + lvl_bytes; }

@@ -274,10 +274,20 @@ struct WithinPlan {
     std::vector<int64_t> evals;
     int rank = 0, world = 1;          // this plan's share of the candidate axis
     bool searched = false;
+    // device-side exchange (level_launch / export_* / commit_dev): job -> pair of the current level
+    std::vector<int32_t> pair_of_job;
+    int32_t* d_pair_of_job = nullptr;
+    std::vector<double> h_gcost;
+    std::vector<long long> h_keys;
 
+    ~WithinPlan() { if (d_pair_of_job) (void)hipFree(d_pair_of_job); }
     int prepare();
+    int level_launch(size_t l);
     int level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
     int level_commit(size_t l, const uint8_t* ok, const double* angle);
+    int level_export_cost(size_t l, double* cost_dev);
+    int level_export_keys(size_t l, const double* gcost_dev, long long* keys_dev);
+    int level_commit_dev(size_t l, const double* gcost_dev, const long long* keys_dev);
     void build_level_pairs(size_t l, const std::vector<double>& centres, const std::vector<uint8_t>& take,
                            std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out);
     int search();
@@ -347,14 +357,14 @@ int WithinPlan::prepare()
     int rc;
     {
         TraceTimer t("prepare: stage sets");
-        rc = plan.stage_sets(e, sets, /*transient=*/false);
+        rc = plan.stage_sets(e, sets, /*transient=*/false, e->aux);   // staging: the high-priority side stream
     }
     if (rc) return rc;
     // level 0 has no centre: its candidate list, descriptors and tables are known now
     if (level0_ok) {
         TraceTimer t("prepare: stage level 0");
         build_level_pairs(0, std::vector<double>(), std::vector<uint8_t>(job_geom.size(), 1), lvl_pairs, lvl_active, nullptr);
-        if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
+        if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false, e->aux))) return rc;
         level0_staged = true;
     }
     staged = true;
@@ -397,11 +407,11 @@ void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centres,
 // takes part in this level; cost/idx/angle = exact first minimum inside the slice (+inf/-1
 // if the slice is empty); uniform = every candidate of the slice within the tie tolerance
 // of that minimum is the same angle value.
-int WithinPlan::level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active)
+// Stage (if needed) and enqueue level l over this rank's candidate slice; results stay in HBM.
+int WithinPlan::level_launch(size_t l)
 {
     const int J = (int)job_geom.size();
     if (l == 0) { centre.assign(J, 0.0); resolved.assign(J, 1); evals.assign(J, 0); searched = true; }
-    for (int j = 0; j < J; ++j) { cost[j] = INFINITY; uniform[j] = 1; angle[j] = 0.0; idx[j] = -1; active[j] = 0; }
     int rc;
     if (!(l == 0 && level0_staged)) {
         TraceTimer t("within: stage level");
@@ -410,10 +420,19 @@ int WithinPlan::level_local(size_t l, double* cost, int32_t* uniform, double* an
         if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
     }
     if (lvl_active.empty()) return MM_OK;
+    return plan.run(false);
+}
+
+int WithinPlan::level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active)
+{
+    const int J = (int)job_geom.size();
+    for (int j = 0; j < J; ++j) { cost[j] = INFINITY; uniform[j] = 1; angle[j] = 0.0; idx[j] = -1; active[j] = 0; }
+    int rc;
     BatchResult res;
     {
         TraceTimer t("within: search kernels");
-        if ((rc = plan.run(false))) return rc;
+        if ((rc = level_launch(l))) return rc;
+        if (lvl_active.empty()) return MM_OK;
         if ((rc = plan.fetch(res, nullptr))) return rc;
     }
     for (size_t k = 0; k < lvl_active.size(); ++k) {
@@ -432,6 +451,63 @@ int WithinPlan::level_local(size_t l, double* cost, int32_t* uniform, double* an
         uniform[j] = ok ? 1 : 0;
     }
     return MM_OK;
+}
+
+// ---- device-side exchange -------------------------------------------------------------
+// After level_launch the per-pair results of this rank's slice are in HBM.  export_cost / export_keys
+// write job-indexed exchange records into caller-owned DEVICE buffers (kernels on the plan's stream), the
+// caller all-reduces them over the ranks (RCCL), and commit_dev copies the two reduced records to the
+// host once and commits the level.  No host round trip between the search and the collectives.
+int WithinPlan::level_export_cost(size_t l, double* cost_dev)
+{
+    (void)l;
+    if (!searched) return set_error(MM_ERR_INVALID, "level_export_cost before level_launch");
+    const int J = (int)job_geom.size();
+    if (J == 0) return MM_OK;
+    pair_of_job.assign((size_t)J, -1);
+    for (size_t k = 0; k < lvl_active.size(); ++k) pair_of_job[(size_t)lvl_active[k]] = (int32_t)k;
+    if (!d_pair_of_job) {
+        const hipError_t he = hipMalloc((void**)&d_pair_of_job, (size_t)J * 4);
+        if (he != hipSuccess) return hip_error(he, "hipMalloc(pair_of_job)");
+    }
+    hipError_t he = hipMemcpyAsync(d_pair_of_job, pair_of_job.data(), (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
+    if (he != hipSuccess) return hip_error(he, "hipMemcpyAsync(pair_of_job)");
+    he = launch_export_cost(plan.dev, d_pair_of_job, J, cost_dev, plan.stream);
+    return he == hipSuccess ? MM_OK : hip_error(he, "export_cost kernel launch");
+}
+
+int WithinPlan::level_export_keys(size_t l, const double* gcost_dev, long long* keys_dev)
+{
+    (void)l;
+    if (!searched || !d_pair_of_job) return set_error(MM_ERR_INVALID, "level_export_keys before level_export_cost");
+    const hipError_t he = launch_export_keys(plan.dev, d_pair_of_job, (int)job_geom.size(), gcost_dev, keys_dev, plan.stream);
+    return he == hipSuccess ? MM_OK : hip_error(he, "export_keys kernel launch");
+}
+
+int WithinPlan::level_commit_dev(size_t l, const double* gcost_dev, const long long* keys_dev)
+{
+    const int J = (int)job_geom.size();
+    if (J == 0) return MM_OK;
+    h_gcost.resize((size_t)J); h_keys.resize((size_t)J * 3);
+    hipError_t he = hipMemcpyAsync(h_gcost.data(), gcost_dev, (size_t)J * 8, hipMemcpyDeviceToHost, plan.stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(h_keys.data(), keys_dev, (size_t)J * 24, hipMemcpyDeviceToHost, plan.stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(plan.stream);
+    if (he != hipSuccess) return hip_error(he, "exchange records D2H");
+    std::vector<uint8_t> ok((size_t)J, 1);
+    std::vector<double> angle((size_t)J, 0.0);
+    for (size_t k = 0; k < lvl_active.size(); ++k) {
+        const int j = lvl_active[k];
+        if (!(h_gcost[(size_t)j] < INFINITY)) continue;            // no rank held a candidate (mm_merge_shards: ok = 1)
+        const long long gi = h_keys[(size_t)j], lo = h_keys[(size_t)J + j], hi = ~h_keys[2 * (size_t)J + j];
+        if (gi < 0 || gi >= (long long)lvl_pairs[k].n_angles)
+            return set_error(MM_ERR_INVALID, "exchange: reduced winner index out of range (ranks disagree on the candidate lists)");
+        angle[(size_t)j] = lvl_pairs[k].angles[gi];                // every rank holds the full list on the host
+        ok[(size_t)j] = (lo == hi) ? 1 : 0;                        // all near ranks uniform and of one angle value
+        long long abits; std::memcpy(&abits, &angle[(size_t)j], 8);
+        if (ok[(size_t)j] && abits != lo)
+            return set_error(MM_ERR_INVALID, "exchange: reduced angle differs from the winner's list entry");
+    }
+    return level_commit(l, ok.data(), angle.data());
 }
 
 // Record the merged (all ranks) outcome of level l: ok[j] != 0 -> the level's winner is
@@ -885,7 +961,7 @@ int mm_within_plan_set_shard(mm_within_plan* h, int rank, int world)
         if (wp->level0_ok) {  // re-stage level 0 for the new slice now, not inside the search
             wp->build_level_pairs(0, std::vector<double>(), std::vector<uint8_t>(wp->job_geom.size(), 1), wp->lvl_pairs,
                                   wp->lvl_active, nullptr);
-            int rc = wp->plan.stage_level(wp->lvl_pairs, wp->precision, 0, INT32_MAX, false);
+            int rc = wp->plan.stage_level(wp->lvl_pairs, wp->precision, 0, INT32_MAX, false, wp->e->aux);
             if (rc) return rc;
             wp->level0_staged = true;
         }
@@ -911,6 +987,40 @@ int mm_within_plan_level_local(mm_within_plan* h, int level, double* cost, int32
     if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
     if (int drc = select_device(wp->e)) return drc;
     return wp->level_local((size_t)level, cost, uniform, angle, idx, active);
+}
+
+int mm_within_plan_level_launch(mm_within_plan* h, int level)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
+    if (int drc = select_device(wp->e)) return drc;
+    return wp->level_launch((size_t)level);
+}
+
+int mm_within_plan_level_export_cost(mm_within_plan* h, int level, double* cost_dev)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || level < 0 || (size_t)level >= wp->levels.size() || !cost_dev) return set_error(MM_ERR_INVALID, "bad level / buffer");
+    if (int drc = select_device(wp->e)) return drc;
+    return wp->level_export_cost((size_t)level, cost_dev);
+}
+
+int mm_within_plan_level_export_keys(mm_within_plan* h, int level, const double* gcost_dev, int64_t* keys_dev)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || level < 0 || (size_t)level >= wp->levels.size() || !gcost_dev || !keys_dev)
+        return set_error(MM_ERR_INVALID, "bad level / buffer");
+    if (int drc = select_device(wp->e)) return drc;
+    return wp->level_export_keys((size_t)level, gcost_dev, (long long*)keys_dev);
+}
+
+int mm_within_plan_level_commit_dev(mm_within_plan* h, int level, const double* gcost_dev, const int64_t* keys_dev)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || level < 0 || (size_t)level >= wp->levels.size() || !gcost_dev || !keys_dev)
+        return set_error(MM_ERR_INVALID, "bad level / buffer");
+    if (int drc = select_device(wp->e)) return drc;
+    return wp->level_commit_dev((size_t)level, gcost_dev, (const long long*)keys_dev);
 }
 
 int mm_within_plan_level_commit(mm_within_plan* h, int level, const uint8_t* ok, const double* angle)
@@ -963,7 +1073,7 @@ void mm_within_plan_destroy(mm_within_plan* h)
 {
     WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
     if (!wp) return;
-    (void)hipStreamSynchronize(wp->e->stream);
+    (void)wp->e->sync_all();
     delete wp;
 }
 

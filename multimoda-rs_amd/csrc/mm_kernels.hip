@@ -1347,6 +1347,94 @@ hipError_t launch_shortlist(const BatchDev& b, hipStream_t s)
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------------
+// Exchange records of a sharded search (see mm_device.h).  One thread per job.
+// -------------------------------------------------------------------------------------
+struct LocalBest { double cost; int idx; bool uniform; long long abits; };
+
+static __device__ __forceinline__ LocalBest local_best(const PairDesc& pd, int k, const double* __restrict__ best_cost,
+                                                       const int* __restrict__ best_idx, const int* __restrict__ near_cnt,
+                                                       const int* __restrict__ near_idx, const double* __restrict__ ang64)
+{
+    LocalBest r;
+    r.cost = __longlong_as_double(0x7ff0000000000000ll); r.idx = -1; r.uniform = true; r.abits = 0;
+    if (pd.n_ref == 0 || pd.n_tgt == 0) {
+        // process_utils.rs:86-88: every cost is 0.0, the first candidate of the slice is its first minimum
+        if (pd.n_slice > 0) { r.cost = 0.0; r.idx = pd.ang_begin; r.abits = __double_as_longlong(ang64[pd.tab_off]); }
+        return r;
+    }
+    const int bi = best_idx[k];
+    if (bi < 0) return r;
+    r.cost = best_cost[k]; r.idx = bi;
+    r.abits = __double_as_longlong(ang64[pd.tab_off + (bi - pd.ang_begin)]);
+    const int n = near_cnt[k];
+    bool ok = n == 1;
+    if (!ok && n >= 2 && n <= kMaxNear) {
+        ok = true;
+        const long long a0 = __double_as_longlong(ang64[pd.tab_off + (near_idx[k * kMaxNear] - pd.ang_begin)]);
+        for (int q = 1; q < n; ++q)
+            ok = ok && (__double_as_longlong(ang64[pd.tab_off + (near_idx[k * kMaxNear + q] - pd.ang_begin)]) == a0);
+    }
+    r.uniform = ok;
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+k_export_cost(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pair_of_job, int n_jobs,
+              const double* __restrict__ best_cost, const int* __restrict__ best_idx, const int* __restrict__ near_cnt,
+              const int* __restrict__ near_idx, const double* __restrict__ ang64, double* __restrict__ cost)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const int k = pair_of_job[j];
+    double c = __longlong_as_double(0x7ff0000000000000ll);
+    if (k >= 0) c = local_best(pairs[k], k, best_cost, best_idx, near_cnt, near_idx, ang64).cost;
+    cost[j] = c;
+}
+
+__global__ void __launch_bounds__(256)
+k_export_keys(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pair_of_job, int n_jobs,
+              const double* __restrict__ best_cost, const int* __restrict__ best_idx, const int* __restrict__ near_cnt,
+              const int* __restrict__ near_idx, const double* __restrict__ ang64, const double* __restrict__ gcost,
+              long long* __restrict__ keys)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const long long kMax = 0x7fffffffffffffffll, kMin = (long long)0x8000000000000000ull;
+    long long k_idx = kMax, k_lo = kMax, k_hi = kMax;
+    const int k = pair_of_job[j];
+    if (k >= 0) {
+        const PairDesc pd = pairs[k];
+        const LocalBest lb = local_best(pd, k, best_cost, best_idx, near_cnt, near_idx, ang64);
+        const double g = gcost[j];
+        if (lb.idx >= 0) {
+            if (lb.cost == g) k_idx = (long long)lb.idx;
+            if (lb.cost <= g + pd.tol2) {                       // same expression as mm_merge_shards
+                k_lo = lb.uniform ? lb.abits : kMin;
+                k_hi = lb.uniform ? ~lb.abits : kMin;
+            }
+        }
+    }
+    keys[j] = k_idx; keys[n_jobs + j] = k_lo; keys[2 * (size_t)n_jobs + j] = k_hi;
+}
+
+hipError_t launch_export_cost(const BatchDev& b, const int32_t* pair_of_job, int n_jobs, double* cost, hipStream_t s)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_export_cost, dim3((n_jobs + 255) / 256), dim3(256), 0, s, b.pairs, pair_of_job, n_jobs, b.best_cost,
+                       b.best_idx, b.near_cnt, b.near_idx, b.ang64, cost);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_keys(const BatchDev& b, const int32_t* pair_of_job, int n_jobs, const double* gcost,
+                              long long* keys, hipStream_t s)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_export_keys, dim3((n_jobs + 255) / 256), dim3(256), 0, s, b.pairs, pair_of_job, n_jobs, b.best_cost,
+                       b.best_idx, b.near_cnt, b.near_idx, b.ang64, gcost, keys);
+    return hipGetLastError();
+}
+
 hipError_t launch_finalize(const BatchDev& b, int use_flags, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;

@@ -2,16 +2,27 @@
 the exchange (backend "nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 Every rank scores its slice [n*rank/world, n*(rank+1)/world) of every pair's candidate list
-and reports, per pair, the exact first minimum inside the slice.  The per-shard best scores
-are min-all-reduced (the global best score per pair) and the small per-pair records
-(cost, index, angle, near-tie flag) are all-gathered; ``mm_merge_shards`` (host, C ABI) then
-picks the reference's winner -- the first index of minimal cost over the whole axis,
-process_utils.rs:72 -- identically on every rank.  Message size: 28 B x pairs x ranks
-(2044 pairs x 8 ranks = 0.46 MB): latency-bound, not xGMI-bandwidth-bound.
+and holds, per pair, the exact first minimum inside the slice.  The reference's winner is the
+first index of minimal cost over the whole axis (process_utils.rs:72).
+
+Two exchanges, same result (identical on every rank):
+
+``device`` (default)
+    per level two RCCL all-reduces on DEVICE buffers, stream-ordered behind the search kernels on
+    the engine's stream -- no host round trip between the search and the collectives:
+      1. all_reduce(MIN) of the per-shard best cost (f64 x pairs)
+      2. all_reduce(MIN) of 3 x pairs int64 keys: the best index masked by cost == global min, and the
+         (bits, ~bits) of the near-tie shards' angles (their min / max: equal <=> the step is decided)
+    then ONE D2H copy of the reduced records (32 B x pairs) and the commit.  Message sizes for
+    config3: 16 KB + 48 KB per rank -- latency-bound, not xGMI-bandwidth-bound.
+``gather`` (MM_EXCHANGE=gather; the checker)
+    the per-pair records (cost, index, angle, near-tie flag) go through the host, are all-gathered,
+    and ``mm_merge_shards`` (host, C ABI) picks the winner.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+import os
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 
@@ -21,6 +32,18 @@ from . import _native as N
 def shard_bounds(n: int, rank: int, world: int):
     """This rank's share of a candidate list of length n."""
     return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def exchange_mode() -> str:
+    m = os.environ.get("MM_EXCHANGE", "device")
+    if m not in ("device", "gather"):
+        raise ValueError("MM_EXCHANGE must be 'device' or 'gather'")
+    return m
+
+
+def world_size(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
 def merge_shards(world: int, cost: np.ndarray, uniform: np.ndarray, angle: np.ndarray, idx: np.ndarray,
@@ -43,27 +66,104 @@ def merge_shards(world: int, cost: np.ndarray, uniform: np.ndarray, angle: np.nd
 
 
 def merge_level(local: Dict[str, np.ndarray], tol: Optional[np.ndarray], group=None):
-    """Exchange one level's per-shard results between the ranks of `group` and merge them.
+    """The ``gather`` exchange of one level: per-shard records through the host, all-gathered and merged.
     Without an initialised process group (or world == 1) this is the single-rank merge."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    world = world_size(group)
     if world == 1:
         return merge_shards(1, local["cost"], local["uniform"], local["angle"], local["idx"], tol)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    n = local["cost"].shape[0]
     # one packed f64 record per pair: [cost, angle, idx, uniform] (idx/uniform are small ints: exact in f64)
     rec = torch.from_numpy(np.stack([local["cost"], local["angle"], local["idx"].astype(np.float64),
                                      local["uniform"].astype(np.float64)], axis=0)).to(dev)
     gathered = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(gathered, rec, group=group)
-    # the per-shard best score, min-reduced over the ranks (RCCL all-reduce on the GPU path)
-    gbest = rec[0].clone()
-    dist.all_reduce(gbest, op=dist.ReduceOp.MIN, group=group)
     g = torch.stack(gathered, dim=0).cpu().numpy()     # [world, 4, n]
-    ok, angle, idx, cost = merge_shards(world, g[:, 0, :], g[:, 3, :].astype(np.int32), g[:, 1, :],
-                                        g[:, 2, :].astype(np.int32), tol)
-    if not np.array_equal(cost, gbest.cpu().numpy()):
-        raise RuntimeError("all-reduced best score disagrees with the gathered shards")
-    return ok, angle, idx, cost
+    return merge_shards(world, g[:, 0, :], g[:, 3, :].astype(np.int32), g[:, 1, :], g[:, 2, :].astype(np.int32), tol)
+
+
+# ------------------------------------------------------------------------------------------
+# the exchange on the device
+# ------------------------------------------------------------------------------------------
+class _ExchangeBuffers:
+    """Device buffers of one plan's exchange records (torch owns the memory, the C ABI gets the
+    addresses) and the engine's stream as a torch stream, so that the collectives are enqueued
+    stream-ordered behind the export kernels."""
+
+    def __init__(self, plan, n_jobs: int):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.cost = torch.empty(max(n_jobs, 1), dtype=torch.float64, device=dev)
+        self.keys = torch.empty(3 * max(n_jobs, 1), dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.ExternalStream(plan.engine.stream, device=dev)
+
+
+def _buffers(plan, n_jobs):
+    b = getattr(plan, "_xbuf", None)
+    if b is None:
+        b = plan._xbuf = _ExchangeBuffers(plan, n_jobs)
+    return b
+
+
+def _all_reduce_min(t, group, stream):
+    """all_reduce(MIN) of a device tensor, ordered on `stream`.  RCCL reduces in place on the device; with a
+    CPU backend (gloo: the tests, several ranks on one GPU) the record takes the detour through the host."""
+    import torch
+    import torch.distributed as dist
+    with torch.cuda.stream(stream):
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        else:
+            h = t.cpu()                      # synchronises `stream`: the export kernel has finished
+            dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+            t.copy_(h)
+
+
+def search_device(plan, group=None):
+    """The search half of WithinPlan.run_sharded with the exchange on the device (module docstring)."""
+    n_jobs, n_levels, _tol = plan.dims()
+    b = _buffers(plan, n_jobs)
+    for l in range(n_levels):
+        plan.level_launch(l)
+        plan.level_export_cost(l, b.cost.data_ptr())
+        _all_reduce_min(b.cost, group, b.stream)
+        plan.level_export_keys(l, b.cost.data_ptr(), b.keys.data_ptr())
+        _all_reduce_min(b.keys, group, b.stream)
+        plan.level_commit_dev(l, b.cost.data_ptr(), b.keys.data_ptr())
+
+
+def search_inprocess(plans: Sequence):
+    """`world` shard plans of ONE process driven in lockstep with the device exchange, the all-reduces
+    replaced by element-wise minima over the plans' device records (tests: the kernels, the key encoding
+    and the commit are the ones a multi-rank run uses; only the transport differs)."""
+    import torch
+    n_jobs, n_levels, _tol = plans[0].dims()
+    bufs = [_buffers(p, n_jobs) for p in plans]
+    for l in range(n_levels):
+        for p, b in zip(plans, bufs):
+            p.level_launch(l)
+            p.level_export_cost(l, b.cost.data_ptr())
+        for p in plans:
+            p.engine.synchronize()
+        g = bufs[0].cost.clone()
+        for b in bufs[1:]:
+            g = torch.minimum(g, b.cost)
+        torch.cuda.synchronize()
+        for p, b in zip(plans, bufs):
+            b.cost.copy_(g)
+        torch.cuda.synchronize()
+        for p, b in zip(plans, bufs):
+            p.level_export_keys(l, b.cost.data_ptr(), b.keys.data_ptr())
+        for p in plans:
+            p.engine.synchronize()
+        k = bufs[0].keys.clone()
+        for b in bufs[1:]:
+            k = torch.minimum(k, b.keys)
+        torch.cuda.synchronize()
+        for p, b in zip(plans, bufs):
+            b.keys.copy_(k)
+        torch.cuda.synchronize()
+        for p, b in zip(plans, bufs):
+            p.level_commit_dev(l, b.cost.data_ptr(), b.keys.data_ptr())

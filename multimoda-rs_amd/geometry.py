@@ -275,6 +275,24 @@ class WithinPlan:
         N.check(N.lib().mm_within_plan_level_commit(self._h, int(level), N._ptr(ok), N._ptr(angle)),
                 "mm_within_plan_level_commit")
 
+    # -- the exchange on the device (mm_within_plan_level_launch / export_* / commit_dev) --
+    def level_launch(self, level: int):
+        N.check(N.lib().mm_within_plan_level_launch(self._h, int(level)), "mm_within_plan_level_launch")
+
+    def level_export_cost(self, level: int, cost_dev: int):
+        """cost_dev: device address of n_jobs float64."""
+        N.check(N.lib().mm_within_plan_level_export_cost(self._h, int(level), C.c_void_p(cost_dev)),
+                "mm_within_plan_level_export_cost")
+
+    def level_export_keys(self, level: int, gcost_dev: int, keys_dev: int):
+        """gcost_dev: the all-reduced costs; keys_dev: device address of 3 * n_jobs int64."""
+        N.check(N.lib().mm_within_plan_level_export_keys(self._h, int(level), C.c_void_p(gcost_dev), C.c_void_p(keys_dev)),
+                "mm_within_plan_level_export_keys")
+
+    def level_commit_dev(self, level: int, gcost_dev: int, keys_dev: int):
+        N.check(N.lib().mm_within_plan_level_commit_dev(self._h, int(level), C.c_void_p(gcost_dev), C.c_void_p(keys_dev)),
+                "mm_within_plan_level_commit_dev")
+
     def walk(self):
         G = len(self.geoms)
         log_bufs = [(N.MMAlignLog * max(g.n_frames - 1, 1))() for g in self.geoms]
@@ -291,6 +309,8 @@ class WithinPlan:
         process group this is the single-rank search.  walk() is the other half; a driver may overlap it
         with the search of the next, independent case (bench.py)."""
         from . import distributed as D
+        if D.world_size(group) > 1 and D.exchange_mode() == "device":
+            return D.search_device(self, group)
         n_jobs, n_levels, tol = self.dims()
         for l in range(n_levels):
             local = self.level_local(l, n_jobs)

@@ -1,0 +1,138 @@
+"""BASELINE-sized parity inside the driver-run GPU suite.
+
+The whole 4-phase alignment (entry.rs:140-277: four within-pullback chains, then AB | CD and
+AC | BD between-alignments) of the bench workloads
+
+  config2   4 pullbacks x 128 frames x 501 pts, 1 deg   x +-180 deg  (361 candidates / search)
+  config3   4 pullbacks x 512 frames x 501 pts, 0.5 deg x +-180 deg  (721 candidates / search)
+
+through the product's decoupled path (one launch over all frame pairs, host chain walk) in the
+FAST and BOUNDED precisions with the engine's shipped settings, compared bit for bit -- logs,
+between rotations, every output coordinate -- with the CPU oracle's sequential chain
+(align_within.rs:24-134) and its align_between (align_between.rs:11-68).  The oracle runs once
+per workload (about 4 s / 35 s on the GPU box's 16 host threads).  This is what
+``bench.py --check`` does; here it runs on every `pytest -m gpu`.
+
+Also one slice of the rotation x frame-shift EXTENSION grid at full length (512 frames, shifts
+-2..2) against oracle searches.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import geoms_equal, to_oracle
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "config2": dict(frames=128, points=501, step_deg=1.0, range_deg=180.0, sample_size=501),
+    "config3": dict(frames=512, points=501, step_deg=0.5, range_deg=180.0, sample_size=501),
+}
+BETWEEN_PAIRS = ((0, 1), (2, 3), (0, 2), (1, 3))      # AB | CD, then AC | BD (entry.rs:206-277)
+
+
+def _threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except Exception:
+        return 8
+
+
+@pytest.fixture(scope="module")
+def fresh_engine(mm):
+    """An engine with the shipped settings (test_gpu_parity.py switches its shared engine's bound
+    threshold to 0; the full-size cases must run what a caller gets by default)."""
+    import __graft_entry__ as ge
+    ge.build()
+    eng = mm.Engine()
+    yield eng
+    eng.close()
+
+
+_oracle_cache = {}
+
+
+def _oracle_alignment(oracle, mm, name):
+    """(logs per pullback, between rotations, final oracle geometries) of one workload."""
+    if name not in _oracle_cache:
+        cfg = CONFIGS[name]
+        base = mm.synthetic_case(cfg["frames"], cfg["points"])
+        og = [to_oracle(oracle, g) for g in base]
+        th = _threads()
+        logs = [oracle.align_within_chain(o, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"], n_threads=th)
+                for o in og]
+        rot = [oracle.align_between(og[i], og[j], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], n_threads=th)
+               for i, j in BETWEEN_PAIRS]
+        _oracle_cache[name] = (logs, rot, og)
+    return _oracle_cache[name]
+
+
+@pytest.mark.parametrize("precision", ["fast", "bounded"])
+@pytest.mark.parametrize("name", ["config2", "config3"])
+def test_full_four_phase_alignment_equals_oracle(fresh_engine, oracle, mm, name, precision):
+    cfg = CONFIGS[name]
+    prec = {"fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED}[precision]
+    ologs, orot, ogeoms = _oracle_alignment(oracle, mm, name)
+    geoms = mm.synthetic_case(cfg["frames"], cfg["points"])
+    plan = mm.WithinPlan(fresh_engine, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"], precision=prec)
+    logs, evals, unresolved = plan.run()
+    plan.close()
+    n_ang = len(mm.search_angles(cfg["step_deg"], cfg["range_deg"])[0])
+    assert evals == 4 * (cfg["frames"] - 1) * n_ang
+    assert unresolved == 0                      # generic data: every step decided by the one-shot search
+    for k in range(4):
+        assert logs[k] == ologs[k], f"within logs of pullback {k} differ"
+    a, b, c, d = geoms
+    r1, _ = mm.align_between(fresh_engine, [(a, b), (c, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], prec)
+    r2, _ = mm.align_between(fresh_engine, [(a, c), (b, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], prec)
+    assert list(r1) + list(r2) == orot
+    for k, (g, og) in enumerate(zip(geoms, ogeoms)):
+        assert geoms_equal(g, og), f"coordinates of pullback {k} differ"
+
+
+def test_full_size_chain_mode_equals_oracle_config2(fresh_engine, oracle, mm):
+    """The faithful per-step chain (mode 0) at config2 size: 127 dependent batched searches."""
+    cfg = CONFIGS["config2"]
+    ologs, _orot, _og = _oracle_alignment(oracle, mm, "config2")
+    geoms = mm.synthetic_case(cfg["frames"], cfg["points"])
+    logs, evals = mm.align_within(fresh_engine, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                                  precision=mm.MM_PRECISION_F32_FAST, mode=0)
+    for k in range(4):
+        assert logs[k] == ologs[k]
+    assert evals == 4 * 127 * 361
+
+
+@pytest.mark.parametrize("precision", ["fast", "bounded"])
+def test_extension_grid_full_length_slice_vs_oracle(fresh_engine, oracle, mm, precision):
+    """EXTENSION axis (absent from the reference's 4-phase path): one 512-frame pullback, shifts -2..2,
+    721 rotations = 2 041 searches.  Every 8th search is re-done by the oracle (brute force over the same
+    candidate list on the same centred sets); winners and exact costs must agree bit for bit, and the
+    bounded search must agree with the full screen everywhere."""
+    prec = {"fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED}[precision]
+    g = mm.synthetic_pullback(512, 501, pullback_id=2)
+    srs = mm.ShiftRotationSearch(fresh_engine, [g], -2, 2, 0.5, 180.0, 501, precision=prec)
+    res = srs.run()
+    angles = srs.angles
+    assert len(angles) == 721 and len(srs.meta) == 4 * 512 - 7   # refs i-3, i-2, i-1, i+1 inside the pullback
+    sets = {}
+
+    def centred(i):
+        if i not in sets:
+            sets[i] = mm.search_set(g, int(i), 501) - g.centroids[i, :2]
+        return sets[i]
+
+    th = _threads()
+    for p in range(0, len(srs.meta), 8):
+        _gi, i, _sh, j = srs.meta[p]
+        # the oracle's search_range over the same list (process_utils.rs:33-75), candidates in parallel
+        best = oracle.bruteforce_rotation(centred(j), centred(i), 0.5, 180.0, 0.0, 0.0, n_threads=th)
+        assert res["best_angle"][p] == best and angles[res["best_idx"][p]] == best
+        assert res["best_cost"][p] == oracle.cost_within(centred(j), centred(i), best, 0.0, 0.0)
+    srs.close()
+    key = "ext_slice_result"
+    if key in _oracle_cache:                     # second precision: identical to the first everywhere
+        prev = _oracle_cache[key]
+        assert np.array_equal(prev["best_idx"], res["best_idx"]) and np.array_equal(prev["best_cost"], res["best_cost"])
+        assert prev["winners"] == res["winners"]
+    _oracle_cache[key] = res

@@ -1,0 +1,140 @@
+"""The real multi-rank WithinPlan path on the GPU.
+
+(a) In one process: `world` WithinPlans on copies of the same geometries, each owning its share
+    [n*r/world, n*(r+1)/world) of every candidate list (set_shard), driven level by level exactly as
+    `world` ranks would be: level_local on every plan -> merge of the per-shard records
+    (mm_merge_shards, what every rank computes after the exchange) -> level_commit into every plan ->
+    walk.  Logs, coordinates and the number of re-searched steps of EVERY "rank" must equal the
+    single-rank plan.run() and the oracle's sequential chain.
+(b) The same through torch.distributed: a world = 2 `gloo` child (torch.distributed.run) on the one
+    GPU drives plan.run_sharded() end to end (tests/_shard_worker.py).
+"""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import geoms_equal, to_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision, exchange="gather"):
+    """Run `world` shard plans in lockstep; returns per rank (geoms, logs, evals, unresolved)."""
+    from multimoda_rs_amd import distributed as D
+    cases = [[g.copy() for g in base] for _ in range(world)]
+    plans = [mm.WithinPlan(engine, cases[r], step, rng_deg, bruteforce, ss, precision=precision) for r in range(world)]
+    for r, p in enumerate(plans):
+        p.set_shard(r, world)
+    n_jobs, n_levels, tol = plans[0].dims()
+    if exchange == "gather":
+        for l in range(n_levels):
+            loc = [p.level_local(l, n_jobs) for p in plans]
+            stack = lambda k: np.stack([x[k] for x in loc], axis=0)
+            for x in loc[1:]:
+                assert np.array_equal(x["active"], loc[0]["active"])      # every rank searches the same jobs
+            ok, angle, _idx, _cost = D.merge_shards(world, stack("cost"), stack("uniform"), stack("angle"), stack("idx"), tol)
+            for p in plans:
+                p.level_commit(l, ok, angle)
+    else:
+        D.search_inprocess(plans)             # device-side exchange, all_reduce(MIN) emulated over the plans
+    out = []
+    for r, p in enumerate(plans):
+        logs, evals, unres = p.walk()
+        out.append((cases[r], logs, evals, unres))
+        p.close()
+    return out
+
+
+CASES = [
+    # bruteforce, step, range, sample_size
+    (True, 1.0, 180.0, 501),          # 361 candidates; first and last are both -pi (duplicates on different shards)
+    (False, 0.05, 45.0, 200),         # ladder 1 deg -> 0.1 deg -> 0.05 deg: per-job lists from level 1 on
+    (True, 45.0, 90.0, 64),           # 5 candidates: with world = 8 some shards own nothing
+]
+
+
+@pytest.mark.parametrize("exchange", ["gather", "device"])
+@pytest.mark.parametrize("precision", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES)
+def test_sharded_within_plan_equals_single_rank_and_oracle(engine, oracle, mm, bruteforce, step, rng_deg, ss, world,
+                                                           precision, exchange):
+    engine.set_bound_min_candidates(0)        # bound rounds on every batch (shards prune against their own best)
+    try:
+        base = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((9, 6, 9, 7))]
+        single = [g.copy() for g in base]
+        wp = mm.WithinPlan(engine, single, step, rng_deg, bruteforce, ss, precision=precision)
+        slogs, sevals, sunres = wp.run()
+        wp.close()
+        ogeoms = [to_oracle(oracle, g) for g in base]
+        ologs = [oracle.align_within_chain(o, step, rng_deg, bruteforce, ss, n_threads=8) for o in ogeoms]
+        for geoms, logs, evals, unres in drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision,
+                                                       exchange):
+            assert evals == sevals and unres == sunres
+            for k in range(len(base)):
+                assert logs[k] == slogs[k] == ologs[k]
+                assert geoms_equal(geoms[k], ogeoms[k]) and geoms_equal(single[k], ogeoms[k])
+    finally:
+        engine.set_bound_min_candidates(16384)
+
+
+@pytest.mark.parametrize("exchange", ["gather", "device"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_cross_shard_ties_fall_back_to_chain_state(engine, oracle, mm, world, exchange):
+    """Perfect circles: every candidate of every shard ties up to rounding, so no shard is uniform, the merge
+    cannot decide (ok == 0) and every step is searched again on the chain state during the walk."""
+    t = np.arange(120) * (2 * math.pi / 120)
+    lum = [np.stack([4.5 + 0.01 * k + 2 * np.cos(t), 4.4 + 2 * np.sin(t), np.full_like(t, 0.5 * k)], 1) for k in range(5)]
+    g = mm.FlatGeometry.from_frames(lum, ref_points={0: (6.5, 4.4, 0.0)})
+    og = to_oracle(oracle, g)
+    ol = oracle.align_within_chain(og, 2.0, 60.0, True, 120)
+    for geoms, logs, _evals, unres in drive_sharded(mm, engine, [g], world, 2.0, 60.0, True, 120, 2, exchange):
+        assert logs[0] == ol and geoms_equal(geoms[0], og)
+        assert unres == 4
+
+
+@pytest.mark.parametrize("exchange", ["gather", "device"])
+def test_sharded_near_tie_across_two_shards(engine, oracle, mm, exchange):
+    """A two-fold symmetric frame pair: the candidates theta and theta + pi cost the same up to rounding and
+    lie on different shards (world = 2 splits +-180 deg in the middle).  Each shard alone is uniform; only
+    the merge sees two different angles within the tolerance -> undecided -> re-searched on the chain
+    state, with the oracle's result."""
+    t = np.arange(200) * (2 * math.pi / 200)
+    def ell(k, rot):
+        x, y = 2.4 * np.cos(t), 1.5 * np.sin(t)                          # centrally symmetric: R(pi) maps it onto itself
+        c, s = math.cos(rot), math.sin(rot)
+        return np.stack([4.5 + c * x - s * y, 4.5 + s * x + c * y, np.full_like(t, 0.5 * k)], 1)
+    g = mm.FlatGeometry.from_frames([ell(0, 0.0), ell(1, math.radians(30.0)), ell(2, math.radians(50.0))],
+                                    ref_points={0: (6.9, 4.5, 0.0)})
+    og = to_oracle(oracle, g)
+    ol = oracle.align_within_chain(og, 1.0, 180.0, True, 200)
+    single = g.copy()
+    wp = mm.WithinPlan(engine, [single], 1.0, 180.0, True, 200, precision=2)
+    slogs, _e, sunres = wp.run()
+    wp.close()
+    assert slogs[0] == ol and geoms_equal(single, og)
+    for geoms, logs, _evals, unres in drive_sharded(mm, engine, [g], 2, 1.0, 180.0, True, 200, 2, exchange):
+        assert logs[0] == ol and geoms_equal(geoms[0], og)
+        assert unres == sunres
+
+
+@pytest.mark.parametrize("exchange", ["gather", "device"])
+def test_run_sharded_world2_gloo_on_the_gpu(exchange):
+    """plan.run_sharded() end to end over torch.distributed (`gloo`, two ranks sharing the one GPU)."""
+    import __graft_entry__ as ge
+    ge.build()
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["OMP_NUM_THREADS"] = "4"
+    env["MM_EXCHANGE"] = exchange
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29700 + (os.getpid() % 200)),
+           os.path.join(ROOT, "tests", "_shard_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "SHARD_WORKER_OK" in r.stdout
