@@ -13,7 +13,13 @@ AC|BD between-pullback alignments, all through the product's C ABI.  Workloads
            512-frame x 501-pt case BASELINE.json's targets are quoted on, and the one its
            multi-GPU config shards)
 
-Usage: python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run)
+`value` is the WHOLE step: the case starts on the host, its raw pullbacks go to HBM over PCIe, the
+search sets are built on the device, then search (N > 1: + the RCCL exchange), chain walk and between
+alignments.  Consecutive (independent) cases are pipelined: K stagings, K searches, K finishes inside
+the timed region.
+
+Usage: python bench.py --gpus N --steps K --warmup W   (N > 1: under torch.distributed.run, or plainly --
+then the N ranks are started as a child job)
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -71,17 +77,27 @@ def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     return logs, rot, evals + e2, unresolved
 
 
-def run_steps(ks, search, finish, pipelined):
-    """Run steps `ks`: search(k) then finish(k).  pipelined: steps are independent cases, so the search of
-    step k+1 (the GPU-heavy half, and the only half with collectives) overlaps the chain walk and between
-    alignment of step k on a second host thread; every step's work still completes inside the call."""
+def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2):
+    """Run steps `ks`: search(k) then finish(k), and -- if `stage` is given -- stage(k + lookahead) after
+    finish(k) (the caller has staged the first `lookahead` steps of `ks` itself: priming), so a call over K steps
+    does K stagings, K searches and K finishes.
+    pipelined: steps are independent cases, so the search of step k+1 (the GPU-heavy half, and the only half with
+    collectives) overlaps the chain walk and between alignment of step k and the staging of step k+2 on a second
+    host thread; step k lives on engine k % 2, so step k+2 is staged only after step k is finished, and searched
+    only after it is staged.  Every step's work completes inside the call."""
+    ks = list(ks)
     if not pipelined:
-        return [(search(k), finish(k))[1] for k in ks]
+        out = []
+        for k in ks:
+            search(k)
+            out.append(finish(k))
+            if stage is not None:
+                stage(k + lookahead)
+        return out
     import queue
     import threading
-    ks = list(ks)
     q, out, err = queue.Queue(), {}, []
-    done = {k: threading.Event() for k in ks}
+    done = {k: threading.Event() for k in ks}            # finished (and its successor on the same engine staged)
 
     def worker():
         while True:
@@ -90,6 +106,8 @@ def run_steps(ks, search, finish, pipelined):
                 return
             try:
                 out[k] = finish(k)
+                if stage is not None:
+                    stage(k + lookahead)
             except BaseException as ex:   # surfaced on the main thread
                 err.append(ex)
                 return
@@ -166,7 +184,7 @@ def cpu_baseline(cfg, geoms, threads, budget_s=10.0):
                       f"({n_angles} candidates each, N={ss + 20} pts/set), {t_used:.1f} s"}
 
 
-def dominant_launch(ms, pair_evals):
+def dominant_launch(ms, pair_evals, peak=FP32_VECTOR_PEAK_TFLOPS):
     """The launches that carry the work (>= half of the largest launch's pair-distances: the one
     within-stage launch of every step): their count, mean device time and algorithmic rate -- the
     figures to hold against the per-dispatch rows of the committed rocprofv3 kernel trace."""
@@ -177,7 +195,67 @@ def dominant_launch(ms, pair_evals):
     pe = float(pair_evals[big].mean())
     tf = pe * FLOPS_PER_PAIR_EVAL / (t * 1e-3) * 1e-12
     return {"launches": int(big.sum()), "avg_ms": t, "pair_distance_evals": pe, "tflops": tf,
-            "frac": tf / FP32_VECTOR_PEAK_TFLOPS}
+            "frac": tf / peak}
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md, Peak FP64 (vector)
+
+
+class Runner:
+    """The three pieces of a step for one precision: stage(k) (raw pullbacks -> HBM, search sets built on the
+    device, level 0 staged), search(k) (all levels: local search -> exchange -> commit) and finish(k) (chain walk,
+    AB|CD and AC|BD between alignments).  Step k lives on engine k % 2 and works on its own copy of the case."""
+
+    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases):
+        self.mm, self.engs, self.cfg, self.prec, self.mode, self.rank, self.world, self.ext = mm, engs, cfg, prec, mode, rank, world, ext
+        # the caller's input data: one fresh copy of the case per step (made before the timed region -- this is
+        # the data a caller hands over, not work of the step)
+        self.cases = [base if ext is not None else [g.copy() for g in base] for _ in range(n_cases)]
+        self.plans = [None] * n_cases
+        self.stage_s = 0.0
+        self.staged = 0
+        if ext is not None:
+            # the EXTENSION grid keeps round 1's protocol: its (Python-built) sets are staged before the timed region
+            for k in range(n_cases - 2):
+                self.plans[k] = mm.ShiftRotationSearch(engs[0], self.cases[k], ext[0], ext[1], cfg["step_deg"],
+                                                       cfg["range_deg"], cfg["sample_size"], precision=prec)
+
+    def stage(self, k):
+        if k >= len(self.cases) or self.mode != 1 or self.ext is not None:
+            return
+        mm, cfg = self.mm, self.cfg
+        t0 = time.perf_counter()
+        self.plans[k] = mm.WithinPlan(self.engs[k % 2], self.cases[k], cfg["step_deg"], cfg["range_deg"], True,
+                                      cfg["sample_size"], precision=self.prec,
+                                      shard=(self.rank, self.world) if self.world > 1 else None)
+        self.stage_s += time.perf_counter() - t0
+        self.staged += 1
+
+    def search(self, k):
+        if self.plans[k] is not None and self.ext is None:
+            self.plans[k].search()                       # levels: local search -> exchange -> commit
+
+    def finish(self, k):
+        mm, cfg = self.mm, self.cfg
+        if self.ext is not None:
+            r = self.plans[k].run()
+            out = (r["winners"], None, self.plans[k].pose_evals, 0)
+        elif self.plans[k] is None:
+            out = full_alignment(mm, self.engs[0], self.cases[k], cfg, None, self.prec)
+        else:
+            logs, ev, unres = self.plans[k].walk()
+            rot, e2 = between_stage(mm, self.engs[k % 2], self.cases[k], cfg, self.prec)
+            out = (logs, rot, ev + e2, unres)
+        if self.plans[k] is not None:
+            self.plans[k].close()                        # HBM of the step is released; at most three plans are alive
+            self.plans[k] = None
+        return out
+
+    def close(self):
+        for i, p in enumerate(self.plans):
+            if p is not None:
+                p.close()
+                self.plans[i] = None
 
 
 def main():
@@ -189,11 +267,12 @@ def main():
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
     ap.add_argument("--precision", default="fast", choices=["f32", "fast", "bounded", "f64"],
                     help="candidate scoring: f32 = direct-form f32 screen + exact f64 re-score; fast = expanded-form "
-                         "f32 screen + exact f64 re-score (default; the same workload through the bounded search is "
-                         "reported beside it); bounded = lower bounds rule candidates out before the screen (not "
-                         "pose-evals in SURVEY 8(d)'s sense: for measurements of that path, never the headline); "
-                         "f64 = every candidate in exact f64")
+                         "f32 screen + exact f64 re-score (default; the same workload through the bounded search and "
+                         "through the all-f64 kernel is reported beside it); bounded = lower bounds rule candidates out "
+                         "before the screen (not pose-evals in SURVEY 8(d)'s sense: for measurements of that path, "
+                         "never the headline); f64 = every candidate in exact f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the bounded-search, all-f64 and sequential legs")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the CPU baseline (default: the GPU box's CPU share per GPU, 16, or fewer cores)")
     ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle (slow)")
@@ -202,9 +281,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as a child job (one process per GPU) and pass its
+        # exit code on.  This parent never touches the GPU and does not exec.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
     import torch.distributed as dist
@@ -229,69 +318,22 @@ def main():
 
     cfg = WORKLOADS[args.workload]
     mode = 0 if args.mode == "chain" else 1
-    PREC = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED,
-            "f64": mm.MM_PRECISION_F64}[args.precision]
+    PRECS = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED,
+             "f64": mm.MM_PRECISION_F64}
+    PREC = PRECS[args.precision]
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
-    # two engines (stream + staging buffers each): step k lives on engine k % 2, so the search of step k+1
-    # and the walk + between alignment of step k never share one (run_steps)
+    # two engines (main stream, high-priority side stream, staging buffers each): step k lives on engine k % 2,
+    # so the search of step k+1 never shares one with the finish of step k or the staging of step k+2
     engs = [mm.Engine(local_rank), mm.Engine(local_rank)]
-    eng = engs[0]
-    pipelined = mode == 1 and cfg.get("shift") is None and not os.environ.get("MM_BENCH_SEQUENTIAL")
-
-    # Every step works on a fresh copy of the case.  In decoupled mode the copies are staged
-    # into HBM (mm.WithinPlan) before the timed region: inputs resident, as the contract asks;
-    # the staging-inclusive rate is reported separately.
-    # N > 1: the candidate axis is sharded -- rank r scores candidates [n*r/N, n*(r+1)/N) of
-    # every frame pair; per-shard bests are exchanged over RCCL (multimoda_rs_amd.distributed)
-    # and every rank then walks the chain and runs the small between stage (strong scaling).
-    if world > 1 and mode != 1:
-        raise SystemExit("--gpus N > 1 shards the decoupled search; use --mode decoupled")
-    n_total = args.warmup + args.steps
-    t_stage0 = time.perf_counter()
-    cases, plans = [], []
     ext = cfg.get("shift")
-    if ext is not None:
-        if world > 1:
-            raise SystemExit("config3ext is a single-GPU workload")
-        for _ in range(n_total):
-            plans.append(mm.ShiftRotationSearch(eng, base, ext[0], ext[1], cfg["step_deg"], cfg["range_deg"],
-                                                cfg["sample_size"], precision=PREC))
-            cases.append(base)
-    for _ in range(0 if ext is not None else n_total):
-        geoms = [g.copy() for g in base]
-        cases.append(geoms)
-        plan = None
-        if mode == 1:
-            plan = mm.WithinPlan(engs[len(plans) % 2], geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                                 precision=PREC)
-            if world > 1:
-                plan.set_shard(rank, world)
-        plans.append(plan)
-    for e in engs:
-        e.synchronize()
-    t_stage = (time.perf_counter() - t_stage0) / n_total
-    if pipelined:
-        # setup, not a step: let both engines grow the transient buffers of the between stage now (the W warm-up
-        # steps alone would leave the second engine's first allocations inside the timed region when W = 1)
-        for e in engs:
-            between_stage(mm, e, [g.copy() for g in base], cfg, PREC)
+    pipelined = mode == 1 and ext is None and not os.environ.get("MM_BENCH_SEQUENTIAL")
+    LOOK = 2
 
-    def make_steps(cases_, plans_, prec):
-        """(search, finish) of step k: decoupled mode splits at the exchange (everything that needs the other
-        ranks is in search); the faithful chain and the extension grid are one piece."""
-        def search(k):
-            if plans_[k] is not None and ext is None:
-                plans_[k].search()                       # levels: local search -> exchange -> merge -> commit
-        def finish(k):
-            if ext is not None:
-                r = plans_[k].run()
-                return r["winners"], None, plans_[k].pose_evals, 0
-            if plans_[k] is None:
-                return full_alignment(mm, eng, cases_[k], cfg, None, prec)
-            logs, ev, unres = plans_[k].walk()
-            rot, e2 = between_stage(mm, engs[k % 2], cases_[k], cfg, prec)
-            return logs, rot, ev + e2, unres
-        return search, finish
+    # N > 1: the candidate axis is sharded -- rank r scores candidates [n*r/N, n*(r+1)/N) of every frame pair;
+    # per-shard bests are all-reduced over RCCL on the device (multimoda_rs_amd.distributed) and every rank then
+    # walks the chain and runs the small between stage (strong scaling).
+    if world > 1 and (mode != 1 or ext is not None):
+        raise SystemExit("--gpus N > 1 shards the decoupled 4-phase search; use --mode decoupled on config2/config3")
 
     def barrier():
         if world > 1:
@@ -313,90 +355,109 @@ def main():
             e.profile(False)
         return np.concatenate(ms), np.concatenate(pe), tot, bound_
 
-    search, finish = make_steps(cases, plans, PREC)
-    run_steps(range(args.warmup), search, finish, pipelined)
-    barrier()
-    for e in engs:
-        e.profile(True)
-    # keep the interpreter's cyclic GC (tens of ms per full collection) out of the timed steps
-    import gc
-    gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    results = run_steps(range(args.warmup, n_total), search, finish, pipelined)
-    tb = time.perf_counter()
-    barrier()
-    dt = time.perf_counter() - t0
-    res = results[-1]
-    evals = sum(r[2] for r in results)
-    unresolved = sum(r[3] for r in results)
-    if os.environ.get("MM_TRACE"):
-        print(f"[bench trace] final barrier {1e3 * (time.perf_counter() - tb):.3f} ms, total {1e3 * dt:.3f} ms", file=sys.stderr)
-    launch_ms, launch_pe, prof, bound = read_profiles()
-    if args.precision != "bounded":
-        bound = None
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item())
 
-    if world > 1:
-        t = torch.tensor([dt, float(evals)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax[0].item())     # max over ranks; every rank holds the same whole-job pose-eval count
-
-    # The same workload through MM_PRECISION_F32_BOUNDED (lower bounds rule most candidates out before
-    # the screen; winners identical).  Reported beside the headline, never as `value`: a candidate that
-    # is ruled out is resolved, not evaluated, so these are not pose-evals in SURVEY 8(d)'s sense.
-    def bounded_search_leg():
-        BND = mm.MM_PRECISION_F32_BOUNDED
-        cases2, plans2 = [], []
-        for _ in range(1 + args.steps):
-            geoms = [g.copy() for g in base]
-            cases2.append(geoms)
-            plan = mm.WithinPlan(engs[len(plans2) % 2], geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                                 precision=BND)
-            if world > 1:
-                plan.set_shard(rank, world)
-            plans2.append(plan)
-        for e in engs:
-            e.synchronize()
-        search2, finish2 = make_steps(cases2, plans2, BND)
-        run_steps(range(1), search2, finish2, pipelined)
+    def timed_leg(prec, warmup, steps, pipe):
+        """W untimed + K timed steps of one precision.  Inside the timed region: K stagings (raw pullbacks ->
+        HBM -> search sets), K searches, K finishes.  The pipeline is primed before it (the first LOOK cases are
+        staged during set-up / warm-up), so the stagings in the region are those of steps W+LOOK .. W+K+LOOK-1:
+        steady-state throughput of a stream of cases, the last LOOK staged cases are not searched."""
+        n_total = warmup + steps
+        r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK)
+        for k in range(LOOK):
+            r.stage(k)                                   # priming (setup, untimed)
+        run_steps(range(warmup), r.search, r.finish, pipe, r.stage, LOOK)
         barrier()
         for e in engs:
             e.profile(True)
-        tb0 = time.perf_counter()
-        results2 = run_steps(range(1, 1 + args.steps), search2, finish2, pipelined)
+        r.stage_s, r.staged = 0.0, 0
+        import gc
+        gc.collect()
+        gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
+        t0 = time.perf_counter()
+        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, r.stage, LOOK)
         barrier()
-        dt2 = time.perf_counter() - tb0
-        res2 = results2[-1]
-        ev2 = sum(r[2] for r in results2)
-        _ms, _pe, _tot, stats = read_profiles()
-        if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t[0].item())
-        same = (list(res2[0]) == list(res[0]) and np.array_equal(res2[1], res[1]) and
-                all(np.array_equal(g.lumen, h.lumen) and np.array_equal(g.cath, h.cath) and np.array_equal(g.centroids, h.centroids)
-                    for g, h in zip(cases2[-1], cases[n_total - 1])))
-        for pl in plans2:
-            pl.close()
-        return {"candidates_resolved_per_s": ev2 / dt2, "ms_per_step": dt2 / args.steps * 1e3,
-                "identical_to_bruteforce_result": bool(same), "counts": stats,
-                "note": "MM_PRECISION_F32_BOUNDED on the same workload and steps: every candidate of the grid is "
-                        "either ruled out by a lower bound of its Hausdorff distance or evaluated; same winners, "
-                        "logs and coordinates as the brute-force run above (compared here)"}
+        dt = time.perf_counter() - t0
+        gc.enable()
+        prof = read_profiles()
+        last_case = r.cases[n_total - 1]
+        stage_ms = 1e3 * r.stage_s / max(r.staged, 1)
+        r.close()
+        return dict(dt=reduce_max(dt), results=results, evals=sum(x[2] for x in results), unresolved=sum(x[3] for x in results),
+                    prof=prof, last_case=last_case, stage_ms=stage_ms, staged=r.staged)
 
-    bounded_leg = None
-    if args.precision == "fast" and ext is None and mode == 1:
+    # setup, not a step: let both engines grow their transient buffers (between stage) now
+    if ext is None:
+        for e in engs:
+            between_stage(mm, e, [g.copy() for g in base], cfg, PREC)
+
+    main_leg = timed_leg(PREC, args.warmup, args.steps, pipelined)
+    dt, results, evals, unresolved = main_leg["dt"], main_leg["results"], main_leg["evals"], main_leg["unresolved"]
+    launch_ms, launch_pe, prof, bound = main_leg["prof"]
+    res = results[-1]
+    if args.precision != "bounded":
+        bound = None
+
+    def same_result(leg):
+        r2 = leg["results"][-1]
+        return bool(list(r2[0]) == list(res[0]) and np.array_equal(r2[1], res[1]) and
+                    all(np.array_equal(g.lumen, h.lumen) and np.array_equal(g.cath, h.cath) and np.array_equal(g.centroids, h.centroids)
+                        for g, h in zip(leg["last_case"], main_leg["last_case"])))
+
+    extra = {}
+    if args.precision == "fast" and ext is None and mode == 1 and not args.no_extra_legs:
+        # The same workload through MM_PRECISION_F32_BOUNDED (lower bounds rule most candidates out before the
+        # screen; winners identical).  Reported beside the headline, never as `value`: a candidate that is ruled
+        # out is resolved, not evaluated, so these are not pose-evals in SURVEY 8(d)'s sense.
         try:
-            bounded_leg = bounded_search_leg()
-        except Exception as ex:   # the extra leg must never take the headline line down with it
-            bounded_leg = {"error": f"{type(ex).__name__}: {ex}"}
+            leg = timed_leg(mm.MM_PRECISION_F32_BOUNDED, 1, args.steps, pipelined)
+            extra["bounded_search"] = {
+                "candidates_resolved_per_s": leg["evals"] / leg["dt"], "ms_per_step": leg["dt"] / args.steps * 1e3,
+                "identical_to_bruteforce_result": same_result(leg), "counts": leg["prof"][3],
+                "note": "MM_PRECISION_F32_BOUNDED on the same workload and steps: every candidate of the grid is either "
+                        "ruled out by a lower bound of its Hausdorff distance or evaluated; same winners, logs and "
+                        "coordinates as the brute-force run above (compared here)"}
+        except Exception as ex:   # an extra leg must never take the headline line down with it
+            extra["bounded_search"] = {"error": f"{type(ex).__name__}: {ex}"}
+        # Every candidate in exact f64, the reference's own arithmetic (MM_PRECISION_F64): the number comparable
+        # with the reference's f64 path; priced against the fp64 vector peak.
+        try:
+            k64 = max(2, min(args.steps, 3))
+            leg = timed_leg(mm.MM_PRECISION_F64, 1, k64, pipelined)
+            p64 = leg["prof"][2]
+            tf = p64["pair_evals"] * FLOPS_PER_PAIR_EVAL / (p64["ms"] * 1e-3) * 1e-12 if p64["ms"] > 0 else 0.0
+            extra["f64_exact"] = {"value": leg["evals"] / leg["dt"], "unit": "pose-evals/s", "steps": k64,
+                                  "ms_per_step": leg["dt"] / k64 * 1e3, "dtype": "f64",
+                                  "identical_to_headline_result": same_result(leg),
+                                  "roofline": {"bound": "valu-fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                               "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                                               "kernel": "mm::k_search<double,17,32,true,false>",
+                                               "avg_launch_ms": p64["ms"] / max(p64["launches"], 1)}}
+        except Exception as ex:
+            extra["f64_exact"] = {"error": f"{type(ex).__name__}: {ex}"}
+        # The headline steps one after the other (stage -> search -> finish, nothing overlapped)
+        try:
+            leg = timed_leg(PREC, 1, 3, False)
+            extra["sequential"] = {"value": leg["evals"] / leg["dt"], "ms_per_step": leg["dt"] / 3 * 1e3,
+                                   "stage_ms_per_step": leg["stage_ms"]}
+        except Exception as ex:
+            extra["sequential"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         na = nb = cfg["sample_size"] + 20
         kern_s = prof["ms"] * 1e-3
         achieved_tflops = prof["pair_evals"] * FLOPS_PER_PAIR_EVAL / kern_s * 1e-12 if kern_s > 0 else 0.0
         algo_gbs = prof["candidates"] * BYTES_PER_POSE_EVAL(na, nb) / kern_s * 1e-9 if kern_s > 0 else 0.0
+        f64_main = args.precision == "f64"
+        peak = FP64_VECTOR_PEAK_TFLOPS if f64_main else FP32_VECTOR_PEAK_TFLOPS
+        # executed VALU lane-operations per squared distance the reference counts twice (2 x 6 = 12 algorithmic FLOP):
+        # fast screen 4 packed-FMA lanes (8 FLOP) + 1 add + 2 min -> 7 issue slots; direct form 8; f64 kernel 7
+        exec_per_12 = {"fast": 7.0, "f32": 8.0, "bounded": None, "f64": 7.0}[args.precision]
         out = {
             "metric": "Hausdorff pose-evals/sec (frames x poses) for 4-phase full align; best-pose match",
             "value": evals / dt,
@@ -419,24 +480,35 @@ def main():
                                    f"{cfg['points']} pts (N={na} pts/set), {cfg['step_deg']} deg x +-{cfg['range_deg']} deg "
                                    f"bruteforce grid", "mode": args.mode, "pose_evals_per_step": evals // max(args.steps, 1),
                        "chain_steps_researched_on_chain_state": unresolved,
-                       "value_incl_host_staging": evals / (dt + t_stage * args.steps),
+                       "value_includes": ("host staging (raw pullbacks host -> HBM over PCIe, search sets built on the device), "
+                                          "search, exchange, chain walk, between alignments: the whole step, inputs on the HOST "
+                                          "when a step starts") if (mode == 1 and ext is None) else
+                                         ("search only, point sets staged in HBM before the timed region" if ext is not None else
+                                          "the whole step (faithful chain: sets built and uploaded per chain step)"),
+                       "staged_cases_in_timed_region": main_leg["staged"], "stage_ms_per_case": main_leg["stage_ms"],
                        "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU",
-                       "step_pipeline": ("2-stage over consecutive (independent) steps: search of step k+1 || chain walk + "
-                                         "between alignment of step k (second host thread, second engine); every step "
-                                         "completes inside the timed region") if pipelined else "sequential"},
+                       "exchange": (os.environ.get("MM_EXCHANGE", "device") + (" (2 all-reduces per level on device records)"
+                                    if os.environ.get("MM_EXCHANGE", "device") == "device" else "")) if world > 1 else None,
+                       "step_pipeline": ("3 pieces per step over consecutive (independent) cases: search of step k+1 || chain "
+                                         "walk + between alignment of step k, then staging of step k+2 (second host thread; "
+                                         "engine k % 2; staging and the small kernels on a high-priority stream); K stagings, K "
+                                         "searches, K finishes inside the timed region, the pipeline primed before it") if pipelined else "sequential"},
             "roofline": {
-                "bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                "bound": "valu", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved_tflops / peak,
+                "executed_op_frac": (achieved_tflops / peak) * exec_per_12 / 12.0 if exec_per_12 else None,
                 "traffic": committed_traffic(args.workload, args.precision),
                 "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
                            "bounded": "mm::k_screen_lb<5, false>",
                            "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
-                "dominant_launch": dominant_launch(launch_ms, launch_pe),
-                "note": "point-set min/max metric: bounded by fp32 VALU issue (SURVEY 8(d)), not HBM/MFMA; "
-                        "achieved = pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every "
-                        "launch); traffic = HBM bytes per launch of the big launch (FETCH_SIZE+WRITE_SIZE, committed "
-                        "rocprofv3 --pmc passes in profiles/)",
+                "dominant_launch": dominant_launch(launch_ms, launch_pe, peak),
+                "note": "point-set min/max metric: bounded by VALU issue (SURVEY 8(d)), not HBM/MFMA; achieved = ALGORITHMIC "
+                        "rate: pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every launch on "
+                        "the kernel's stream); executed_op_frac = the same launches priced by the lane-operations the kernel "
+                        "executes (each squared distance is computed once and serves both directed terms: 7 issue slots "
+                        "against 12 algorithmic FLOP); traffic = HBM bytes per launch of the big launch (FETCH_SIZE+WRITE_SIZE, "
+                        "committed rocprofv3 --pmc passes in profiles/)",
                 "hbm": {"bound": "hbm", "achieved": algo_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_gbs / HBM_PEAK_GBS,
                         "note": "algorithmic no-reuse bytes ((Na+Nb)*8+8 per pose-eval) / kernel time"},
@@ -446,8 +518,7 @@ def main():
             out["config"]["bounded_screen"] = bound
             out["unit"] = "candidates resolved/s"
             out["metric"] += " -- BOUNDED SEARCH: candidates ruled out by a lower bound or evaluated (same winners), not pose-evals"
-        if bounded_leg is not None:
-            out["bounded_search"] = bounded_leg
+        out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             try:
                 avail = len(os.sched_getaffinity(0))
@@ -467,7 +538,7 @@ def main():
                                             n_threads=threads) for o in og]
             orot = [orc.align_between(og[i], og[j], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], n_threads=threads)
                     for i, j in ((0, 1), (2, 3), (0, 2), (1, 3))]
-            last = cases[n_total - 1]
+            last = main_leg["last_case"]
             out["check"] = {
                 "within_logs_identical": bool(list(res[0]) == ologs),
                 "between_rotations_identical": bool(list(res[1]) == orot),
@@ -478,7 +549,7 @@ def main():
             }
         print(json.dumps(out))
     if world > 1:
-        # every rank must have produced the same alignment (merged winners -> identical host walk)
+        # every rank must have produced the same alignment (reduced winners -> identical host walk)
         import hashlib
         digest = hashlib.sha256(repr((res[0], None if res[1] is None else res[1].tolist())).encode()).digest()[:8]
         t = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(torch.int64)

@@ -274,6 +274,13 @@ int  mm_within_plan_create(mm_engine* e, int n_geoms, mm_geometry** geoms,
 int  mm_within_plan_run(mm_within_plan* p, mm_alignlog** logs, int64_t* pose_evals,
                         int64_t* n_unresolved);
 void mm_within_plan_destroy(mm_within_plan* p);
+/* Diagnostics: search set `set` (sets are numbered geometry by geometry, frame by frame) as staged in HBM -- the
+ * centred f64 coordinates, their f32 copy and rho (largest distance from the centre, as the error bounds use it).
+ * The sets are built on the device from the raw contours (k_build_sets); MM_HOST_SETS=1 in the environment selects
+ * the host-side construction instead (the checker).  Returns the set's size (at most cap points are copied), -1 on
+ * error. */
+int64_t mm_within_plan_fetch_set(mm_within_plan* p, int32_t set, double* x64, double* y64, float* x32, float* y32,
+                                 int64_t cap, double* rho);
 
 /* The same search with the candidate axis sharded over `world` ranks (one process per GPU).
  * run() == for every level { level_local; merge over ranks; level_commit }; walk.  Between
@@ -288,6 +295,10 @@ void mm_within_plan_destroy(mm_within_plan* p);
  *                uniform = all near-ties of the slice are one angle value, active = takes part
  *   level_commit ok[j] != 0 -> winner `angle[j]`; 0 -> re-searched on the chain state in walk */
 int  mm_within_plan_set_shard(mm_within_plan* p, int rank, int world);
+/* create + set_shard in one (level 0 is staged once, for the rank's slice) */
+int  mm_within_plan_create_sharded(mm_engine* e, int n_geoms, mm_geometry** geoms,
+                                   double step_deg, double range_deg, int bruteforce, int64_t sample_size,
+                                   int precision, int rank, int world, mm_within_plan** out);
 int  mm_within_plan_dims(mm_within_plan* p, int32_t* n_jobs, int32_t* n_levels, double* tol);
 int  mm_within_plan_level_local(mm_within_plan* p, int level, double* cost, int32_t* uniform,
                                 double* angle, int32_t* idx, int32_t* active);

@@ -31,7 +31,7 @@ EXPORTS = [
     "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
     "mm_plan_create", "mm_plan_create_indexed", "mm_plan_destroy", "mm_plan_run", "mm_plan_run_screen_only", "mm_plan_fetch",
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
-    "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_run", "mm_within_plan_destroy",
+    "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_create_sharded", "mm_within_plan_run", "mm_within_plan_destroy", "mm_within_plan_fetch_set",
     "mm_within_plan_set_shard", "mm_within_plan_dims", "mm_within_plan_level_local", "mm_within_plan_level_commit",
     "mm_within_plan_walk", "mm_within_plan_level_launch", "mm_within_plan_level_export_cost",
     "mm_within_plan_level_export_keys", "mm_within_plan_level_commit_dev", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
@@ -112,6 +112,30 @@ def _close_all_engines():
 atexit.register(_close_all_engines)
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's) but link it by its unversioned name, so when this
+    library is loaded BEFORE torch the loader does not recognise the system runtime as the one torch
+    asks for and maps a second HIP runtime, which then finds no GPU ("No HIP GPUs are available") --
+    and device pointers / streams could not be shared with torch.distributed (RCCL) anyway.  If torch
+    is installed and not yet imported, map its runtime first (by path, without importing torch); our
+    library then binds to it by SONAME and a later `import torch` reuses the same mapping.
+    MM_HIP_RUNTIME=system keeps the system runtime (for processes that never import torch)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("MM_HIP_RUNTIME") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass            # fall back to the system runtime; torch-free use is unaffected
+
+
 def lib():
     """Load the HIP extension; fail loudly if it has not been built."""
     global _lib
@@ -122,6 +146,7 @@ def lib():
             f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (needs hipcc). There is no CPU fallback."
         )
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     P, I, D = C.c_void_p, C.c_int, C.c_double
     I64, I32 = C.c_int64, C.c_int32
@@ -188,6 +213,8 @@ def lib():
     L.mm_align_within.argtypes = [P, I, P, D, D, I, I64, I, I, P, C.POINTER(I64)]
     L.mm_within_plan_create.restype = I
     L.mm_within_plan_create.argtypes = [P, I, P, D, D, I, I64, I, C.POINTER(P)]
+    L.mm_within_plan_create_sharded.restype = I
+    L.mm_within_plan_create_sharded.argtypes = [P, I, P, D, D, I, I64, I, I, I, C.POINTER(P)]
     L.mm_within_plan_run.restype = I
     L.mm_within_plan_run.argtypes = [P, P, C.POINTER(I64), C.POINTER(I64)]
     L.mm_within_plan_destroy.restype = None
@@ -200,6 +227,8 @@ def lib():
     L.mm_within_plan_level_local.argtypes = [P, I, P, P, P, P, P]
     L.mm_within_plan_level_commit.restype = I
     L.mm_within_plan_level_commit.argtypes = [P, I, P, P]
+    L.mm_within_plan_fetch_set.restype = I64
+    L.mm_within_plan_fetch_set.argtypes = [P, I32, P, P, P, P, I64, C.POINTER(D)]
     L.mm_within_plan_level_launch.restype = I
     L.mm_within_plan_level_launch.argtypes = [P, I]
     L.mm_within_plan_level_export_cost.restype = I

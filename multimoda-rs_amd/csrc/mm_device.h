@@ -28,6 +28,18 @@ struct PairDesc {
     double  rho_t;            // largest distance of a target point from the rotation centre
 };
 
+// Source of one search set of the within-pullback search, built on the device from the raw pullback
+// (align_within.rs:173-191: downsample(lumen, S) ++ downsample(catheter, ceil(n_cath * S / len_lumen0)),
+// contour.rs:47-58), centred on the frame's centroid.  Raw pool = xyz triples (f64) as the caller holds them.
+struct SetSrc {
+    int64_t lum_at;           // first lumen point of the frame in the raw pool (point index)
+    int64_t cath_at;          // first catheter point of the frame (unused when cath_take == 0)
+    int32_t lum_len, lum_take;    // points of the contour, points asked for
+    int32_t cath_len, cath_take;
+    int32_t dst_off, n;       // into the point pool; n = min(lum_len, lum_take) + min(cath_len, cath_take)
+    double  cx, cy;           // the frame's centroid
+};
+
 // One workgroup's share: `cnt` consecutive candidates of one pair.
 struct WorkItem {
     int32_t pair, a0, cnt, pad;
@@ -124,6 +136,14 @@ int        nn_queries_per_block();
 int        nn_chunk_points();
 int        nn_span_chunks();
 hipError_t launch_exact_all(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
+// bytes between HBM and pinned host memory by a 256-thread kernel (see k_copy_small: a runtime copy behind a
+// kernel is a 512-thread blit that starves beside another stream's screen launch); 16-byte aligned pointers
+hipError_t launch_copy_small(void* dst, const void* src, size_t bytes, hipStream_t s);
+// search sets built on the device: one workgroup per set; writes the four planes of the point pool and, per
+// set, the largest squared distance from the centre (rho2) and the largest coordinate magnitude before / after
+// centring (scale)
+hipError_t launch_build_sets(const SetSrc* src, int n_sets, const double* raw, float* p32x, float* p32y, double* p64x,
+                             double* p64y, double* rho2, double* scale, hipStream_t s);
 hipError_t launch_shortlist(const BatchDev& b, hipStream_t s);
 hipError_t launch_rescore(const BatchDev& b, int max_na, int max_nbp, int total_candidates, hipStream_t s);
 hipError_t launch_finalize(const BatchDev& b, int use_flags, hipStream_t s);

@@ -67,6 +67,35 @@ int Engine::ensure(Buf& b, size_t bytes, bool host)
     return MM_OK;
 }
 
+int Engine::blob_alloc(void** p, size_t bytes, size_t* cap)
+{
+    bytes = std::max<size_t>(align_up(bytes, 4096), 4096);
+    int best = -1;
+    for (int i = 0; i < (int)blob_cache.size(); ++i)
+        if (blob_cache[i].cap >= bytes && blob_cache[i].cap <= 2 * bytes + (1 << 20) && (best < 0 || blob_cache[i].cap < blob_cache[best].cap)) best = i;
+    if (best >= 0) {
+        *p = blob_cache[best].p; *cap = blob_cache[best].cap;
+        blob_cache.erase(blob_cache.begin() + best);
+        return MM_OK;
+    }
+    MM_HIP(hipMalloc(p, bytes));
+    *cap = bytes;
+    return MM_OK;
+}
+
+void Engine::blob_release(void* p, size_t cap)
+{
+    if (!p) return;
+    if ((int)blob_cache.size() >= kBlobCache) {   // drop the smallest cached block (hipFree synchronises the device)
+        int small = 0;
+        for (int i = 1; i < (int)blob_cache.size(); ++i) if (blob_cache[i].cap < blob_cache[small].cap) small = i;
+        if (blob_cache[small].cap < cap) { (void)hipFree(blob_cache[small].p); blob_cache[small] = Buf{p, cap}; }
+        else (void)hipFree(p);
+        return;
+    }
+    blob_cache.push_back(Buf{p, cap});
+}
+
 int Engine::sync_all()
 {
     MM_HIP(hipStreamSynchronize(stream));
@@ -100,27 +129,48 @@ int Engine::profile_end(hipStream_t stream, double pair_evals, int64_t candidate
 // -------------------------------------------------------------------------------------
 // plan: point pool
 // -------------------------------------------------------------------------------------
-int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_, hipStream_t st)
+// Layout and allocation of the point pool for sets of the given sizes; no data yet.
+int Plan::alloc_pool(Engine* e, const std::vector<int32_t>& lens, bool transient_)
 {
     eng = e;
     transient = transient_;
     stream = transient ? e->aux : e->stream;
-    if (!st) st = stream;
-    const size_t S = sets.size();
+    const size_t S = lens.size();
     set_off.assign(S, 0); set_len.assign(S, 0);
     set_rho.assign(S, 0.0);
     n_points = 0;
     for (size_t s = 0; s < S; ++s) {
-        if (sets[s].n < 0) return set_error(MM_ERR_INVALID, "negative set size");
-        set_off[s] = (int32_t)n_points; set_len[s] = sets[s].n;
-        n_points += sets[s].n;
+        if (lens[s] < 0) return set_error(MM_ERR_INVALID, "negative set size");
+        set_off[s] = (int32_t)n_points; set_len[s] = lens[s];
+        n_points += lens[s];
         if (n_points > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "batch exceeds 2^30 points");
     }
     const size_t n = (size_t)n_points;
-    const size_t o32x = 0, o32y = align_up(o32x + n * 4), o64x = align_up(o32y + n * 4), o64y = align_up(o64x + n * 8);
+    o32x = 0; o32y = align_up(o32x + n * 4); o64x = align_up(o32y + n * 4); o64y = align_up(o64x + n * 8);
     pts_bytes = align_up(o64y + n * 8);
-    int rc = e->ensure(e->host_pts, pts_bytes, true);
-    if (rc) return rc;
+    if (transient) {
+        int rc = e->ensure(e->dev_pts, pts_bytes, false);
+        if (rc) return rc;
+        pts_blob = (unsigned char*)e->dev_pts.p; own_pts = false;
+    } else {
+        int rc = e->blob_alloc((void**)&pts_blob, pts_bytes, &pts_cap);
+        if (rc) return rc;
+        own_pts = true;
+    }
+    dev.p32x = (const float*)(pts_blob + o32x); dev.p32y = (const float*)(pts_blob + o32y);
+    dev.p64x = (const double*)(pts_blob + o64x); dev.p64y = (const double*)(pts_blob + o64y);
+    return MM_OK;
+}
+
+int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_, hipStream_t st)
+{
+    const size_t S = sets.size();
+    std::vector<int32_t> lens(S);
+    for (size_t s = 0; s < S; ++s) lens[s] = sets[s].n;
+    int rc;
+    if ((rc = alloc_pool(e, lens, transient_))) return rc;
+    if (!st) st = stream;
+    if ((rc = e->ensure(e->host_pts, pts_bytes, true))) return rc;
     unsigned char* h = (unsigned char*)e->host_pts.p;
     float *x32 = (float*)(h + o32x), *y32 = (float*)(h + o32y);
     double *x64 = (double*)(h + o64x), *y64 = (double*)(h + o64y);
@@ -136,18 +186,8 @@ int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_
         }
         set_rho[s] = std::sqrt(rho2) * (1.0 + 1e-12);
     }
-    if (transient) {
-        rc = e->ensure(e->dev_pts, pts_bytes, false);
-        if (rc) return rc;
-        pts_blob = (unsigned char*)e->dev_pts.p; own_pts = false;
-    } else {
-        MM_HIP(hipMalloc((void**)&pts_blob, std::max<size_t>(pts_bytes, 256)));
-        own_pts = true;
-    }
     if (pts_bytes) MM_HIP(hipMemcpyAsync(pts_blob, h, pts_bytes, hipMemcpyHostToDevice, st));
     if (!transient) MM_HIP(hipStreamSynchronize(st));
-    dev.p32x = (const float*)(pts_blob + o32x); dev.p32y = (const float*)(pts_blob + o32y);
-    dev.p64x = (const double*)(pts_blob + o64x); dev.p64y = (const double*)(pts_blob + o64y);
     return MM_OK;
 }
 
@@ -341,9 +381,9 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         if (rc) return rc;
         lvl_blob = (unsigned char*)e->dev_lvl.p; own_lvl = false;
     } else if (lvl_bytes > lvl_cap) {
-        if (lvl_blob) { MM_HIP(hipStreamSynchronize(stream)); MM_HIP(hipStreamSynchronize(st)); (void)hipFree(lvl_blob); lvl_blob = nullptr; }
-        MM_HIP(hipMalloc((void**)&lvl_blob, lvl_bytes));
-        lvl_cap = lvl_bytes; own_lvl = true;
+        if (lvl_blob) { MM_HIP(hipStreamSynchronize(stream)); MM_HIP(hipStreamSynchronize(st)); e->blob_release(lvl_blob, lvl_cap); lvl_blob = nullptr; }
+        if ((rc = e->blob_alloc((void**)&lvl_blob, lvl_bytes, &lvl_cap))) return rc;
+        own_lvl = true;
     }
     MM_HIP(hipMemcpyAsync(lvl_blob, h, lvl_in_bytes, hipMemcpyHostToDevice, st));
     if (!transient) MM_HIP(hipStreamSynchronize(st));  // host staging buffer is reused
@@ -431,7 +471,7 @@ int Plan::fetch(BatchResult& out, double* all_costs_plan_order)
 {
     const size_t cost_bytes = (all_costs_plan_order && dev.all_costs) ? (size_t)A * 8 : 0;
     unsigned char* h = (unsigned char*)eng->host_lvl.p;  // sized in stage_level
-    if (P > 0) MM_HIP(hipMemcpyAsync(h, lvl_blob + off_best_cost, res_bytes, hipMemcpyDeviceToHost, stream));
+    if (P > 0) MM_HIP(launch_copy_small(h, lvl_blob + off_best_cost, res_bytes, stream));   // not hipMemcpyAsync: k_copy_small
     if (cost_bytes)
         MM_HIP(hipMemcpyAsync(all_costs_plan_order, dev.all_costs, cost_bytes, hipMemcpyDeviceToHost, stream));
     MM_HIP(hipStreamSynchronize(stream));
@@ -468,8 +508,9 @@ double Plan::angle_of(int p, int32_t idx) const
 
 Plan::~Plan()
 {
-    if (pts_blob && own_pts) (void)hipFree(pts_blob);
-    if (lvl_blob && own_lvl) (void)hipFree(lvl_blob);
+    // callers have synchronised the plan's streams (mm_plan_destroy, mm_within_plan_destroy, run_batch's fetch)
+    if (pts_blob && own_pts) eng->blob_release(pts_blob, pts_cap);
+    if (lvl_blob && own_lvl) eng->blob_release(lvl_blob, lvl_cap);
 }
 
 int run_batch(Engine* e, const std::vector<SetRef>& sets, const std::vector<PairSpec>& pairs, int precision,
@@ -780,7 +821,8 @@ void mm_engine_destroy(mm_engine* h)
     (void)hipSetDevice(e->device);
     (void)e->sync_all();
     for (Engine::Buf* b : {&e->host_pts, &e->host_lvl}) if (b->p) (void)hipHostFree(b->p);
-    for (Engine::Buf* b : {&e->dev_pts, &e->dev_lvl}) if (b->p) (void)hipFree(b->p);
+    for (Engine::Buf* b : {&e->dev_pts, &e->dev_lvl, &e->dev_raw}) if (b->p) (void)hipFree(b->p);
+    for (Engine::Buf& b : e->blob_cache) (void)hipFree(b.p);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->dev_stats) (void)hipFree(e->dev_stats);
     if (e->own_aux) (void)hipStreamDestroy(e->aux);

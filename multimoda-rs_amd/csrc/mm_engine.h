@@ -33,7 +33,16 @@ struct Engine {
     bool own_aux = false;
     Buf host_pts, host_lvl;   // pinned staging: point pool / level (+ results)
     Buf dev_pts, dev_lvl;     // device buffers of transient plans
+    Buf dev_raw;              // raw pullbacks of a within-plan while its search sets are built on the device
     int ensure(Buf& b, size_t bytes, bool host);
+    // Device blobs of resident plans come from a small per-engine cache: hipFree waits for EVERY stream of the
+    // device (a plan closed beside another engine's 30 ms launch stalled its thread for the whole launch), and
+    // a stream of cases asks for the same sizes again and again.  blob_release keeps the block for the next
+    // blob_alloc of a similar size (at most kBlobCache blocks; the rest, and everything at destroy, is freed).
+    static constexpr int kBlobCache = 8;
+    std::vector<Buf> blob_cache;
+    int blob_alloc(void** p, size_t bytes, size_t* cap);
+    void blob_release(void* p, size_t cap);
     int sync_all();                 // both streams
     // grow-only pageable scratch for host-side set construction (refinement grid): a fresh 50 MB
     // std::vector per call costs ~10 ms of zero-fill and page faults
@@ -84,7 +93,8 @@ struct Plan {
     std::vector<int32_t> set_off, set_len;
     std::vector<double> set_rho;   // max distance of a point from the set's centre
     int64_t n_points = 0;
-    unsigned char* pts_blob = nullptr; size_t pts_bytes = 0; bool own_pts = false;
+    unsigned char* pts_blob = nullptr; size_t pts_bytes = 0; bool own_pts = false; size_t pts_cap = 0;
+    size_t o32x = 0, o32y = 0, o64x = 0, o64y = 0;   // planes of the pool inside pts_blob
     // level
     int P = 0, W = 0;
     int64_t A = 0;            // candidates in this plan (sum of slices)
@@ -109,6 +119,9 @@ struct Plan {
     int64_t lb_sparse_total = 0;              // candidates the first bound round scores
     std::vector<WorkItem> host_work_lb;
 
+    // pool layout + allocation for sets of the given sizes, no data (the caller fills it on the device and
+    // sets set_rho); stage_sets = alloc_pool + host conversion + one H2D copy
+    int alloc_pool(Engine* e, const std::vector<int32_t>& lens, bool transient);
     // `st` (nullable -> this->stream): the stream the staging copies go to
     int stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient, hipStream_t st = nullptr);
     int stage_level(const std::vector<PairSpec>& pairs, int precision, int32_t angle_begin, int32_t angle_end,

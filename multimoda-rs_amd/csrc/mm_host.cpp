@@ -277,11 +277,13 @@ struct WithinPlan {
     // device-side exchange (level_launch / export_* / commit_dev): job -> pair of the current level
     std::vector<int32_t> pair_of_job;
     int32_t* d_pair_of_job = nullptr;
-    std::vector<double> h_gcost;
-    std::vector<long long> h_keys;
+    int pof_level = -1;               // level whose map d_pair_of_job holds
 
-    ~WithinPlan() { if (d_pair_of_job) (void)hipFree(d_pair_of_job); }
+    size_t pof_cap = 0;
+    ~WithinPlan() { if (d_pair_of_job) e->blob_release(d_pair_of_job, pof_cap); }   // not hipFree: it waits for the whole device
     int prepare();
+    int build_sets_host(int32_t n_sets);
+    int build_sets_device(int32_t n_sets);
     int level_launch(size_t l);
     int level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
     int level_commit(size_t l, const uint8_t* ok, const double* angle);
@@ -293,6 +295,128 @@ struct WithinPlan {
     int search();
     int walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
 };
+
+// The search sets built on the HOST and uploaded as four planes (the path of round 1; kept behind
+// MM_HOST_SETS=1 as the checker of build_sets_device: tests compare the two pools bit for bit).
+int WithinPlan::build_sets_host(int32_t n_sets)
+{
+    sx.assign((size_t)n_sets, {}); sy.assign((size_t)n_sets, {});
+    std::vector<double> set_scale((size_t)n_sets, 0.0);
+    std::vector<int> set_geom((size_t)n_sets);
+    for (int g = 0; g < n_geoms; ++g)
+        for (int32_t i = 0; i < geoms[g]->n_frames; ++i) set_geom[(size_t)(set_base[g] + i)] = g;
+    {
+        TraceTimer t_sets("prepare: search sets (host)");
+        parallel_for(n_sets, [&](int s) {           // sets are independent: build them over the worker pool
+            const int g = set_geom[(size_t)s];
+            const int32_t i = s - set_base[g];
+            const mm_geometry* G = geoms[g];
+            std::vector<double>&x = sx[(size_t)s], &y = sy[(size_t)s];
+            frame_search_set(G, i, spec[g], x, y);
+            const double cx = G->centroid[3 * i], cy = G->centroid[3 * i + 1];
+            double scale = 0.0;
+            for (size_t k = 0; k < x.size(); ++k) {
+                scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
+                x[k] -= cx; y[k] -= cy;
+                scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
+            }
+            set_scale[(size_t)s] = scale;
+        });
+    }
+    for (int g = 0; g < n_geoms; ++g) {
+        double scale = 0.0;
+        for (int32_t i = 0; i < geoms[g]->n_frames; ++i) scale = std::max(scale, set_scale[(size_t)(set_base[g] + i)]);
+        // chain-state coordinates stay within |frame-0 centroid| + radius: 4x covers it amply
+        eps[g] = std::ldexp(4.0 * scale + 1.0, -42);
+    }
+    std::vector<SetRef> sets(sx.size());
+    for (size_t s = 0; s < sx.size(); ++s) sets[s] = SetRef{sx[s].data(), sy[s].data(), (int32_t)sx[s].size(), 0.0, 0.0};
+    TraceTimer t("prepare: stage sets (host)");
+    return plan.stage_sets(e, sets, /*transient=*/false, e->aux);   // staging: the high-priority side stream
+}
+
+// The search sets built on the DEVICE: the raw contours (xyz f64, as the caller holds them) go up once through
+// pinned staging, k_build_sets writes the four planes of the pool, and 16 bytes per set (rho^2, scale) come back.
+// Everything on the engine's high-priority side stream, so staging the next case does not wait behind another
+// engine's search.
+int WithinPlan::build_sets_device(int32_t n_sets)
+{
+    TraceTimer t_all("prepare: sets on the device");
+    std::vector<SetSrc> src((size_t)n_sets);
+    std::vector<int32_t> lens((size_t)n_sets);
+    std::vector<int64_t> lum_base(n_geoms), cath_base(n_geoms);
+    int64_t raw_pts = 0;
+    for (int g = 0; g < n_geoms; ++g) {
+        const mm_geometry* G = geoms[g];
+        lum_base[g] = raw_pts; raw_pts += G->lumen_off[G->n_frames];
+        const bool hc = spec[g].has_cath && G->cath_off;
+        cath_base[g] = raw_pts; if (hc) raw_pts += G->cath_off[G->n_frames];
+    }
+    for (int g = 0; g < n_geoms; ++g) {
+        const mm_geometry* G = geoms[g];
+        const bool hc = spec[g].has_cath && G->cath_off;
+        for (int32_t i = 0; i < G->n_frames; ++i) {
+            SetSrc& d = src[(size_t)(set_base[g] + i)];
+            const int64_t ll = G->lumen_off[i + 1] - G->lumen_off[i], cl = hc ? G->cath_off[i + 1] - G->cath_off[i] : 0;
+            if (ll < 0 || cl < 0 || ll > INT32_MAX || cl > INT32_MAX || spec[g].lumen > INT32_MAX || spec[g].cath > INT32_MAX)
+                return set_error(MM_ERR_INVALID, "contour too long");
+            d.lum_at = lum_base[g] + G->lumen_off[i];
+            d.cath_at = hc ? cath_base[g] + G->cath_off[i] : 0;
+            d.lum_len = (int32_t)ll; d.lum_take = (int32_t)spec[g].lumen;
+            d.cath_len = (int32_t)cl; d.cath_take = hc ? (int32_t)std::max<int64_t>(spec[g].cath, 0) : 0;
+            d.n = std::min(d.lum_len, d.lum_take) + std::min(d.cath_len, d.cath_take);
+            d.cx = G->centroid[3 * i]; d.cy = G->centroid[3 * i + 1];
+            lens[(size_t)(set_base[g] + i)] = d.n;
+        }
+    }
+    int rc = plan.alloc_pool(e, lens, /*transient=*/false);
+    if (rc) return rc;
+    for (int32_t s = 0; s < n_sets; ++s) src[(size_t)s].dst_off = plan.set_off[(size_t)s];
+
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t raw_bytes = (size_t)raw_pts * 24, o_src = up(raw_bytes), o_out = up(o_src + (size_t)n_sets * sizeof(SetSrc));
+    const size_t total = up(o_out + (size_t)n_sets * 16);
+    if ((rc = e->ensure(e->host_pts, total, true))) return rc;
+    if ((rc = e->ensure(e->dev_raw, total, false))) return rc;
+    unsigned char* h = (unsigned char*)e->host_pts.p;
+    unsigned char* d = (unsigned char*)e->dev_raw.p;
+    {
+        // pageable -> pinned, 1 MiB pieces over the worker pool (the runtime's own pageable path is one thread)
+        struct Piece { const double* from; size_t at, bytes; };
+        std::vector<Piece> pieces;
+        auto add = [&](const double* p, int64_t at_pts, int64_t n_pts) {
+            const size_t bytes = (size_t)n_pts * 24, step = (size_t)1 << 20;
+            for (size_t o = 0; o < bytes; o += step)
+                pieces.push_back(Piece{(const double*)((const unsigned char*)p + o), (size_t)at_pts * 24 + o, std::min(step, bytes - o)});
+        };
+        for (int g = 0; g < n_geoms; ++g) {
+            const mm_geometry* G = geoms[g];
+            add(G->lumen, lum_base[g], G->lumen_off[G->n_frames]);
+            if (spec[g].has_cath && G->cath_off) add(G->cath, cath_base[g], G->cath_off[G->n_frames]);
+        }
+        parallel_for((int)pieces.size(), [&](int k) { std::memcpy(h + pieces[(size_t)k].at, pieces[(size_t)k].from, pieces[(size_t)k].bytes); });
+        std::memcpy(h + o_src, src.data(), (size_t)n_sets * sizeof(SetSrc));
+    }
+    hipStream_t st = e->aux;
+    hipError_t he = hipMemcpyAsync(d, h, o_out, hipMemcpyHostToDevice, st);
+    if (he != hipSuccess) return hip_error(he, "raw pullbacks H2D");
+    double *d_rho2 = (double*)(d + o_out), *d_scale = d_rho2 + n_sets;
+    he = launch_build_sets((const SetSrc*)(d + o_src), n_sets, (const double*)d, (float*)(plan.pts_blob + plan.o32x),
+                           (float*)(plan.pts_blob + plan.o32y), (double*)(plan.pts_blob + plan.o64x),
+                           (double*)(plan.pts_blob + plan.o64y), d_rho2, d_scale, st);
+    if (he != hipSuccess) return hip_error(he, "build_sets kernel launch");
+    he = launch_copy_small(h + o_out, d + o_out, (size_t)n_sets * 16, st);   // not hipMemcpyAsync: see k_copy_small
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) return hip_error(he, "build_sets");
+    const double *h_rho2 = (const double*)(h + o_out), *h_scale = h_rho2 + n_sets;
+    for (int32_t s = 0; s < n_sets; ++s) plan.set_rho[(size_t)s] = std::sqrt(h_rho2[s]) * (1.0 + 1e-12);
+    for (int g = 0; g < n_geoms; ++g) {
+        double scale = 0.0;
+        for (int32_t i = 0; i < geoms[g]->n_frames; ++i) scale = std::max(scale, h_scale[set_base[g] + i]);
+        eps[g] = std::ldexp(4.0 * scale + 1.0, -42);   // chain-state coordinates stay within |frame-0 centroid| + radius
+    }
+    return MM_OK;
+}
 
 int WithinPlan::prepare()
 {
@@ -311,54 +435,19 @@ int WithinPlan::prepare()
 
     // centred search sets of the ORIGINAL frames + per-geometry rounding scale
     set_base.assign(n_geoms + 1, 0); job_base.assign(n_geoms + 1, 0);
-    sx.clear(); sy.clear(); job_geom.clear(); job_frame.clear();
+    job_geom.clear(); job_frame.clear();
     eps.assign(n_geoms, 0.0);
-    {
-        TraceTimer t_sets("prepare: search sets");
-        int32_t n_sets = 0;
-        for (int g = 0; g < n_geoms; ++g) {
-            set_base[g] = n_sets;
-            job_base[g] = (int32_t)job_geom.size();
-            for (int32_t i = 1; i < geoms[g]->n_frames; ++i) { job_geom.push_back(g); job_frame.push_back(i); }
-            n_sets += geoms[g]->n_frames;
-        }
-        sx.assign((size_t)n_sets, {}); sy.assign((size_t)n_sets, {});
-        std::vector<double> set_scale((size_t)n_sets, 0.0);
-        std::vector<int> set_geom((size_t)n_sets);
-        for (int g = 0; g < n_geoms; ++g)
-            for (int32_t i = 0; i < geoms[g]->n_frames; ++i) set_geom[(size_t)(set_base[g] + i)] = g;
-        parallel_for(n_sets, [&](int s) {           // sets are independent: build them over the worker pool
-            const int g = set_geom[(size_t)s];
-            const int32_t i = s - set_base[g];
-            const mm_geometry* G = geoms[g];
-            std::vector<double>&x = sx[(size_t)s], &y = sy[(size_t)s];
-            frame_search_set(G, i, spec[g], x, y);
-            const double cx = G->centroid[3 * i], cy = G->centroid[3 * i + 1];
-            double scale = 0.0;
-            for (size_t k = 0; k < x.size(); ++k) {
-                scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
-                x[k] -= cx; y[k] -= cy;
-                scale = std::max(scale, std::max(std::fabs(x[k]), std::fabs(y[k])));
-            }
-            set_scale[(size_t)s] = scale;
-        });
-        for (int g = 0; g < n_geoms; ++g) {
-            double scale = 0.0;
-            for (int32_t i = 0; i < geoms[g]->n_frames; ++i) scale = std::max(scale, set_scale[(size_t)(set_base[g] + i)]);
-            // chain-state coordinates stay within |frame-0 centroid| + radius: 4x covers it amply
-            eps[g] = std::ldexp(4.0 * scale + 1.0, -42);
-        }
+    int32_t n_sets = 0;
+    for (int g = 0; g < n_geoms; ++g) {
+        set_base[g] = n_sets;
+        job_base[g] = (int32_t)job_geom.size();
+        for (int32_t i = 1; i < geoms[g]->n_frames; ++i) { job_geom.push_back(g); job_frame.push_back(i); }
+        n_sets += geoms[g]->n_frames;
     }
-    set_base[n_geoms] = (int32_t)sx.size();
+    set_base[n_geoms] = n_sets;
     job_base[n_geoms] = (int32_t)job_geom.size();
-
-    std::vector<SetRef> sets(sx.size());
-    for (size_t s = 0; s < sx.size(); ++s) sets[s] = SetRef{sx[s].data(), sy[s].data(), (int32_t)sx[s].size(), 0.0, 0.0};
-    int rc;
-    {
-        TraceTimer t("prepare: stage sets");
-        rc = plan.stage_sets(e, sets, /*transient=*/false, e->aux);   // staging: the high-priority side stream
-    }
+    static const bool host_sets = std::getenv("MM_HOST_SETS") != nullptr;   // the previous host-side construction (checker)
+    int rc = host_sets ? build_sets_host(n_sets) : build_sets_device(n_sets);
     if (rc) return rc;
     // level 0 has no centre: its candidate list, descriptors and tables are known now
     if (level0_ok) {
@@ -420,6 +509,16 @@ int WithinPlan::level_launch(size_t l)
         if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
     }
     if (lvl_active.empty()) return MM_OK;
+    if (world > 1) {   // job -> pair map of the level for the device-side exchange, uploaded ahead of the search
+        pair_of_job.assign((size_t)J, -1);
+        for (size_t k = 0; k < lvl_active.size(); ++k) pair_of_job[(size_t)lvl_active[k]] = (int32_t)k;
+        if (!d_pair_of_job) {
+            if (int arc = e->blob_alloc((void**)&d_pair_of_job, (size_t)std::max(J, 1) * 4, &pof_cap)) return arc;
+        }
+        const hipError_t hc = hipMemcpyAsync(d_pair_of_job, pair_of_job.data(), (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
+        if (hc != hipSuccess) return hip_error(hc, "hipMemcpyAsync(pair_of_job)");
+        pof_level = (int)l;
+    }
     return plan.run(false);
 }
 
@@ -464,15 +563,17 @@ int WithinPlan::level_export_cost(size_t l, double* cost_dev)
     if (!searched) return set_error(MM_ERR_INVALID, "level_export_cost before level_launch");
     const int J = (int)job_geom.size();
     if (J == 0) return MM_OK;
-    pair_of_job.assign((size_t)J, -1);
-    for (size_t k = 0; k < lvl_active.size(); ++k) pair_of_job[(size_t)lvl_active[k]] = (int32_t)k;
-    if (!d_pair_of_job) {
-        const hipError_t he = hipMalloc((void**)&d_pair_of_job, (size_t)J * 4);
-        if (he != hipSuccess) return hip_error(he, "hipMalloc(pair_of_job)");
+    if (pof_level != (int)l || lvl_active.empty()) {   // world == 1 (tests), or a level without active jobs
+        pair_of_job.assign((size_t)J, -1);
+        for (size_t k = 0; k < lvl_active.size(); ++k) pair_of_job[(size_t)lvl_active[k]] = (int32_t)k;
+        if (!d_pair_of_job) {
+            if (int arc = e->blob_alloc((void**)&d_pair_of_job, (size_t)J * 4, &pof_cap)) return arc;
+        }
+        const hipError_t hc = hipMemcpyAsync(d_pair_of_job, pair_of_job.data(), (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
+        if (hc != hipSuccess) return hip_error(hc, "hipMemcpyAsync(pair_of_job)");
+        pof_level = (int)l;
     }
-    hipError_t he = hipMemcpyAsync(d_pair_of_job, pair_of_job.data(), (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
-    if (he != hipSuccess) return hip_error(he, "hipMemcpyAsync(pair_of_job)");
-    he = launch_export_cost(plan.dev, d_pair_of_job, J, cost_dev, plan.stream);
+    const hipError_t he = launch_export_cost(plan.dev, d_pair_of_job, J, cost_dev, plan.stream);
     return he == hipSuccess ? MM_OK : hip_error(he, "export_cost kernel launch");
 }
 
@@ -488,11 +589,17 @@ int WithinPlan::level_commit_dev(size_t l, const double* gcost_dev, const long l
 {
     const int J = (int)job_geom.size();
     if (J == 0) return MM_OK;
-    h_gcost.resize((size_t)J); h_keys.resize((size_t)J * 3);
-    hipError_t he = hipMemcpyAsync(h_gcost.data(), gcost_dev, (size_t)J * 8, hipMemcpyDeviceToHost, plan.stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(h_keys.data(), keys_dev, (size_t)J * 24, hipMemcpyDeviceToHost, plan.stream);
+    // reduced records -> pinned host memory (the engine's level staging buffer: free between stage_level and fetch)
+    const size_t o_keys = ((size_t)J * 8 + 255) / 256 * 256;
+    int rc = e->ensure(e->host_lvl, o_keys + (size_t)J * 24, true);
+    if (rc) return rc;
+    unsigned char* hp = (unsigned char*)e->host_lvl.p;
+    hipError_t he = launch_copy_small(hp, gcost_dev, (size_t)J * 8, plan.stream);
+    if (he == hipSuccess) he = launch_copy_small(hp + o_keys, keys_dev, (size_t)J * 24, plan.stream);
     if (he == hipSuccess) he = hipStreamSynchronize(plan.stream);
     if (he != hipSuccess) return hip_error(he, "exchange records D2H");
+    const double* h_gcost = (const double*)hp;
+    const long long* h_keys = (const long long*)(hp + o_keys);
     std::vector<uint8_t> ok((size_t)J, 1);
     std::vector<double> angle((size_t)J, 0.0);
     for (size_t k = 0; k < lvl_active.size(); ++k) {
@@ -923,12 +1030,21 @@ int mm_align_within(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step
 int mm_within_plan_create(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step_deg, double range_deg,
                           int bruteforce, int64_t sample_size, int precision, mm_within_plan** out)
 {
+    return mm_within_plan_create_sharded(eh, n_geoms, geoms, step_deg, range_deg, bruteforce, sample_size, precision, 0, 1, out);
+}
+
+int mm_within_plan_create_sharded(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step_deg, double range_deg,
+                                  int bruteforce, int64_t sample_size, int precision, int rank, int world,
+                                  mm_within_plan** out)
+{
     Engine* e = reinterpret_cast<Engine*>(eh);
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine/out == NULL");
     *out = nullptr;
     if (n_geoms <= 0 || !geoms) return set_error(MM_ERR_INVALID, "no geometries");
+    if (world <= 0 || rank < 0 || rank >= world) return set_error(MM_ERR_INVALID, "bad shard");
     if (int drc = select_device(e)) return drc;
     WithinPlan* wp = new WithinPlan();
+    wp->rank = rank; wp->world = world;
     wp->e = e; wp->n_geoms = n_geoms; wp->geoms.assign(geoms, geoms + n_geoms);
     wp->step_deg = step_deg; wp->range_deg = range_deg; wp->bruteforce = bruteforce != 0;
     wp->sample_size = sample_size; wp->precision = precision;
@@ -987,6 +1103,24 @@ int mm_within_plan_level_local(mm_within_plan* h, int level, double* cost, int32
     if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
     if (int drc = select_device(wp->e)) return drc;
     return wp->level_local((size_t)level, cost, uniform, angle, idx, active);
+}
+
+int64_t mm_within_plan_fetch_set(mm_within_plan* h, int32_t set, double* x64, double* y64, float* x32, float* y32,
+                                 int64_t cap, double* rho)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || set < 0 || (size_t)set >= wp->plan.set_len.size()) { set_error(MM_ERR_INVALID, "bad set index"); return -1; }
+    if (select_device(wp->e)) return -1;
+    const Plan& pl = wp->plan;
+    const int64_t n = pl.set_len[(size_t)set], o = pl.set_off[(size_t)set], m = std::min<int64_t>(n, cap);
+    if (rho) *rho = pl.set_rho[(size_t)set];
+    hipError_t he = hipSuccess;
+    if (m > 0 && x64) he = hipMemcpy(x64, pl.dev.p64x + o, (size_t)m * 8, hipMemcpyDeviceToHost);
+    if (he == hipSuccess && m > 0 && y64) he = hipMemcpy(y64, pl.dev.p64y + o, (size_t)m * 8, hipMemcpyDeviceToHost);
+    if (he == hipSuccess && m > 0 && x32) he = hipMemcpy(x32, pl.dev.p32x + o, (size_t)m * 4, hipMemcpyDeviceToHost);
+    if (he == hipSuccess && m > 0 && y32) he = hipMemcpy(y32, pl.dev.p32y + o, (size_t)m * 4, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { hip_error(he, "fetch_set"); return -1; }
+    return n;
 }
 
 int mm_within_plan_level_launch(mm_within_plan* h, int level)

@@ -152,8 +152,9 @@ static __device__ __forceinline__ int xcd_work_index(int b, int n)
 // device shortlist queue (count read from *n_work_dev); workgroups stride over them, so
 // every wave terminates whatever the queue length is.
 // -------------------------------------------------------------------------------------
-template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB>
-__global__ void __launch_bounds__(NLI * 16)
+//   MINB   workgroups per CU the register allocation must leave room for (launch bounds)
+template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB, int MINB = 1>
+__global__ void __launch_bounds__(NLI * 16, MINB)
 k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
          int n_work_host, const int* __restrict__ n_work_dev,
          const T* __restrict__ ptx, const T* __restrict__ pty,
@@ -1131,12 +1132,12 @@ size_t lds_bytes_f64(int nbp) { return (size_t)nbp * (16 + 16 + 8) + 16; }
 int max_target_points_f32() { return ((LDS_CAP - 16) / 20) & ~15; }
 int max_target_points_f64() { return ((LDS_CAP - 16) / 40) & ~15; }
 
-template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB>
+template <typename T, int R, int NLI, bool EXACT, bool MULTI_RB, int MINB = 1>
 static hipError_t launch_one(const BatchDev& b, const WorkItem* work, int n_work, const int* n_work_dev,
                              int grid, size_t lds, const T* px, const T* py,
                              const T* cv, const T* sv, T* out, hipStream_t s)
 {
-    auto kern = k_search<T, R, NLI, EXACT, MULTI_RB>;
+    auto kern = k_search<T, R, NLI, EXACT, MULTI_RB, MINB>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1318,6 +1319,19 @@ static hipError_t launch_f64(const BatchDev& b, int max_na, int max_nbp, int gri
     const int nw = FROM_QUEUE ? 0 : b.n_work;
 #define MM_F64(Rv, NLIv, MRB) launch_one<double, Rv, NLIv, true, MRB>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, \
                                                                  b.cos64, b.sin64, b.sq64, s)
+    if constexpr (FROM_QUEUE) {
+        // The re-score of the shortlisted candidates is a few workgroups, often launched while ANOTHER engine's
+        // screen fills the device (a pipelined driver; the between stage beside the next case's search).  The
+        // screen runs 3 workgroups of 4 waves per CU at ~168 VGPRs; whenever one retires, exactly one such slot
+        // per SIMD is free.  A 512-thread, 2-waves-per-SIMD workgroup never fits that hole, and the dispatcher
+        // refills it with the screen's next workgroup: the re-score then waits for the whole 30 ms launch to
+        // drain (measured: 23 us alone, 30-34 ms beside the screen; stream priority does not help, the
+        // workgroup simply does not fit).  So the queue variant has the screen's own footprint: 256 threads,
+        // register budget of 3 workgroups per CU, two row blocks for the larger sets.
+        if (max_na <= 16 * 4) return launch_one<double, 4, 16, true, false, 3>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, b.cos64, b.sin64, b.sq64, s);
+        if (max_na <= 16 * 14) return launch_one<double, 14, 16, true, false, 3>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, b.cos64, b.sin64, b.sq64, s);
+        return launch_one<double, 17, 16, true, true, 3>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, b.cos64, b.sin64, b.sq64, s);
+    }
     if (max_na <= 16 * 4) return MM_F64(4, 16, false);
     if (max_na <= 16 * 14) return MM_F64(14, 16, false);
     if (max_na <= 32 * 9) return MM_F64(9, 32, false);
@@ -1344,6 +1358,85 @@ hipError_t launch_shortlist(const BatchDev& b, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_shortlist, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.sq32, b.flag, b.items, b.n_items);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------
+// Small copies between HBM and pinned host memory as a 256-thread kernel.  Why not hipMemcpyAsync: a copy that
+// follows a kernel on its stream is executed by the runtime as a blit kernel of 512-thread workgroups, and a
+// 2-waves-per-SIMD workgroup is never dispatched while another stream's screen launch keeps every CU at
+// 3 x (1 wave per SIMD, ~168 VGPRs): it waits for the whole 30 ms launch (tools/prio_probe2.hip: k512 12 ms
+// against k256 0.13 ms beside the same launch, whatever the stream priorities).  With a pipelined driver that
+// stalled the result fetch of the between stage and the staging of the next case.  256 threads fit the hole a
+// retiring screen workgroup leaves.  dst/src: device-accessible (HBM or hipHostMalloc), 16-byte aligned.
+// -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_copy_small(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, size_t tail_bytes)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail_bytes)
+        reinterpret_cast<unsigned char*>(dst + n16)[threadIdx.x] = reinterpret_cast<const unsigned char*>(src + n16)[threadIdx.x];
+}
+
+hipError_t launch_copy_small(void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    const size_t n16 = bytes / 16, tail = bytes % 16;
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 64);
+    hipLaunchKernelGGL(k_copy_small, dim3(grid), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16, tail);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------
+// Search sets of the within-pullback search, built from the raw pullback in HBM (SetSrc, mm_device.h).
+// The host path did this per case on the CPU (14 ms for 4 x 512 frames) and uploaded four planes; here the
+// raw contours go up once as they are and one small kernel writes the planes.  Same arithmetic as the host
+// code it replaces, so the pool is bit-identical: index = (i64)((f64)i * ((f64)len / (f64)n)) (contour.rs:51-55),
+// coordinate - centroid in f64, one rounding to f32.
+// -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_build_sets(const SetSrc* __restrict__ src, const double* __restrict__ raw, float* __restrict__ p32x,
+             float* __restrict__ p32y, double* __restrict__ p64x, double* __restrict__ p64y,
+             double* __restrict__ rho2_out, double* __restrict__ scale_out)
+{
+    __shared__ double s_rho[4], s_scale[4];
+    const SetSrc s = src[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int nl = s.lum_len < s.lum_take ? s.lum_len : s.lum_take;
+    const double stride_l = (double)s.lum_len / (double)s.lum_take;
+    const double stride_c = (double)s.cath_len / (double)s.cath_take;
+    double rho2 = 0.0, scale = 0.0;
+    for (int k = tid; k < s.n; k += 256) {
+        long long at;
+        if (k < nl) {
+            at = s.lum_at + (s.lum_len <= s.lum_take ? (long long)k : (long long)((double)k * stride_l));
+        } else {
+            const int kk = k - nl;
+            at = s.cath_at + (s.cath_len <= s.cath_take ? (long long)kk : (long long)((double)kk * stride_c));
+        }
+        double x = raw[3 * at], y = raw[3 * at + 1];
+        scale = fmax(scale, fmax(fabs(x), fabs(y)));
+        x -= s.cx; y -= s.cy;
+        scale = fmax(scale, fmax(fabs(x), fabs(y)));
+        p64x[s.dst_off + k] = x; p64y[s.dst_off + k] = y;
+        p32x[s.dst_off + k] = (float)x; p32y[s.dst_off + k] = (float)y;
+        rho2 = fmax(rho2, x * x + y * y);
+    }
+    rho2 = wave_max(rho2); scale = wave_max(scale);
+    if ((tid & 63) == 0) { s_rho[tid >> 6] = rho2; s_scale[tid >> 6] = scale; }
+    __syncthreads();
+    if (tid == 0) {
+        rho2_out[blockIdx.x] = fmax(fmax(s_rho[0], s_rho[1]), fmax(s_rho[2], s_rho[3]));
+        scale_out[blockIdx.x] = fmax(fmax(s_scale[0], s_scale[1]), fmax(s_scale[2], s_scale[3]));
+    }
+}
+
+hipError_t launch_build_sets(const SetSrc* src, int n_sets, const double* raw, float* p32x, float* p32y, double* p64x,
+                             double* p64y, double* rho2, double* scale, hipStream_t s)
+{
+    if (n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_sets, dim3(n_sets), dim3(256), 0, s, src, raw, p32x, p32y, p64x, p64y, rho2, scale);
     return hipGetLastError();
 }
 

@@ -226,7 +226,9 @@ class WithinPlan:
     Same results as :func:`align_within`; a plan runs once."""
 
     def __init__(self, engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: float, range_deg: float,
-                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32):
+                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32, shard=None):
+        """shard = (rank, world): this plan owns the share [n*rank/world, n*(rank+1)/world) of every candidate
+        list from the start (same as set_shard afterwards, without staging level 0 twice)."""
         self.engine = engine
         self.geoms = list(geoms)
         G = len(self.geoms)
@@ -234,9 +236,11 @@ class WithinPlan:
         self._gptrs = (C.POINTER(N.MMGeometry) * G)(*[C.pointer(s) for s in self._structs])
         self._h = C.c_void_p()
         engine._children.add(self)
-        N.check(N.lib().mm_within_plan_create(engine.handle, G, C.cast(self._gptrs, C.c_void_p), float(step_deg),
-                                              float(range_deg), int(bool(bruteforce)), int(sample_size),
-                                              int(precision), C.byref(self._h)), "mm_within_plan_create")
+        rank, world = (0, 1) if shard is None else (int(shard[0]), int(shard[1]))
+        N.check(N.lib().mm_within_plan_create_sharded(engine.handle, G, C.cast(self._gptrs, C.c_void_p), float(step_deg),
+                                                      float(range_deg), int(bool(bruteforce)), int(sample_size),
+                                                      int(precision), rank, world, C.byref(self._h)),
+                "mm_within_plan_create")
 
     def run(self):
         """Returns (logs per geometry, pose_evals, n_unresolved)."""
@@ -248,6 +252,18 @@ class WithinPlan:
                 "mm_within_plan_run")
         logs = [AlignLogs(b, g.n_frames - 1) for b, g in zip(log_bufs, self.geoms)]
         return logs, int(pe.value), int(nu.value)
+
+    def fetch_set(self, set_index: int):
+        """Diagnostics: search set `set_index` as staged in HBM -> (xy f64 (n,2), xy f32 (n,2), rho)."""
+        rho = C.c_double(0.0)
+        n = N.lib().mm_within_plan_fetch_set(self._h, int(set_index), None, None, None, None, 0, C.byref(rho))
+        if n < 0:
+            raise RuntimeError(N.last_error())
+        a64 = np.zeros((2, int(n)), dtype=np.float64)
+        a32 = np.zeros((2, int(n)), dtype=np.float32)
+        N.lib().mm_within_plan_fetch_set(self._h, int(set_index), N._ptr(a64[0]), N._ptr(a64[1]), N._ptr(a32[0]),
+                                         N._ptr(a32[1]), int(n), C.byref(rho))
+        return a64.T.copy(), a32.T.copy(), rho.value
 
     # -- candidate axis sharded over ranks (one process per GPU) ---------------------------
     def set_shard(self, rank: int, world: int):

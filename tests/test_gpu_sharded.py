@@ -138,3 +138,38 @@ def test_run_sharded_world2_gloo_on_the_gpu(exchange):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "SHARD_WORKER_OK" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------
+# search sets built on the device (k_build_sets) vs the host-side helper (mm_catheter_lumen_vec)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sample_size", [7, 64, 200, 501, 600])
+def test_device_built_search_sets_equal_host_construction(engine, mm, sample_size):
+    """Ragged contours (33..501 points per frame), with and without catheter: every set staged in HBM must hold
+    exactly downsample(lumen, S) ++ downsample(catheter, ceil(n_cath * S / len_lumen0)) minus the frame centroid
+    (align_within.rs:45-59,173-191, contour.rs:47-58), its f32 copy the once-rounded value, rho the largest
+    distance from the centre."""
+    rng = np.random.default_rng(5)
+    lens = [501, 33, 200, 64, 500, 77]
+    def contour(n, k):
+        t = np.sort(rng.uniform(0, 2 * np.pi, n))
+        r = 2.0 + 0.3 * np.cos(3 * t + k)
+        return np.stack([4.4 + 0.05 * k + r * np.cos(t), 4.6 + 0.8 * r * np.sin(t), np.full(n, 0.5 * k)], 1)
+    lum = [contour(n, k) for k, n in enumerate(lens)]
+    from multimoda_rs_amd.geometry import catheter_points
+    cath = [catheter_points(0.5 * k) for k in range(len(lens))]
+    g1 = mm.FlatGeometry.from_frames(lum, catheters=cath, ref_points={0: lum[0][0]})
+    g2 = mm.FlatGeometry.from_frames(lum[::-1], ref_points={0: lum[-1][0]})          # no catheter
+    plan = mm.WithinPlan(engine, [g1, g2], 5.0, 30.0, True, sample_size)
+    s = 0
+    for g in (g1, g2):
+        for i in range(g.n_frames):
+            want = mm.search_set(g, i, sample_size) - g.centroids[i, :2]
+            got64, got32, rho = plan.fetch_set(s)
+            assert got64.shape == want.shape
+            assert np.array_equal(got64, want)
+            assert np.array_equal(got32, want.astype(np.float32))
+            r = float(np.sqrt(np.max(want[:, 0] * want[:, 0] + want[:, 1] * want[:, 1])))
+            assert r <= rho <= r * (1 + 1e-11)
+            s += 1
+    plan.close()
