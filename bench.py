@@ -137,7 +137,7 @@ def committed_traffic(workload, precision):
     (profiles/, tools/gpu_pmc.sh): FETCH_SIZE + WRITE_SIZE in KiB, raw (on gfx950 FETCH_SIZE can
     under-report wide streaming reads by up to 2x; these are dword loads, uncalibrated).  bench.py
     cannot run the profiler itself, so this is null unless a matching profile is committed."""
-    name = {("config3", "fast"): "r1_config3_fast_pmc_summary.csv", ("config3", "f32"): "r1_config3_pmc_summary.csv"}.get(
+    name = {("config3", "fast"): "r2_config3_fast_pmc_summary.csv", ("config3", "f32"): "r1_config3_pmc_summary.csv"}.get(
         (workload, precision))
     path = os.path.join(ROOT, "profiles", name) if name else None
     if not path or not os.path.exists(path):
