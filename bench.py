@@ -436,7 +436,7 @@ def main():
                                   "identical_to_headline_result": same_result(leg),
                                   "roofline": {"bound": "valu-fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
                                                "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
-                                               "kernel": "mm::k_search<double,17,32,true,false>",
+                                               "kernel": "mm::k_search<double,11,16,true,true,3>",
                                                "avg_launch_ms": p64["ms"] / max(p64["launches"], 1)}}
         except Exception as ex:
             extra["f64_exact"] = {"error": f"{type(ex).__name__}: {ex}"}
@@ -500,7 +500,7 @@ def main():
                 "traffic": committed_traffic(args.workload, args.precision),
                 "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
                            "bounded": "mm::k_screen_lb<5, false>",
-                           "f64": "mm::k_search<double,17,32,true,false>"}[args.precision], "launches": prof["launches"],
+                           "f64": "mm::k_search<double,11,16,true,true,3>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "dominant_launch": dominant_launch(launch_ms, launch_pe, peak),
                 "note": "point-set min/max metric: bounded by VALU issue (SURVEY 8(d)), not HBM/MFMA; achieved = ALGORITHMIC "

@@ -1310,6 +1310,17 @@ hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int ca
     return launch_fast_any(b, b.items_lb + 2 * (size_t)cap, 0, b.n_items + 5, cap, max_na, max_nbp, false, s);
 }
 
+// Exact f64 kernel variants.  Every variant is a 256-thread workgroup (one wave per SIMD) with a register budget
+// of three workgroups per CU:
+//  * beside another stream's screen launch only such a workgroup is ever dispatched (3 x 1 wave per SIMD at ~168
+//    VGPRs fill every CU; a 512-thread, 2-waves-per-SIMD workgroup never fits the hole a retiring workgroup
+//    leaves and waited for the whole 30 ms launch: the re-score of the between stage, 23 us alone, took 30-34 ms
+//    in a pipelined driver; stream priority does not help, tools/prio_probe2.hip);
+//  * three independent workgroups per CU run out of phase, so the rotation / epilogue / barriers of one overlap
+//    the distance loop of the others -- the all-f64 search (MM_PRECISION_F64) went from 108.9 ms (512 threads,
+//    R = 17, one workgroup per CU) to 87.1 ms on config3, 0.91 of the measured fp64 issue rate.
+// Sets beyond 16 x 14 points loop over row blocks of 16 x R rows; R in {9, 10, 11} is chosen for the least padding
+// (521 points = 3 x 176).
 template <bool FROM_QUEUE>
 static hipError_t launch_f64(const BatchDev& b, int max_na, int max_nbp, int grid, hipStream_t s)
 {
@@ -1317,26 +1328,20 @@ static hipError_t launch_f64(const BatchDev& b, int max_na, int max_nbp, int gri
     const WorkItem* work = FROM_QUEUE ? b.items : b.work;
     const int* nd = FROM_QUEUE ? b.n_items : nullptr;
     const int nw = FROM_QUEUE ? 0 : b.n_work;
-#define MM_F64(Rv, NLIv, MRB) launch_one<double, Rv, NLIv, true, MRB>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, \
-                                                                 b.cos64, b.sin64, b.sq64, s)
-    if constexpr (FROM_QUEUE) {
-        // The re-score of the shortlisted candidates is a few workgroups, often launched while ANOTHER engine's
-        // screen fills the device (a pipelined driver; the between stage beside the next case's search).  The
-        // screen runs 3 workgroups of 4 waves per CU at ~168 VGPRs; whenever one retires, exactly one such slot
-        // per SIMD is free.  A 512-thread, 2-waves-per-SIMD workgroup never fits that hole, and the dispatcher
-        // refills it with the screen's next workgroup: the re-score then waits for the whole 30 ms launch to
-        // drain (measured: 23 us alone, 30-34 ms beside the screen; stream priority does not help, the
-        // workgroup simply does not fit).  So the queue variant has the screen's own footprint: 256 threads,
-        // register budget of 3 workgroups per CU, two row blocks for the larger sets.
-        if (max_na <= 16 * 4) return launch_one<double, 4, 16, true, false, 3>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, b.cos64, b.sin64, b.sq64, s);
-        if (max_na <= 16 * 14) return launch_one<double, 14, 16, true, false, 3>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, b.cos64, b.sin64, b.sq64, s);
-        return launch_one<double, 17, 16, true, true, 3>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, b.cos64, b.sin64, b.sq64, s);
+#define MM_F64(Rv, MRB) launch_one<double, Rv, 16, true, MRB, 3>(b, work, nw, nd, grid, lds, b.p64x, b.p64y, \
+                                                            b.cos64, b.sin64, b.sq64, s)
+    if (max_na <= 16 * 4) return MM_F64(4, false);
+    if (max_na <= 16 * 11) return MM_F64(11, false);
+    if (max_na <= 16 * 14) return MM_F64(14, false);
+    int best = 11;
+    long best_rows = -1;
+    for (int r = 11; r >= 9; --r) {
+        const long blk = 16L * r, rows = (max_na + blk - 1) / blk * blk;
+        if (best_rows < 0 || rows < best_rows) { best_rows = rows; best = r; }
     }
-    if (max_na <= 16 * 4) return MM_F64(4, 16, false);
-    if (max_na <= 16 * 14) return MM_F64(14, 16, false);
-    if (max_na <= 32 * 9) return MM_F64(9, 32, false);
-    if (max_na <= 32 * 17) return MM_F64(17, 32, false);
-    return MM_F64(16, 32, true);
+    if (best == 9) return MM_F64(9, true);
+    if (best == 10) return MM_F64(10, true);
+    return MM_F64(11, true);
 #undef MM_F64
 }
 
