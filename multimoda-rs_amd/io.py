@@ -337,7 +337,18 @@ def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: 
         rest = sorted((fr for fr in flist if fr.orig not in used), key=lambda fr: fr.orig)
         flist = new + rest
         for i, fr in enumerate(flist):
-            fr.id = i                                              # z stays the frame's own original z
+            fr.id = i
+            # geometry.rs:77-83,106-141: every z of the frame -- points, extras, reference point AND the frame
+            # centroid -- becomes the z of the frame's first lumen point (the centroid's z was the rounded mean
+            # of the points' z until here; ensure_proximal_at_position_zero below hands the centroid z's on to
+            # all points, so leaving the mean in place put a 1e-13 rounding residue into every output z)
+            z = float(fr.lumen[0, 2])
+            fr.lumen[:, 2] = z
+            for k in fr.extras:
+                fr.extras[k][:, 2] = z
+            if fr.ref is not None:
+                fr.ref[2] = z
+            fr.centroid[2] = z
 
     for fr in flist:                                               # build.rs:188-190
         fr.lumen = sort_contour_points(fr.lumen)

@@ -3,7 +3,10 @@ fixtures of the reference's own tests (tests/golden/ivus_rest, ivus_stress, idea
 
 The oracle's behaviour is pinned by the reference's known-answer tests (test_oracle_kat.py);
 the reference itself cannot be built here, so these vectors are "oracle-generated, not
-reference-verified".  Floats are stored as hex strings (bit-exact).  Run:
+reference-verified".  The oracle's INPUT geometries come from tests/refbuild.py, an independent
+restatement of the reference's CSV reader and geometry builder -- not from the product's
+multimoda_rs_amd.io, so a builder bug cannot cancel out (tests/test_refbuild.py compares the two).
+Floats are stored as hex strings (bit-exact).  Run:
     python tests/make_golden.py
 """
 import json
@@ -16,9 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import multimoda_rs_amd as mm            # host-side builder only (no GPU needed)
 from oracle import oracle as orc
-from helpers import to_oracle
+import refbuild                          # independent pure-Python restatement of the reference's reader + builder
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = [
@@ -37,8 +39,7 @@ def hexf(x):
 def main():
     out = {}
     for name, folder, dia, step, rng, brute, ss in CASES:
-        g = mm.build_geometry_from_inputdata(None, os.path.join(GOLD, folder), folder, dia)
-        og = to_oracle(orc, g)
+        og = g = refbuild.oracle_geometry(orc, os.path.join(GOLD, folder), dia, folder)
         logs = orc.align_within_chain(og, step, rng, brute, ss, n_threads=8)
         out[name] = {
             "folder": folder, "diastole": dia, "step_deg": step, "range_deg": rng, "bruteforce": brute,
@@ -49,9 +50,8 @@ def main():
         }
         print(name, g.n_frames, "frames; first rot_deg", logs[0][2])
     # between: rest diastole vs systole after their chains
-    ga = mm.build_geometry_from_inputdata(None, os.path.join(GOLD, "ivus_rest"), "rest", True)
-    gb = mm.build_geometry_from_inputdata(None, os.path.join(GOLD, "ivus_rest"), "rest", False)
-    oa, ob = to_oracle(orc, ga), to_oracle(orc, gb)
+    oa = refbuild.oracle_geometry(orc, os.path.join(GOLD, "ivus_rest"), True, "rest")
+    ob = gb = refbuild.oracle_geometry(orc, os.path.join(GOLD, "ivus_rest"), False, "rest")
     orc.align_within_chain(oa, 1.0, 90.0, False, 500, n_threads=8)
     orc.align_within_chain(ob, 1.0, 90.0, False, 500, n_threads=8)
     best = orc.align_between(oa, ob, 90.0, 0.5, 500, n_threads=8)

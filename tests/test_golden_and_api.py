@@ -60,8 +60,8 @@ def test_builder_ivus_fixtures_and_array_path(mm):
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_reproduces_committed_vectors(mm, oracle, name):
     v = VEC[name]
-    g = mm.build_geometry_from_inputdata(None, os.path.join(GOLD, v["folder"]), v["folder"], v["diastole"])
-    og = to_oracle(oracle, g)
+    import refbuild                                   # oracle inputs come from the independent builder, not the product's
+    og = refbuild.oracle_geometry(oracle, os.path.join(GOLD, v["folder"]), v["diastole"], v["folder"])
     logs = oracle.align_within_chain(og, v["step_deg"], v["range_deg"], v["bruteforce"], v["sample_size"], n_threads=8)
     assert logs == unhex(v["logs"])
     assert [float(np.sum(og.lumen[:, 0])).hex(), float(np.sum(og.lumen[:, 1])).hex()] == v["lumen_sum_hex"]
@@ -240,6 +240,7 @@ def test_config1_example_data_singlepair_matches_oracle(engine, mm, oracle, brut
                                                      engine=engine)
     assert pair.geom_a.n_frames == 20 and pair.geom_b.n_frames == 17 and pair.label == "examples_ivus_rest - examples_ivus_rest"
     for dia, logs in ((True, logs_d), (False, logs_s)):
-        og = to_oracle(oracle, mm.build_geometry_from_inputdata(None, path, "x", dia))
+        import refbuild                               # oracle inputs from the independent builder (tests/refbuild.py)
+        og = refbuild.oracle_geometry(oracle, path, dia, "x")
         assert list(logs) == oracle.align_within_chain(og, 0.5, 90.0, bruteforce, 500, n_threads=8)
     assert len(logs_d) == 19 and len(logs_s) == 16
