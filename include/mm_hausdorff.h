@@ -353,8 +353,8 @@ void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double 
 void mm_frame_rotate(mm_geometry* g, int32_t i, double angle, double cx, double cy);
 
 /* read_contour_data (src/intravascular/io/input.rs:172-194) for the regular case: headerless rows of
- * exactly four plain decimal numbers `frame<delim>x<delim>y<delim>z`, LF or CRLF line ends, the first a
- * non-negative integer below 2^32.  Every number is converted with correct rounding (what Rust's
+ * exactly four plain decimal numbers `frame<delim>x<delim>y<delim>z`, LF or CRLF line ends, the first a u32
+ * written as the reference's u32::from_str takes it (optional '+', decimal digits only, below 2^32).  Every number is converted with correct rounding (what Rust's
  * str::parse::<f64> and the csv crate deliver).  Returns the number of rows written to out (4 doubles
  * each, at most cap rows are stored), or -1 if the text is not of that regular form (quotes, blank or
  * ragged lines, other characters, non-finite values): the caller then reads it row by row, skipping

@@ -883,6 +883,14 @@ int64_t mm_parse_contour_table(const char* text, int64_t len, char delim, double
     int64_t rows = 0;
     while (p < end) {
         double v[4];
+        {   // field 0 is a u32 in the reference (ContourPoint.frame_index): optional '+', decimal digits, nothing else
+            // ("1.0", "1e0", "-0" do not deserialise there); anything else is left to the row reader
+            const char* q = p;
+            if (q < end && *q == '+') ++q;
+            const char* d0 = q;
+            while (q < end && *q >= '0' && *q <= '9') ++q;
+            if (q == d0 || q >= end || *q != delim) return -1;
+        }
         for (int f = 0; f < 4; ++f) {
             p = parse_decimal(p, end, &v[f]);
             if (!p || !std::isfinite(v[f])) return -1;

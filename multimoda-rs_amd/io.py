@@ -12,6 +12,7 @@ from __future__ import annotations
 import csv
 import math
 import os
+import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -47,6 +48,7 @@ class InputData:
     calcification: Optional[np.ndarray] = None
     sidebranch: Optional[np.ndarray] = None
     record: Optional[List[Record]] = None
+    lumen_aortic: Optional[np.ndarray] = None  # (N,) bool: ContourPoint.aortic of the lumen rows (optional 5th CSV column)
 
 
 def _as_points4(arr, name: str) -> Optional[np.ndarray]:
@@ -113,63 +115,74 @@ def _read_numeric_table_native(path: str, delim: str) -> Optional[np.ndarray]:
 
 
 def _read_numeric_table(path: str, delim: str) -> Optional[np.ndarray]:
-    """Fast path of read_contour_data for the regular case -- every line is exactly four plain numbers,
-    the first a non-negative integer.  Same values as the row-by-row reader (both parse with correctly
-    rounded strtod); anything irregular returns None and the robust reader decides row by row."""
-    native = _read_numeric_table_native(path, delim)
-    if native is not None:
-        return native
-    with open(path, "r", newline="") as f:
-        text = f.read()
-    if not text or '"' in text:
+    """Fast path of read_contour_data for the regular case -- every line is exactly four plain numbers, the
+    first a u32 written in digits only (native parser, ``mm_parse_contour_table``).  Anything irregular returns
+    None and the row reader decides record by record, like the reference."""
+    return _read_numeric_table_native(path, delim)
+
+
+# Rust's grammars for the two field types of ContourPoint (contour_point.rs:55-68): u32::from_str takes an
+# optional '+' and decimal digits; f64::from_str takes [+-] digits [. digits] [e [+-] digits] (either digit
+# run may be empty, not both) or inf / infinity / nan in any case.  No surrounding blanks, no underscores --
+# Python's int() / float() accept both, so the fields are checked before they are converted.
+_RE_U32 = re.compile(r"^\+?[0-9]+$")
+_RE_F64 = re.compile(r"^[+-]?(?:(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?|[iI][nN][fF](?:[iI][nN][iI][tT][yY])?|[nN][aA][nN])$")
+
+
+def _parse_contour_row(rec):
+    """One headerless record -> (frame, x, y, z, aortic) as serde deserialises ContourPoint from it, or None
+    where the reference skips the row ("Skipping invalid record", input.rs:186-190): fewer than four fields, a
+    frame index that is not a u32, a coordinate that is not an f64, or a fifth field that is not true / false."""
+    if len(rec) < 4:
         return None
-    if "\r" in text:                                   # CRLF files: the csv crate drops the \r as well
-        if text.count("\r") != text.count("\r\n"):
+    if not _RE_U32.match(rec[0]):
+        return None
+    fi = int(rec[0])
+    if fi > 0xFFFFFFFF:
+        return None
+    for v in rec[1:4]:
+        if not _RE_F64.match(v):
             return None
-        text = text.replace("\r\n", "\n")
-    lines = text.count("\n") + (0 if text.endswith("\n") else 1)
-    if text.count(delim) != 3 * lines:
-        return None
-    try:
-        flat = np.fromstring(text.replace("\n", delim), sep=delim, dtype=np.float64)
-    except (ValueError, DeprecationWarning):
-        return None
-    if flat.size != 4 * lines or not np.isfinite(flat).all():
-        return None
-    arr = flat.reshape(lines, 4)
-    fi = arr[:, 0]
-    if (fi < 0).any() or (fi != np.floor(fi)).any() or (fi > 4294967295.0).any():
-        return None
-    return arr
+    aortic = False
+    if len(rec) >= 5:
+        if rec[4] not in ("true", "false"):
+            return None
+        aortic = rec[4] == "true"
+    return float(fi), float(rec[1]), float(rec[2]), float(rec[3]), aortic
 
 
-def read_contour_data(path: str) -> np.ndarray:
-    """input.rs:172-194: headerless ``frame,x,y,z`` rows; invalid rows are skipped."""
+def read_contour_data(path: str, with_aortic: bool = False):
+    """input.rs:172-194: headerless ``frame,x,y,z[,aortic]`` rows; invalid rows are skipped.
+    Returns the (N, 4) array, with_aortic=True: (array, (N,) bool flags of the optional fifth column)."""
     delim = _detect_delimiter(path)
     fast = _read_numeric_table(path, delim)
     if fast is not None:
-        return fast
-    rows = []
+        return (fast, np.zeros(fast.shape[0], dtype=bool)) if with_aortic else fast
+    rows, flags = [], []
     with open(path, "r", newline="") as f:
         for rec in csv.reader(f, delimiter=delim):
-            try:
-                if len(rec) < 4:
-                    raise ValueError
-                fi = int(rec[0])
-                if fi < 0:
-                    raise ValueError
-                rows.append((float(fi), float(rec[1]), float(rec[2]), float(rec[3])))
-            except ValueError:
-                continue
-    return np.array(rows, dtype=np.float64).reshape(-1, 4)
+            if not rec:
+                continue                                   # the csv crate skips empty lines
+            r = _parse_contour_row(rec)
+            if r is not None:
+                rows.append(r[:4]); flags.append(r[4])
+    arr = np.array(rows, dtype=np.float64).reshape(-1, 4)
+    return (arr, np.array(flags, dtype=bool)) if with_aortic else arr
 
 
 def read_reference_point(path: str) -> np.ndarray:
-    """input.rs:213-233: the first record; an empty file is an error."""
-    pts = read_contour_data(path)
-    if pts.shape[0] == 0:
-        raise RuntimeError(f"reference-point file {path!r} was empty — this data is required")
-    return pts[0].copy()
+    """input.rs:213-233: the FIRST record; an empty file is an error, and so is a first record that does not
+    deserialise ("failed to deserialize first reference-point record") -- it is not skipped."""
+    delim = _detect_delimiter(path)
+    with open(path, "r", newline="") as f:
+        for rec in csv.reader(f, delimiter=delim):
+            if not rec:
+                continue
+            r = _parse_contour_row(rec)
+            if r is None:
+                raise RuntimeError(f"failed to deserialize first reference-point record of {path!r}")
+            return np.array(r[:4], dtype=np.float64)
+    raise RuntimeError(f"reference-point file {path!r} was empty — this data is required")
 
 
 def read_records(path: str) -> List[Record]:
@@ -207,9 +220,10 @@ def process_directory(path: str, diastole: bool, label: str) -> InputData:
     if not os.path.exists(rec_path):
         rec_path = os.path.join(path, RECORD_FILE_NAME_ALT)
     record = read_records(rec_path) if os.path.exists(rec_path) else None
-    return InputData(lumen=read_contour_data(contours_path), ref_point=read_reference_point(ref_path),
+    lumen, aortic = read_contour_data(contours_path, with_aortic=True)
+    return InputData(lumen=lumen, ref_point=read_reference_point(ref_path),
                      diastole=diastole, label=label, eem=optional("eem"), calcification=optional("calcium"),
-                     sidebranch=optional("branch"), record=record)
+                     sidebranch=optional("branch"), record=record, lumen_aortic=aortic if aortic.any() else None)
 
 
 # ---------------------------------------------------------------------------------------
@@ -226,18 +240,23 @@ def sort_contour_points(points: np.ndarray) -> np.ndarray:
         out = np.ascontiguousarray(points, dtype=np.float64).copy()
         N.check(N.lib().mm_sort_contour_points(N._ptr(out), n), "sort_contour_points")
         return out
+    return points[sort_contour_order(points)]
+
+
+def sort_contour_order(points: np.ndarray) -> np.ndarray:
+    """The permutation ``sort_contour_points`` applies (new position -> old index), pure Python."""
+    n = points.shape[0]
     sx = sy = 0.0
     for p in points:                                   # fold((0,0), |(sx,sy),p| (sx+p.x, sy+p.y))
         sx += float(p[0]); sy += float(p[1])
     cx, cy = sx / float(n), sy / float(n)
     keys = [math.atan2(float(p[1]) - cy, float(p[0]) - cx) for p in points]
     order = sorted(range(n), key=keys.__getitem__)     # stable, like slice::sort_by
-    pts = points[order]
     best = 0
     for i in range(n):                                 # Iterator::max_by keeps the LAST maximum
-        if pts[i, 1] >= pts[best, 1]:
+        if points[order[i], 1] >= points[order[best], 1]:
             best = i
-    return np.concatenate([pts[best:], pts[:best]], axis=0)
+    return np.array(order[best:] + order[:best], dtype=np.int64)
 
 
 def create_catheter_points(frame_z: Dict[int, float], image_center, radius: float, n_points: int) -> Dict[int, np.ndarray]:
@@ -266,6 +285,7 @@ class _Frame:
     ref: Optional[List[float]] = None
     aortic: Optional[float] = None
     pulmonary: Optional[float] = None
+    lumen_aortic: Optional[np.ndarray] = None      # per-point ContourPoint.aortic read from the file (rare)
 
 
 def _group_by_frame(arr: np.ndarray) -> Dict[int, np.ndarray]:
@@ -303,10 +323,16 @@ def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: 
             meas[r.frame] = (r.measurement_1, r.measurement_2)
 
     frames: Dict[int, _Frame] = {}
+    flags = None
+    if d.lumen_aortic is not None and np.any(d.lumen_aortic):      # per-point aortic flags of the optional 5th column
+        tagged = np.concatenate([d.lumen[:, :1], np.asarray(d.lumen_aortic, dtype=np.float64).reshape(-1, 1),
+                                 np.zeros((d.lumen.shape[0], 2))], axis=1)
+        flags = {o: v[:, 0] != 0.0 for o, v in _group_by_frame(tagged).items()}
     for orig, pts in sorted(_group_by_frame(d.lumen).items()):     # build.rs:74-129
         fid = mapping[orig]
         m = meas.get(orig, (None, None))
-        fr = _Frame(id=fid, orig=orig, lumen=pts, centroid=list(contour_centroid(pts)), aortic=m[0], pulmonary=m[1])
+        fr = _Frame(id=fid, orig=orig, lumen=pts, centroid=list(contour_centroid(pts)), aortic=m[0], pulmonary=m[1],
+                    lumen_aortic=None if flags is None else flags[orig])
         if mapping.get(ref_frame) == fid:
             fr.ref = [float(d.ref_point[1]), float(d.ref_point[2]), float(d.ref_point[3])]
         frames[fid] = fr
@@ -351,7 +377,12 @@ def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: 
             fr.centroid[2] = z
 
     for fr in flist:                                               # build.rs:188-190
-        fr.lumen = sort_contour_points(fr.lumen)
+        if fr.lumen_aortic is not None:
+            order = sort_contour_order(fr.lumen)
+            fr.lumen_aortic = fr.lumen_aortic[order]
+            fr.lumen = np.ascontiguousarray(fr.lumen[order])
+        else:
+            fr.lumen = sort_contour_points(fr.lumen)
         for k in list(fr.extras):
             fr.extras[k] = sort_contour_points(fr.extras[k])
 
@@ -403,6 +434,9 @@ def _to_flat(flist: Sequence[_Frame], label: str) -> FlatGeometry:
         g.extra_off = off
         g.extra = np.ascontiguousarray(np.concatenate(chunks, axis=0))
     g.meta["extra_counts"] = counts
+    if any(fr.lumen_aortic is not None and fr.lumen_aortic.any() for fr in flist):
+        g.meta["lumen_aortic"] = np.concatenate([fr.lumen_aortic if fr.lumen_aortic is not None
+                                                 else np.zeros(fr.lumen.shape[0], dtype=bool) for fr in flist])
     g.meta["aortic_thickness"] = [fr.aortic for fr in flist]
     g.meta["pulmonary_thickness"] = [fr.pulmonary for fr in flist]
     return g

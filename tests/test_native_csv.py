@@ -89,3 +89,57 @@ def test_empty_file_and_read_contour_data_dispatch(io, tmp_path):
     assert io.read_contour_data(_write(tmp_path, "", "e.csv")).shape == (0, 4)
     a = io.read_contour_data(_write(tmp_path, "3\t1.25\t-2.5\t7\r\n4\t0.1\t0.2\t0.3", "t.csv"))
     assert np.array_equal(a, np.array([[3.0, 1.25, -2.5, 7.0], [4.0, 0.1, 0.2, 0.3]]))
+
+
+# ---------------------------------------------------------------------------------------
+# the rows the reference's csv + serde reader skips (ContourPoint { frame_index: u32, x, y, z: f64, aortic: bool })
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("row", ["1.0,2,3,4", "1e0,2,3,4", "-0,2,3,4", "1_0,2,3,4", " 2,2,3,4", "2 ,2,3,4", "1,1_0,3,4",
+                                 "1, 2,3,4", "1,2,3,4abc", "1,2,3,0x10", "1,2,3", "1,2,3,4,maybe", "1,2,3,4,True",
+                                 "4294967296,2,3,4", "1,,3,4", "1,e5,3,4", "1,.,3,4"])
+def test_rows_the_reference_skips_are_skipped(io, tmp_path, row):
+    text = "7,1.5,2.5,3.5\n" + row + "\n8,4.5,5.5,6.5\n"
+    assert io._read_numeric_table_native(_write(tmp_path, text), ",") is None          # not the regular form
+    got = io.read_contour_data(_write(tmp_path, text, "r.csv"))
+    assert np.array_equal(got, np.array([[7.0, 1.5, 2.5, 3.5], [8.0, 4.5, 5.5, 6.5]]))
+
+
+@pytest.mark.parametrize("row,exp", [("+5,1,2,3", [5.0, 1.0, 2.0, 3.0]), ("5,+1,.5,5.", [5.0, 1.0, 0.5, 5.0]),
+                                     ("5,1E2,-2e-1,3", [5.0, 100.0, -0.2, 3.0]), ("5,inf,2,3", [5.0, np.inf, 2.0, 3.0]),
+                                     ("5,1,2,3,true", [5.0, 1.0, 2.0, 3.0]), ("5,1,2,3,false", [5.0, 1.0, 2.0, 3.0])])
+def test_rows_the_reference_accepts_are_kept(io, tmp_path, row, exp):
+    got = io.read_contour_data(_write(tmp_path, "7,1.5,2.5,3.5\n" + row + "\n"))
+    assert got.shape == (2, 4) and np.array_equal(got[1], np.array(exp))
+
+
+def test_fifth_column_is_the_aortic_flag(io, tmp_path):
+    arr, flags = io.read_contour_data(_write(tmp_path, "1,1,2,3,true\n1,2,3,4,false\n1,3,4,5\n"), with_aortic=True)
+    assert arr.shape == (3, 4) and flags.tolist() == [True, False, False]
+
+
+def test_reference_point_first_record_must_parse(io, tmp_path):
+    with pytest.raises(RuntimeError, match="failed to deserialize first reference-point record"):
+        io.read_reference_point(_write(tmp_path, "x,1,2,3\n5,1,2,3\n"))
+    with pytest.raises(RuntimeError, match="was empty"):
+        io.read_reference_point(_write(tmp_path, "", "e.csv"))
+    assert io.read_reference_point(_write(tmp_path, "5,1,2,3\nx,1,2,3\n", "ok.csv")).tolist() == [5.0, 1.0, 2.0, 3.0]
+
+
+def test_aortic_flags_follow_their_points_through_the_builder(io, tmp_path):
+    """Per-point flags of the fifth column stay attached to their points through grouping and
+    sort_contour_points (contour.rs:368-405)."""
+    import math
+    d = tmp_path / "case"
+    d.mkdir()
+    rows = []
+    for f in (3, 4):
+        for k in range(12):
+            a = 2 * math.pi * k / 12
+            x, y = 4.5 + 2 * math.cos(a), 4.5 + 1.5 * math.sin(a)
+            rows.append(f"{f},{x!r},{y!r},{0.5 * f},{'true' if x > 4.5 else 'false'}")
+    (d / "diastolic_contours.csv").write_text("\n".join(rows) + "\n")
+    (d / "diastolic_reference_points.csv").write_text("3,6.5,4.5,1.5\n")
+    g = io.build_geometry_from_inputdata(None, str(d), "t", True)
+    fl = g.meta["lumen_aortic"]
+    assert fl.shape[0] == g.lumen.shape[0] == 24
+    assert np.array_equal(fl, g.lumen[:, 0] > 4.5)
