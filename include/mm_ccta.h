@@ -10,6 +10,8 @@
  *   src/ccta/adjust_mesh/scale_coronary.rs:133-183  find_region_points
  *   src/ccta/adjust_mesh/scale_coronary.rs:188-216  symmetric_nn_distance
  *   src/ccta/adjust_mesh/scale_coronary.rs:218-261  centerline_based_diameter_morphing
+ *   src/ccta/adjust_mesh/scale_coronary.rs:263-340  find_points_by_cl_region_rs, find_cl_points_in_range
+ *   src/ccta/adjust_mesh/scale_coronary.rs:342-409  clean_up_non_section_points
  * Python entry points that bind them: src/ccta/binding/ccta_py.rs:263-481
  * (adjust_diameter_centerline_morphing_simple, find_proximal_distal_scaling, find_aortic_scaling,
  * find_aortic_wall_scaling), wrapped by multimodars/ccta/scaling.py.
@@ -59,6 +61,23 @@ int     mm_diameter_optimization(mm_engine* e, const double* anomalous_xyz, int6
 /* centerline_based_wall_diameter_optimization (:8-63), host f64 */
 int     mm_wall_diameter_optimization(const mm_clpoint* cl, int64_t ncl, const double ref_pt[3],
                                       const double* aortic_xyz, int64_t na, double* out);
+
+/* clean_up_non_section_points (:342-409; Python: clean_outlier_points, ccta_py.rs:345-358): for every point of
+ * `cleanup`, the neighbours within neighborhood_radius among the reference points and among the other cleanup
+ * points are counted on the device (exact f64, |q - p|^2 <= r^2 like rstar's locate_within_distance);
+ * to_reference[i] = 1 where ref / (ref + self) >= min_neighbor_ratio: the point joins the reference set
+ * (appended in input order), 0: it stays. */
+int     mm_clean_outlier_points(mm_engine* e, const double* cleanup_xyz, int64_t nc, const double* reference_xyz,
+                                int64_t nr, double neighborhood_radius, double min_neighbor_ratio,
+                                uint8_t* to_reference);
+/* find_points_by_cl_region_rs (:263-312; Python: find_points_by_cl_region, ccta_py.rs:304-319).  cl_frame_index
+ * (nullable -> 0, 1, 2, ...) = contour_point.frame_index of every centerline point.  label[i]:
+ *   0 proximal, 1 distal, 2 between (anomalous section), 3 proximal moved to between by the first clean-up,
+ *   4 distal moved to between by the second.  The reference's three vectors are: proximal = labels 0 in input
+ *   order; distal = labels 1 in input order; between = labels 2 in input order, then 3 in input order, then 4. */
+int     mm_find_points_by_cl_region(mm_engine* e, const mm_clpoint* cl, const uint32_t* cl_frame_index, int64_t ncl,
+                                    const double* frame_centroids_xyz, int64_t n_frames, const double* points_xyz,
+                                    int64_t n, uint8_t* label);
 
 #ifdef __cplusplus
 }

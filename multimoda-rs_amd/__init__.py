@@ -23,8 +23,9 @@ from .centerline import (Centerline, align_combined, align_manual, align_three_p
                          preprocess_centerline)
 from . import centerline
 from . import ccta
-from .ccta import (adjust_diameter_centerline_morphing_simple, find_aorta_scaling, find_aortic_scaling,
-                   find_aortic_wall_scaling, find_distal_and_proximal_scaling, find_proximal_distal_scaling)
+from .ccta import (adjust_diameter_centerline_morphing_simple, clean_outlier_points, find_aorta_scaling,
+                   find_aortic_scaling, find_aortic_wall_scaling, find_distal_and_proximal_scaling,
+                   find_points_by_cl_region, find_proximal_distal_scaling)
 from .convert import numpy_to_geometry, to_array
 from .export import to_obj
 from . import export
@@ -46,6 +47,7 @@ __all__ = [
     "align_combined", "centerline",
     "ccta", "adjust_diameter_centerline_morphing_simple", "find_proximal_distal_scaling", "find_aortic_scaling",
     "find_aortic_wall_scaling", "find_distal_and_proximal_scaling", "find_aorta_scaling",
+    "find_points_by_cl_region", "clean_outlier_points",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
     "MM_PRECISION_F32", "MM_PRECISION_F32_BOUNDED", "MM_PRECISION_F32_FAST", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

@@ -69,6 +69,7 @@ class MMGeometry(C.Structure):
 EXPORTS_CCTA = [
     "mm_nn_min_sq_batch", "mm_symmetric_nn_distance", "mm_diameter_morphing", "mm_find_region_points",
     "mm_aortic_diameter_optimization", "mm_diameter_optimization", "mm_wall_diameter_optimization",
+    "mm_clean_outlier_points", "mm_find_points_by_cl_region",
 ]
 
 
@@ -290,6 +291,10 @@ def lib():
     L.mm_aortic_diameter_optimization.argtypes = [P, P, I64, P, I64, P, I64, C.POINTER(D), P]
     L.mm_diameter_optimization.restype = I
     L.mm_diameter_optimization.argtypes = [P, P, I64, I64, I64, P, I64, P, I64, P, I64, C.POINTER(D), C.POINTER(D)]
+    L.mm_clean_outlier_points.restype = I
+    L.mm_clean_outlier_points.argtypes = [P, P, I64, P, I64, D, D, P]
+    L.mm_find_points_by_cl_region.restype = I
+    L.mm_find_points_by_cl_region.argtypes = [P, P, P, I64, P, I64, P, I64, P]
     L.mm_wall_diameter_optimization.restype = I
     L.mm_wall_diameter_optimization.argtypes = [P, I64, P, P, I64, C.POINTER(D)]
     _lib = L

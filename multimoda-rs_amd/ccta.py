@@ -175,3 +175,39 @@ def find_aortic_wall_scaling(geometry_or_centerline, cl_aorta=None, results=None
     if ref_point is None:
         raise ValueError("No coronary reference point found")
     return find_aortic_wall_scaling_raw(cl_aorta, ref_point, results["aorta_points"])
+
+
+def clean_outlier_points(points_to_cleanup, reference_points, neighborhood_radius: float, min_neigbor_ratio: float,
+                         engine: Optional[N.Engine] = None):
+    """ccta_py.rs:345-358 -> ``clean_up_non_section_points`` (scale_coronary.rs:342-409): a point of
+    ``points_to_cleanup`` most of whose neighbours (within ``neighborhood_radius``) are reference points joins
+    the reference set.  Returns (cleaned points, reference points + the moved ones in input order).  The
+    neighbour counts run on the device in exact f64."""
+    c, r = _p3(points_to_cleanup), _p3(reference_points)
+    mv = np.zeros(c.shape[0], dtype=np.uint8)
+    N.check(N.lib().mm_clean_outlier_points(_engine(engine).handle, N._ptr(c), c.shape[0], N._ptr(r), r.shape[0],
+                                            float(neighborhood_radius), float(min_neigbor_ratio), N._ptr(mv)),
+            "clean_outlier_points")
+    return c[mv == 0].copy(), np.concatenate([r, c[mv == 1]], axis=0)
+
+
+def find_points_by_cl_region(centerline: Centerline, frames, points, engine: Optional[N.Engine] = None,
+                             cl_frame_index=None, return_labels: bool = False):
+    """ccta_py.rs:304-319 -> ``find_points_by_cl_region_rs`` (scale_coronary.rs:263-312): the points whose
+    closest centerline point lies within the imaged section (within the mean frame spacing of a frame
+    centroid) are ``between``; the rest is proximal or distal of the last frame's centroid; two density
+    clean-ups then move stray proximal / distal points into ``between``.  ``frames``: a FlatGeometry (its
+    frame centroids are used) or an (F, 3) array of centroids.  Returns (proximal, distal, between) as
+    (n, 3) arrays in the reference's order."""
+    cen = frames.centroids if isinstance(frames, G.FlatGeometry) else np.asarray(frames, dtype=np.float64)
+    cen = np.ascontiguousarray(cen.reshape(-1, 3))
+    p = _p3(points)
+    fi = None if cl_frame_index is None else np.ascontiguousarray(cl_frame_index, dtype=np.uint32)
+    if fi is not None and fi.shape[0] != len(centerline):
+        raise ValueError("cl_frame_index: one entry per centerline point")
+    lab = np.zeros(p.shape[0], dtype=np.uint8)
+    N.check(N.lib().mm_find_points_by_cl_region(_engine(engine).handle, N._ptr(centerline.points), N._ptr(fi),
+                                                len(centerline), N._ptr(cen), cen.shape[0], N._ptr(p), p.shape[0],
+                                                N._ptr(lab)), "find_points_by_cl_region")
+    out = (p[lab == 0].copy(), p[lab == 1].copy(), np.concatenate([p[lab == 2], p[lab == 3], p[lab == 4]], axis=0))
+    return out + (lab,) if return_labels else out

@@ -450,6 +450,143 @@ int region_points(Engine* e, const double* an, int64_t n, const double* ref, int
     return MM_OK;
 }
 
+// ---- neighbour counts within a radius (clean_up_non_section_points, scale_coronary.rs:342-409) ------------
+// counts[k][i] = #{p in sets[pr[k][1]] : |q_i - p|^2 <= r2} for every query q_i of sets[pr[k][0]], exact f64 on
+// the device (k_nn3_count).  Large sets are staged in slab order and only the (query block, chunk) combinations
+// whose bounding boxes come within the radius are launched; a count does not depend on the order.
+int radius_counts(Engine* e, const std::vector<Set3>& sets, const std::vector<std::array<int32_t, 2>>& pr, double r2,
+                  std::vector<std::vector<uint32_t>>& counts)
+{
+    counts.assign(pr.size(), {});
+    const size_t S = sets.size();
+    std::vector<int64_t> soff(S + 1, 0);
+    for (size_t s = 0; s < S; ++s) soff[s + 1] = soff[s] + sets[s].n;
+    const int64_t npts = soff.back();
+    const int qpb = nn_queries_per_block(), ch = nn_chunk_points();
+    constexpr int64_t kSortMin = 4096;
+    std::vector<std::vector<int32_t>> perms(S);
+    parallel_for((int)S, [&](int s) { if (sets[(size_t)s].n >= kSortMin) slab_order(sets[(size_t)s], perms[(size_t)s]); });
+    std::vector<int64_t> perm_off(S + 1, 0);
+    for (size_t s = 0; s < S; ++s) perm_off[s + 1] = perm_off[s] + (int64_t)perms[s].size();
+
+    std::vector<NnPairH> hp;
+    std::vector<int> owner;
+    int64_t nout = 0;
+    for (size_t k = 0; k < pr.size(); ++k) {
+        const int32_t q = pr[k][0], p = pr[k][1];
+        if (q < 0 || p < 0 || (size_t)q >= S || (size_t)p >= S) return set_error(MM_ERR_INVALID, "radius counts: set index out of range");
+        counts[k].assign((size_t)sets[(size_t)q].n, 0u);
+        if (sets[(size_t)q].n == 0 || sets[(size_t)p].n == 0) continue;
+        hp.push_back(NnPairH{(int32_t)soff[(size_t)q], (int32_t)sets[(size_t)q].n, (int32_t)soff[(size_t)p], (int32_t)sets[(size_t)p].n,
+                             (int32_t)nout, perms[(size_t)q].empty() ? -1 : (int32_t)perm_off[(size_t)q]});
+        owner.push_back((int)k);
+        nout += sets[(size_t)q].n;
+    }
+    if (hp.empty()) return MM_OK;
+    if (npts > (int64_t)1 << 30 || nout > (int64_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "radius counts: batch exceeds 2^30 points");
+
+    // staged points (slab order where sorted) + bounding boxes of groups of ch points (ch is a multiple of qpb)
+    const size_t o_x = 0, o_y = up256((size_t)npts * 8), o_z = up256(o_y + (size_t)npts * 8);
+    const size_t o_perm = up256(o_z + (size_t)npts * 8), o_pairs = up256(o_perm + (size_t)perm_off.back() * 4);
+    int rc = e->ensure(e->host_pts, o_pairs, true);
+    if (rc) return rc;
+    unsigned char* h = (unsigned char*)e->host_pts.p;
+    double *hx = (double*)(h + o_x), *hy = (double*)(h + o_y), *hz = (double*)(h + o_z);
+    const int g = qpb;   // box granularity: one query block; a chunk's box is the union of its ch / qpb groups
+    std::vector<int64_t> goff(S + 1, 0);
+    for (size_t s = 0; s < S; ++s) goff[s + 1] = goff[s] + (sets[s].n + g - 1) / g;
+    std::vector<double> box((size_t)goff.back() * 6);
+    parallel_for((int)S, [&](int si) {
+        const Set3& st = sets[(size_t)si];
+        const int32_t* pm = perms[(size_t)si].empty() ? nullptr : perms[(size_t)si].data();
+        double *dx = hx + soff[(size_t)si], *dy = hy + soff[(size_t)si], *dz = hz + soff[(size_t)si];
+        for (int64_t g0 = 0, gi = goff[(size_t)si]; g0 < st.n; g0 += g, ++gi) {
+            double* b = box.data() + (size_t)gi * 6;
+            b[0] = b[1] = b[2] = DBL_MAX; b[3] = b[4] = b[5] = -DBL_MAX;
+            for (int64_t j = g0; j < std::min<int64_t>(st.n, g0 + g); ++j) {
+                const int64_t i = pm ? (int64_t)pm[j] : j;
+                const double v[3] = {st.xyz[3 * i], st.xyz[3 * i + 1], st.xyz[3 * i + 2]};
+                dx[j] = v[0]; dy[j] = v[1]; dz[j] = v[2];
+                for (int a = 0; a < 3; ++a) { b[a] = std::min(b[a], v[a]); b[3 + a] = std::max(b[3 + a], v[a]); }
+            }
+        }
+    });
+    for (size_t s = 0; s < S; ++s)
+        if (!perms[s].empty()) std::memcpy(h + o_perm + (size_t)perm_off[s] * 4, perms[s].data(), perms[s].size() * 4);
+
+    auto box_lb2 = [](const double* a, const double* b) {   // squared distance between two boxes, never overstated
+        double s2 = 0.0;
+        for (int ax = 0; ax < 3; ++ax) {
+            const double gap = std::max(0.0, std::max(a[ax] - b[3 + ax], b[ax] - a[3 + ax]));
+            s2 += gap * gap;
+        }
+        return s2 * (1.0 - 1e-12);
+    };
+    const int gpc = std::max(1, ch / g);
+    std::vector<std::vector<NnWorkH>> lw(hp.size());
+    parallel_for((int)hp.size(), [&](int ii) {
+        const size_t i = (size_t)ii;
+        const int32_t q = pr[(size_t)owner[i]][0], p = pr[(size_t)owner[i]][1];
+        const int64_t nq = hp[i].nq, np = hp[i].np, n_chunks = (np + ch - 1) / ch;
+        for (int64_t q0 = 0, qb = 0; q0 < nq; q0 += qpb, ++qb) {
+            const double* bq = box.data() + (size_t)(goff[(size_t)q] + qb) * 6;
+            for (int64_t c = 0; c < n_chunks; ++c) {
+                double lb2 = DBL_MAX;
+                for (int64_t gi = c * gpc; gi < std::min<int64_t>((c + 1) * gpc, goff[(size_t)p + 1] - goff[(size_t)p]); ++gi)
+                    lb2 = std::min(lb2, box_lb2(bq, box.data() + (size_t)(goff[(size_t)p] + gi) * 6));
+                if (lb2 <= r2) lw[i].push_back(NnWorkH{(int32_t)i, (int32_t)q0, (int32_t)(c * ch), 1, lb2});
+            }
+        }
+    });
+    std::vector<NnWorkH> work;
+    for (auto& v : lw) work.insert(work.end(), v.begin(), v.end());
+    if (work.size() > (size_t)1 << 30) return set_error(MM_ERR_TOO_LARGE, "radius counts: too many work items");
+
+    const size_t o_work = up256(o_pairs + hp.size() * sizeof(NnPairH)), in_bytes = up256(o_work + work.size() * sizeof(NnWorkH));
+    const size_t o_out = in_bytes, total = up256(o_out + (size_t)nout * 4);
+    if ((rc = e->ensure(e->host_lvl, std::max(in_bytes - o_pairs, (size_t)nout * 4), true))) return rc;
+    if ((rc = e->ensure(e->dev_pts, total, false))) return rc;
+    unsigned char* hl = (unsigned char*)e->host_lvl.p;
+    std::memcpy(hl, hp.data(), hp.size() * sizeof(NnPairH));
+    if (!work.empty()) std::memcpy(hl + (o_work - o_pairs), work.data(), work.size() * sizeof(NnWorkH));
+    unsigned char* d = (unsigned char*)e->dev_pts.p;
+    MM_TRY_HIP(hipMemcpyAsync(d, h, o_pairs, hipMemcpyHostToDevice, e->stream));
+    MM_TRY_HIP(hipMemcpyAsync(d + o_pairs, hl, in_bytes - o_pairs, hipMemcpyHostToDevice, e->stream));
+    const hipError_t he = launch_nn3_count(d + o_pairs, d + o_work, (int)work.size(), (const double*)(d + o_x), (const double*)(d + o_y),
+                                           (const double*)(d + o_z), (const int32_t*)(d + o_perm), r2, (unsigned int*)(d + o_out), nout,
+                                           e->stream);
+    if (he != hipSuccess) return hip_error(he, "radius-count launch");
+    MM_TRY_HIP(hipMemcpyAsync(hl, d + o_out, (size_t)nout * 4, hipMemcpyDeviceToHost, e->stream));
+    MM_TRY_HIP(hipStreamSynchronize(e->stream));
+    const uint32_t* res = (const uint32_t*)hl;
+    for (size_t i = 0; i < hp.size(); ++i)
+        std::memcpy(counts[(size_t)owner[i]].data(), res + hp[i].out_off, (size_t)hp[i].nq * 4);
+    return MM_OK;
+}
+
+// clean_up_non_section_points (:342-409).  to_ref[i] = 1: point i of `cleanup` joins the reference set (appended
+// in input order), 0: it stays.
+int clean_up_points(Engine* e, const double* cleanup, int64_t nc, const double* reference, int64_t nr, double radius,
+                    double min_ratio, std::vector<uint8_t>& to_ref)
+{
+    to_ref.assign((size_t)nc, 0);
+    if (nc == 0) return MM_OK;                                                        // :353-355
+    const double r2 = radius * radius;                                                // :348
+    std::vector<std::vector<uint32_t>> cnt;
+    int rc = radius_counts(e, {Set3{cleanup, nc}, Set3{reference, nr}}, {{0, 1}, {0, 0}}, r2, cnt);
+    if (rc) return rc;
+    for (int64_t i = 0; i < nc; ++i) {
+        const uint64_t ref_n = cnt[0][(size_t)i];                                     // :375-377
+        const uint64_t self_n = cnt[1][(size_t)i] > 0 ? cnt[1][(size_t)i] - 1 : 0;    // :381-384 saturating_sub(1)
+        const uint64_t total = ref_n + self_n;
+        if (total > 0) {                                                              // :388-400
+            const double ratio = (double)ref_n / (double)total;
+            to_ref[(size_t)i] = ratio >= min_ratio ? 1 : 0;
+        }
+    }
+    return MM_OK;
+}
+
 int engine_of(mm_engine* h, Engine*& e)
 {
     e = reinterpret_cast<Engine*>(h);
@@ -587,6 +724,84 @@ int mm_wall_diameter_optimization(const mm_clpoint* cl, int64_t ncl, const doubl
     const double tx = ref[0] - aortic[3 * ka], ty = ref[1] - aortic[3 * ka + 1], tz = ref[2] - aortic[3 * ka + 2];  // :59
     const double t = tx * ux + ty * uy + tz * uz;                                                    // :60
     *out = t > 0.0 ? t : 0.0;                                                                        // :62
+    return MM_OK;
+}
+
+int mm_clean_outlier_points(mm_engine* h, const double* cleanup, int64_t nc, const double* reference, int64_t nr,
+                            double neighborhood_radius, double min_neighbor_ratio, uint8_t* to_reference)
+{
+    Engine* e;
+    int rc = engine_of(h, e);
+    if (rc) return rc;
+    if (nc < 0 || nr < 0 || (nc > 0 && (!cleanup || !to_reference)) || (nr > 0 && !reference))
+        return set_error(MM_ERR_INVALID, "mm_clean_outlier_points: bad arguments");
+    std::vector<uint8_t> f;
+    if ((rc = clean_up_points(e, cleanup, nc, reference, nr, neighborhood_radius, min_neighbor_ratio, f))) return rc;
+    if (nc > 0) std::memcpy(to_reference, f.data(), (size_t)nc);
+    return MM_OK;
+}
+
+// find_points_by_cl_region_rs (:263-312)
+int mm_find_points_by_cl_region(mm_engine* h, const mm_clpoint* cl, const uint32_t* cl_frame_index, int64_t ncl,
+                                const double* frame_centroids, int64_t n_frames, const double* pts, int64_t n,
+                                uint8_t* label)
+{
+    Engine* e;
+    int rc = engine_of(h, e);
+    if (rc) return rc;
+    if (n < 0 || ncl <= 0 || !cl || n_frames < 2 || !frame_centroids || (n > 0 && (!pts || !label)))
+        return set_error(MM_ERR_INVALID, "mm_find_points_by_cl_region: bad arguments (needs a centerline and >= 2 frames)");
+    double mean_dz = 0.0;                                                              // :268-272
+    for (int64_t i = 1; i < n_frames; ++i) mean_dz += std::fabs(frame_centroids[3 * i + 2] - frame_centroids[3 * (i - 1) + 2]);
+    mean_dz /= (double)(n_frames - 1);
+    // find_cl_points_in_range (:314-338): frame indices of the centerline points within mean_dz of a frame centroid
+    auto fidx = [&](int64_t k) { return cl_frame_index ? cl_frame_index[k] : (uint32_t)k; };
+    std::vector<uint32_t> in_range;
+    const double rr = mean_dz * mean_dz;
+    for (int64_t f = 0; f < n_frames; ++f)
+        for (int64_t k = 0; k < ncl; ++k) {
+            const double dx = frame_centroids[3 * f] - cl[k].x, dy = frame_centroids[3 * f + 1] - cl[k].y,
+                         dz = frame_centroids[3 * f + 2] - cl[k].z;
+            if (dx * dx + dy * dy + dz * dz <= rr) in_range.push_back(fidx(k));
+        }
+    std::sort(in_range.begin(), in_range.end());
+    in_range.erase(std::unique(in_range.begin(), in_range.end()), in_range.end());
+    const double* dref = frame_centroids + 3 * (n_frames - 1);                        // :279
+    // first pass (:289-300): between = the closest centerline point (first minimum, :245-260) is one of those;
+    // second pass (:303-309): the rest is proximal if it exceeds the last centroid in all three coordinates
+    std::vector<uint8_t> cls((size_t)n, 0);   // 0 proximal, 1 distal, 2 between
+    constexpr int64_t kBlock = 256;
+    parallel_for((int)((n + kBlock - 1) / kBlock), [&](int blk) {
+        const int64_t i0 = (int64_t)blk * kBlock;
+        for (int64_t i = i0; i < std::min(n, i0 + kBlock); ++i) {
+            const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+            double best = DBL_MAX;
+            int64_t kb = 0;
+            for (int64_t k = 0; k < ncl; ++k) {
+                const double dx = x - cl[k].x, dy = y - cl[k].y, dz = z - cl[k].z;
+                const double d = dx * dx + dy * dy + dz * dz;
+                if (d < best) { best = d; kb = k; }
+            }
+            if (std::binary_search(in_range.begin(), in_range.end(), fidx(kb))) cls[(size_t)i] = 2;
+            else cls[(size_t)i] = (x > dref[0] && y > dref[1] && z > dref[2]) ? 0 : 1;
+        }
+    });
+    std::vector<double> prox, dist, betw;
+    std::vector<int64_t> iprox, idist;
+    for (int64_t i = 0; i < n; ++i) {
+        std::vector<double>& dst = cls[(size_t)i] == 0 ? prox : (cls[(size_t)i] == 1 ? dist : betw);
+        dst.insert(dst.end(), pts + 3 * i, pts + 3 * i + 3);
+        if (cls[(size_t)i] == 0) iprox.push_back(i); else if (cls[(size_t)i] == 1) idist.push_back(i);
+        label[i] = cls[(size_t)i];
+    }
+    // :310-313 the two clean-ups; the second one sees the points the first one moved into `between`
+    std::vector<uint8_t> mv;
+    if ((rc = clean_up_points(e, prox.data(), (int64_t)iprox.size(), betw.data(), (int64_t)(betw.size() / 3), 1.0, 0.6, mv))) return rc;
+    for (size_t k = 0; k < iprox.size(); ++k)
+        if (mv[k]) { label[iprox[k]] = 3; betw.insert(betw.end(), pts + 3 * iprox[k], pts + 3 * iprox[k] + 3); }
+    if ((rc = clean_up_points(e, dist.data(), (int64_t)idist.size(), betw.data(), (int64_t)(betw.size() / 3), 1.0, 0.6, mv))) return rc;
+    for (size_t k = 0; k < idist.size(); ++k)
+        if (mv[k]) label[idist[k]] = 4;
     return MM_OK;
 }
 

@@ -126,6 +126,10 @@ int        large_rows_per_block();
 hipError_t launch_nn3_min(const void* pairs, const void* work_a, int n_a, const void* work_b, int n_b, const double* px,
                           const double* py, const double* pz, const int32_t* qperm, double* out, long long n_out,
                           hipStream_t s);
+// neighbour counts within a radius (same records; every work item runs): out[n_out] u32
+hipError_t launch_nn3_count(const void* pairs, const void* work, int n_work, const double* px, const double* py,
+                            const double* pz, const int32_t* qperm, double r2, unsigned int* out, long long n_out,
+                            hipStream_t s);
 // derived sets (NnMorph {dst_off, n, aux_off, pad, adj (f64)}): base point + unit vector * adj where flagged,
 // from 7 planes of n_aux doubles (bx by bz ux uy uz flag), written into the SoA point pool
 hipError_t launch_nn3_morph(const void* items, int n_items, const double* aux, long long n_aux, double* px, double* py,

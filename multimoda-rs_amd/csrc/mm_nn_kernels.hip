@@ -141,6 +141,58 @@ k_nn3_min(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int
     }
 }
 
+// Radius counts: cnt[q] += #{p in the chunk : |q - p|^2 <= r2}, the same squared distance, exact f64 -- the
+// neighbour counts of clean_up_non_section_points (scale_coronary.rs:342-409; rstar's locate_within_distance keeps
+// the points with distance_2 <= the squared radius).  Work items are the (query block, chunk) combinations whose
+// bounding boxes come within the radius of each other (host); counts merge with a 32-bit atomicAdd.
+template <int QPT>
+__global__ void __launch_bounds__(256)
+k_nn3_count(const NnPair* __restrict__ pairs, const NnWork* __restrict__ work, int n_work,
+            const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
+            const int32_t* __restrict__ qperm, double r2, unsigned int* __restrict__ out)
+{
+    constexpr int NT = 256, CH = kNnChunk;
+    __shared__ double4 s_p[CH];
+    const int tid = threadIdx.x;
+    for (int wi = (int)gridDim.x == n_work ? nn_xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
+         wi += gridDim.x) {
+        const NnWork w = work[wi];
+        const NnPair pd = pairs[w.pair];
+        int oi[QPT];
+        double qx[QPT], qy[QPT], qz[QPT];
+        unsigned int c[QPT];
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const int q = w.q0 + k * NT + tid;
+            oi[k] = q < pd.nq ? (pd.qperm_off >= 0 ? qperm[pd.qperm_off + q] : q) : -1;
+            const int qc = q < pd.nq ? q : pd.nq - 1;
+            qx[k] = px[pd.q_off + qc]; qy[k] = py[pd.q_off + qc]; qz[k] = pz[pd.q_off + qc];
+            c[k] = 0u;
+        }
+        const int c_end = pd.np - w.c0 < w.n_chunks * CH ? pd.np : w.c0 + w.n_chunks * CH;
+        for (int c0 = w.c0; c0 < c_end; c0 += CH) {
+            const int n = c_end - c0 < CH ? c_end - c0 : CH;
+            __syncthreads();
+            for (int j = tid; j < n; j += NT)
+                s_p[j] = make_double4(px[pd.p_off + c0 + j], py[pd.p_off + c0 + j], pz[pd.p_off + c0 + j], 0.0);
+            __syncthreads();
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) {
+                const double4 p = s_p[j];
+#pragma unroll
+                for (int k = 0; k < QPT; ++k) {
+                    const double dx = qx[k] - p.x, dy = qy[k] - p.y, dz = qz[k] - p.z;
+                    const double v = dx * dx + dy * dy + dz * dz;
+                    c[k] += v <= r2 ? 1u : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QPT; ++k)
+            if (oi[k] >= 0 && c[k]) atomicAdd(&out[pd.out_off + oi[k]], c[k]);
+    }
+}
+
 // queries per lane: 1..4 measured within 5 % of each other on MI355X (10.9 / 10.4 / 10.4 / 10.3 ms for the
 // 3.3e10-pair search of tools/bench_ccta.py): the kernel is bound by fp64 VALU issue, not by the LDS reads
 static constexpr int kNnQpt = 2;
@@ -192,6 +244,21 @@ hipError_t launch_nn3_morph(const void* items, int n_items, const double* aux, l
     // grid.x covers the largest set; blocks past a set's end exit
     hipLaunchKernelGGL(k_nn3_morph, dim3((unsigned)((n_aux + 255) / 256), (unsigned)n_items), dim3(256), 0, s,
                        (const NnMorph*)items, aux, n_aux, px, py, pz);
+    return hipGetLastError();
+}
+
+// out[n_out] (u32, zeroed here) += neighbours within sqrt(r2) over the work items
+hipError_t launch_nn3_count(const void* pairs, const void* work, int n_work, const double* px, const double* py,
+                            const double* pz, const int32_t* qperm, double r2, unsigned int* out, long long n_out,
+                            hipStream_t s)
+{
+    if (n_out > 0) {
+        const hipError_t e = hipMemsetAsync(out, 0, (size_t)n_out * 4, s);
+        if (e != hipSuccess) return e;
+    }
+    if (n_work > 0)
+        hipLaunchKernelGGL((k_nn3_count<kNnQpt>), dim3((unsigned)n_work), dim3(256), 0, s, (const NnPair*)pairs,
+                           (const NnWork*)work, n_work, px, py, pz, qperm, r2, out);
     return hipGetLastError();
 }
 

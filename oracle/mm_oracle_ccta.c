@@ -171,3 +171,72 @@ double orc_wall_diameter_optimization(const orc_clpoint* cl, size_t ncl, const d
     double t = tx * ux + ty * uy + tz * uz;                      /* :60 */
     return t > 0.0 ? t : 0.0;                                    /* :62 f64::max(0.0) */
 }
+
+/* clean_up_non_section_points (:342-409).  The reference counts neighbours with two rstar R-trees
+ * (locate_within_distance: distance_2 <= squared radius, distance_2 = the sum of the squared coordinate
+ * differences folded x, y, z); an exhaustive count gives the same numbers.  PARITY UNPINNED: the reference
+ * holds no test for this function nor for find_points_by_cl_region_rs. */
+void orc_clean_outlier_points(const orc_point* cleanup, size_t nc, const orc_point* reference, size_t nr,
+                              double radius, double min_ratio, uint8_t* to_reference)
+{
+    const double r2 = radius * radius;                            /* :348 */
+    for (size_t i = 0; i < nc; ++i) {
+        size_t ref_n = 0, self_n = 0;
+        for (size_t k = 0; k < nr; ++k)
+            if (sq_dist(cleanup[i].x, cleanup[i].y, cleanup[i].z, reference[k].x, reference[k].y, reference[k].z) <= r2) ++ref_n;
+        for (size_t k = 0; k < nc; ++k)
+            if (sq_dist(cleanup[i].x, cleanup[i].y, cleanup[i].z, cleanup[k].x, cleanup[k].y, cleanup[k].z) <= r2) ++self_n;
+        self_n = self_n > 0 ? self_n - 1 : 0;                     /* :381-384 saturating_sub(1): the point itself */
+        const size_t total = ref_n + self_n;
+        to_reference[i] = 0;
+        if (total > 0) {                                          /* :388-400 */
+            const double ratio = (double)ref_n / (double)total;
+            if (ratio >= min_ratio) to_reference[i] = 1;
+        }
+    }
+}
+
+/* find_points_by_cl_region_rs (:263-312) with find_cl_points_in_range (:314-338) and
+ * find_closest_centerline_point_optimized (:245-260).  label: 0 proximal, 1 distal, 2 between, 3 / 4 = moved
+ * into `between` by the first / second clean-up (the order in which the reference appends them). */
+void orc_find_points_by_cl_region(const orc_clpoint* cl, const uint32_t* cl_frame_index, size_t ncl,
+                                  const double* centroids, size_t n_frames, const orc_point* pts, size_t n,
+                                  uint8_t* label)
+{
+    double mean_dz = 0.0;
+    for (size_t i = 1; i < n_frames; ++i) mean_dz += fabs(centroids[3 * i + 2] - centroids[3 * (i - 1) + 2]);   /* :268-272 */
+    mean_dz /= (double)(n_frames - 1);
+    uint8_t* sel = (uint8_t*)calloc(ncl ? ncl : 1, 1);             /* centerline point k is within range of a centroid */
+    for (size_t f = 0; f < n_frames; ++f)
+        for (size_t k = 0; k < ncl; ++k)
+            if (sq_dist(centroids[3 * f], centroids[3 * f + 1], centroids[3 * f + 2], cl[k].x, cl[k].y, cl[k].z) <= mean_dz * mean_dz)
+                sel[k] = 1;
+    const double* dref = centroids + 3 * (n_frames - 1);           /* :279 */
+    orc_point* prox = (orc_point*)malloc((n ? n : 1) * sizeof(orc_point));
+    orc_point* dist = (orc_point*)malloc((n ? n : 1) * sizeof(orc_point));
+    orc_point* betw = (orc_point*)malloc((n ? n : 1) * sizeof(orc_point));
+    size_t* ip = (size_t*)malloc((n ? n : 1) * sizeof(size_t));
+    size_t* id = (size_t*)malloc((n ? n : 1) * sizeof(size_t));
+    size_t np = 0, nd = 0, nb = 0;
+    for (size_t i = 0; i < n; ++i) {
+        double best = DBL_MAX; size_t kb = 0;                      /* :249-258 strict <: first minimum */
+        for (size_t k = 0; k < ncl; ++k) {
+            const double d = sq_dist(pts[i].x, pts[i].y, pts[i].z, cl[k].x, cl[k].y, cl[k].z);
+            if (d < best) { best = d; kb = k; }
+        }
+        /* cl_points_indices.contains(&frame_index): some selected centerline point carries this frame index */
+        const uint32_t fi = cl_frame_index ? cl_frame_index[kb] : (uint32_t)kb;
+        int between = 0;
+        for (size_t k = 0; k < ncl && !between; ++k)
+            if (sel[k] && (cl_frame_index ? cl_frame_index[k] : (uint32_t)k) == fi) between = 1;
+        if (between) { label[i] = 2; betw[nb++] = pts[i]; }
+        else if (pts[i].x > dref[0] && pts[i].y > dref[1] && pts[i].z > dref[2]) { label[i] = 0; ip[np] = i; prox[np++] = pts[i]; }  /* :303-309 */
+        else { label[i] = 1; id[nd] = i; dist[nd++] = pts[i]; }
+    }
+    uint8_t* mv = (uint8_t*)malloc(n ? n : 1);
+    orc_clean_outlier_points(prox, np, betw, nb, 1.0, 0.6, mv);    /* :310-311 */
+    for (size_t k = 0; k < np; ++k) if (mv[k]) { label[ip[k]] = 3; betw[nb++] = prox[k]; }
+    orc_clean_outlier_points(dist, nd, betw, nb, 1.0, 0.6, mv);    /* :312-313: sees the points moved above */
+    for (size_t k = 0; k < nd; ++k) if (mv[k]) label[id[k]] = 4;
+    free(sel); free(prox); free(dist); free(betw); free(ip); free(id); free(mv);
+}

@@ -46,6 +46,15 @@ void   orc_diameter_optimization(const orc_point* anomalous, size_t n, size_t n_
 double orc_wall_diameter_optimization(const orc_clpoint* cl, size_t ncl, const double ref_pt[3],
                                       const orc_point* aortic, size_t na);
 
+/* clean_up_non_section_points (:342-409), exhaustive neighbour counts; to_reference[i] = 1: joins the reference set.
+ * PARITY UNPINNED (no reference test). */
+void   orc_clean_outlier_points(const orc_point* cleanup, size_t nc, const orc_point* reference, size_t nr,
+                                double radius, double min_ratio, uint8_t* to_reference);
+/* find_points_by_cl_region_rs (:263-340); label as in include/mm_ccta.h.  PARITY UNPINNED (no reference test). */
+void   orc_find_points_by_cl_region(const orc_clpoint* cl, const uint32_t* cl_frame_index, size_t ncl,
+                                    const double* centroids, size_t n_frames, const orc_point* pts, size_t n,
+                                    uint8_t* label);
+
 #ifdef __cplusplus
 }
 #endif

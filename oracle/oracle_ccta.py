@@ -30,6 +30,10 @@ def lib():
     L.orc_aortic_diameter_optimization.argtypes = [P, Z, P, Z, P, Z, P]
     L.orc_diameter_optimization.restype = None
     L.orc_diameter_optimization.argtypes = [P, Z, Z, Z, P, Z, P, Z, P, Z, C.POINTER(D), C.POINTER(D)]
+    L.orc_clean_outlier_points.restype = None
+    L.orc_clean_outlier_points.argtypes = [P, Z, P, Z, D, D, P]
+    L.orc_find_points_by_cl_region.restype = None
+    L.orc_find_points_by_cl_region.argtypes = [P, P, Z, P, Z, P, Z, P]
     L.orc_wall_diameter_optimization.restype = D
     L.orc_wall_diameter_optimization.argtypes = [P, Z, P, P, Z]
     _ready = True
@@ -85,3 +89,24 @@ def diameter_optimization(anomalous, n_proximal, n_distal, cl, proximal_referenc
 def wall_diameter_optimization(cl, ref_pt, aortic) -> float:
     cl, r, a = _cl(cl), _v3(ref_pt), _p3(aortic)
     return lib().orc_wall_diameter_optimization(O._p(cl), cl.shape[0], O._p(r), O._p(a), a.shape[0])
+
+
+def clean_outlier_points(points_to_cleanup, reference_points, neighborhood_radius, min_neigbor_ratio):
+    """clean_up_non_section_points (scale_coronary.rs:342-409) -> (cleaned points, augmented reference)."""
+    c, r = _p3(points_to_cleanup), _p3(reference_points)
+    mv = np.zeros(c.shape[0], dtype=np.uint8)
+    lib().orc_clean_outlier_points(O._p(c), c.shape[0], O._p(r), r.shape[0], float(neighborhood_radius),
+                                   float(min_neigbor_ratio), O._p(mv))
+    return c[mv == 0].copy(), np.concatenate([r, c[mv == 1]], axis=0)
+
+
+def find_points_by_cl_region(cl, frame_centroids, points, cl_frame_index=None):
+    """find_points_by_cl_region_rs (scale_coronary.rs:263-312) -> (proximal, distal, between, labels)."""
+    cl, p = _cl(cl), _p3(points)
+    cen = np.ascontiguousarray(np.asarray(frame_centroids, dtype=np.float64).reshape(-1, 3))
+    fi = None if cl_frame_index is None else np.ascontiguousarray(cl_frame_index, dtype=np.uint32)
+    lab = np.zeros(p.shape[0], dtype=np.uint8)
+    lib().orc_find_points_by_cl_region(O._p(cl), None if fi is None else O._p(fi), cl.shape[0], O._p(cen), cen.shape[0],
+                                       O._p(p), p.shape[0], O._p(lab))
+    between = np.concatenate([p[lab == 2], p[lab == 3], p[lab == 4]], axis=0)
+    return p[lab == 0].copy(), p[lab == 1].copy(), between, lab

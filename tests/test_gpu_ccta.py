@@ -125,3 +125,50 @@ def test_proximal_distal_scaling_matches_oracle(engine, mm, occ, ocl):
     e = occ.diameter_optimization(res["anomalous_points"], n4, n4, to_oracle_cl(ocl, cl),
                                   g.lumen[:g.lumen_off[2]], g.lumen[g.lumen_off[5]:])
     assert w == e
+
+
+# ---------------------------------------------------------------------------------------
+# find_points_by_cl_region / clean_outlier_points (scale_coronary.rs:263-409) -- oracle parity unpinned (no
+# reference test), product against the oracle bit for bit
+# ---------------------------------------------------------------------------------------
+def _vessel(mm, n_pts, seed, spread=0.3):
+    case = mm.synth.synthetic_tube_case(n_points=n_pts, n_reference=10, seed=seed)
+    rng = np.random.default_rng(seed)
+    pts = case["points"] + rng.normal(0, spread, size=case["points"].shape)     # thicken the shell: neighbours within 1 mm
+    return case["centerline"], pts
+
+
+@pytest.mark.parametrize("n_pts,seed", [(50, 1), (700, 2), (6000, 3), (12000, 4)])     # the last two: slab order + box pruning
+def test_find_points_by_cl_region_matches_oracle(engine, mm, occ, n_pts, seed):
+    cl, pts = _vessel(mm, n_pts, seed)
+    xyz = cl.xyz()
+    k0, k1 = len(xyz) // 3, len(xyz) // 3 + 14
+    cen = xyz[k0:k1:2] + 0.05                                     # frame centroids along a section of the vessel
+    got = mm.find_points_by_cl_region(cl, cen, pts, engine=engine, return_labels=True)
+    exp = occ.find_points_by_cl_region(to_oracle_cl(ocl_mod(), cl), cen, pts)
+    assert np.array_equal(got[3], exp[3])
+    for a, b in zip(got[:3], exp[:3]):
+        assert np.array_equal(a, b)
+    assert len(got[2]) > 0 and len(got[0]) + len(got[1]) + len(got[2]) == n_pts
+    if n_pts >= 700:
+        assert (got[3] >= 3).any()                                # the clean-ups moved something
+
+
+def ocl_mod():
+    from oracle import oracle_cl
+    oracle_cl.lib()
+    return oracle_cl
+
+
+@pytest.mark.parametrize("nc,nr,radius,ratio", [(1, 1, 1.0, 0.6), (300, 500, 1.0, 0.6), (5000, 4500, 0.7, 0.5),
+                                                (9000, 100, 2.0, 0.9), (0, 10, 1.0, 0.6), (10, 0, 1.0, 0.6)])
+def test_clean_outlier_points_matches_oracle(engine, mm, occ, nc, nr, radius, ratio):
+    rng = np.random.default_rng(nc * 31 + nr)
+    c = rng.normal(0, 3, size=(nc, 3)) + [10.0, -190.0, 1700.0]
+    r = rng.normal(0, 3, size=(nr, 3)) + [11.0, -190.0, 1700.0]
+    if nc > 3 and nr > 3:
+        c[1] = c[0]                                                # duplicates count as neighbours, the point itself does not
+        r[2] = c[3] + [radius, 0.0, 0.0]                           # (nearly) on the boundary of the radius
+    got = mm.clean_outlier_points(c, r, radius, ratio, engine=engine)
+    exp = occ.clean_outlier_points(c, r, radius, ratio)
+    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])

@@ -95,3 +95,45 @@ def test_wall_diameter_optimization(occ, ocl):                  # :8-63
     assert occ.wall_diameter_optimization(cl, (3.0, 0.0, 0.0), [[4.0, 0, 0]]) == 0.0
     assert occ.wall_diameter_optimization(cl, (0.0, 0.0, 0.0), [[4.0, 0, 0]]) == 0.0      # zero vector (:53-55)
     assert occ.wall_diameter_optimization(cl, (3.0, 0.0, 0.0), np.zeros((0, 3))) == 0.0   # :13-15
+
+
+# ---------------------------------------------------------------------------------------
+# find_points_by_cl_region_rs / clean_up_non_section_points (scale_coronary.rs:263-409): the reference holds no
+# test for them ("parity unpinned"); these cases are small enough to be worked out by hand from the source.
+# ---------------------------------------------------------------------------------------
+def test_clean_outlier_points_by_hand(occ):
+    # cleanup point 0 has 3 reference neighbours and 1 other cleanup neighbour: 3/4 >= 0.6 -> moved;
+    # point 1 (next to it) has the same 3 reference points at distance <= 1 ... and point 2 is isolated -> stays
+    ref = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.0, 0.5, 0.0], [50.0, 0.0, 0.0]]
+    cleanup = [[0.1, 0.1, 0.0], [0.2, 0.1, 0.0], [20.0, 20.0, 20.0], [0.0, 0.0, 1.0]]
+    cleaned, aug = occ.clean_outlier_points(cleanup, ref, 1.0, 0.6)
+    # point 3: reference neighbours within 1.0: (0,0,0) at exactly distance 1.0 (<= counts) -> ref 1;
+    #          (0.5,0,0): sqrt(1.25) no; cleanup neighbours: (0.1,0.1,0): sqrt(.01+.01+1) no -> self 0; 1/1 -> moved
+    assert np.array_equal(cleaned, np.array([[20.0, 20.0, 20.0]]))
+    assert np.array_equal(aug, np.array(ref + [[0.1, 0.1, 0.0], [0.2, 0.1, 0.0], [0.0, 0.0, 1.0]]))
+    # empty cleanup set: the reference returns (empty, reference) (:353-355)
+    c2, a2 = occ.clean_outlier_points(np.zeros((0, 3)), ref, 1.0, 0.6)
+    assert c2.shape == (0, 3) and np.array_equal(a2, np.array(ref))
+    # ratio exactly at the threshold: 3 reference + 2 others = 0.6 -> moved (>=)
+    ref3 = [[0.0, 0.0, 0.0], [0.1, 0.0, 0.0], [0.0, 0.1, 0.0]]
+    cl3 = [[0.05, 0.05, 0.0], [0.06, 0.05, 0.0], [0.05, 0.06, 0.0]]
+    cleaned, aug = occ.clean_outlier_points(cl3, ref3, 1.0, 0.6)
+    assert cleaned.shape == (0, 3) and aug.shape == (6, 3)
+
+
+def test_find_points_by_cl_region_by_hand(occ, ocl):
+    # straight centerline along -z, 21 points 1 mm apart; frames at z = 10, 9, 8 (spacing 1 -> radius 1):
+    # centerline points with z in [7, 11] are "in range"
+    z = np.arange(20.0, -1.0, -1.0)
+    cl = ocl.make_centerline(np.stack([np.zeros_like(z), np.zeros_like(z), z], 1), np.tile([0.0, 0.0, -1.0], (len(z), 1)))
+    cen = np.array([[0.0, 0.0, 10.0], [0.0, 0.0, 9.0], [0.0, 0.0, 8.0]])
+    pts = np.array([[1.0, 0.0, 9.2],      # closest cl point z = 9 -> between
+                    [1.0, 1.0, 15.0],     # closest z = 15: outside; > (0, 0, 8) in all coordinates -> proximal
+                    [1.0, 1.0, 3.0],      # z below the last centroid -> distal
+                    [-1.0, 1.0, 15.0],    # x not greater than the last centroid's -> distal, whatever its z
+                    [1.0, 0.0, 11.4],     # closest z = 11: in range (|11 - 10| <= 1) -> between
+                    [1.0, 0.5, 11.6]])    # closest z = 12: not in range -> proximal ... but its only neighbour within 1 mm
+                                          # is the between point at 11.4 (distance 0.54): ratio 1 -> moved to between (label 3)
+    prox, dist, betw, lab = occ.find_points_by_cl_region(cl, cen, pts)
+    assert lab.tolist() == [2, 0, 1, 1, 2, 3]
+    assert np.array_equal(prox, pts[[1]]) and np.array_equal(dist, pts[[2, 3]]) and np.array_equal(betw, pts[[0, 4, 5]])
