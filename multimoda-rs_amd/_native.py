@@ -65,6 +65,16 @@ class MMGeometry(C.Structure):
     ]
 
 
+# include/mm_build.h
+EXPORTS_BUILD = ["mm_build_geometry", "mm_built_dims", "mm_built_export", "mm_built_destroy"]
+
+
+class MMRecord(C.Structure):
+    """``mm_record`` (include/mm_build.h)."""
+    _fields_ = [("frame", C.c_uint32), ("phase", C.c_uint8), ("has_m1", C.c_uint8), ("has_m2", C.c_uint8),
+                ("pad_", C.c_uint8), ("m1", C.c_double), ("m2", C.c_double)]
+
+
 # include/mm_ccta.h
 EXPORTS_CCTA = [
     "mm_nn_min_sq_batch", "mm_symmetric_nn_distance", "mm_diameter_morphing", "mm_find_region_points",
@@ -278,6 +288,15 @@ def lib():
     L.mm_align_combined.restype = I
     L.mm_align_combined.argtypes = [P, P, I64, P, I, U32, P, P, P, P, I64, D, D, I64, I, C.POINTER(D), C.POINTER(D),
                                     C.POINTER(I64), C.POINTER(I64)]
+    # include/mm_build.h
+    L.mm_build_geometry.restype = I
+    L.mm_build_geometry.argtypes = [P, I64, P, P, I64, P, I64, P, I64, P, P, I64, I, D, D, D, C.c_uint32, C.POINTER(P)]
+    L.mm_built_dims.restype = I
+    L.mm_built_dims.argtypes = [P, C.POINTER(I32), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)]
+    L.mm_built_export.restype = I
+    L.mm_built_export.argtypes = [P, C.POINTER(MMGeometry), P, P, P, P, P, P]
+    L.mm_built_destroy.restype = None
+    L.mm_built_destroy.argtypes = [P]
     # include/mm_ccta.h
     L.mm_nn_min_sq_batch.restype = I
     L.mm_nn_min_sq_batch.argtypes = [P, I, P, P, I, P, P, P, P]

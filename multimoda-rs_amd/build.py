@@ -15,9 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmm_hausdorff.so")
-SOURCES = ["mm_kernels.hip", "mm_nn_kernels.hip", "mm_engine.cpp", "mm_host.cpp", "mm_centerline.cpp", "mm_ccta.cpp"]
+SOURCES = ["mm_kernels.hip", "mm_nn_kernels.hip", "mm_engine.cpp", "mm_host.cpp", "mm_centerline.cpp", "mm_ccta.cpp",
+           "mm_build.cpp"]
 HEADERS = ["mm_device.h", "mm_engine.h", "mm_pool.h", "mm_trace.h", os.path.join("..", "..", "include", "mm_hausdorff.h"),
-           os.path.join("..", "..", "include", "mm_centerline.h"), os.path.join("..", "..", "include", "mm_ccta.h")]
+           os.path.join("..", "..", "include", "mm_centerline.h"), os.path.join("..", "..", "include", "mm_ccta.h"),
+           os.path.join("..", "..", "include", "mm_build.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -301,12 +301,79 @@ def _group_by_frame(arr: np.ndarray) -> Dict[int, np.ndarray]:
 def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: Optional[str] = None, label: str = "",
                                   diastole: bool = True, image_center=(4.5, 4.5), radius: float = 0.5,
                                   n_points: int = 20) -> FlatGeometry:
-    """``build_geometry_from_inputdata`` (io/build.rs:9-205)."""
+    """``build_geometry_from_inputdata`` (io/build.rs:9-205): behind the C ABI (``mm_build_geometry``,
+    include/mm_build.h, csrc/mm_build.cpp).  ``build_geometry_python`` below is the same builder in Python, kept as
+    a checker (tests/test_refbuild.py compares both with the independent restatement in tests/refbuild.py)."""
     if input_data is None:
         if path is None:
             raise RuntimeError("Either input_data or path must be provided")
         input_data = process_directory(path, diastole, label)
-    d = input_data
+    if os.environ.get("MM_PY_BUILDER"):
+        return build_geometry_python(input_data, label, image_center, radius, n_points)
+    return _build_geometry_native(input_data, label, image_center, radius, n_points)
+
+
+def _build_geometry_native(d: InputData, label: str, image_center, radius: float, n_points: int) -> FlatGeometry:
+    import ctypes as C
+    from . import _native as N
+    L = N.lib()
+    rows = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 4)
+    lum, eem, calc, side = rows(d.lumen), rows(d.eem), rows(d.calcification), rows(d.sidebranch)
+    ref = np.ascontiguousarray(d.ref_point, dtype=np.float64).reshape(4)
+    flags = None
+    if d.lumen_aortic is not None and np.any(d.lumen_aortic):
+        flags = np.ascontiguousarray(d.lumen_aortic, dtype=np.uint8)
+    recs = None
+    if d.record is not None:
+        recs = (N.MMRecord * max(len(d.record), 1))()
+        for i, r in enumerate(d.record):
+            recs[i].frame = int(r.frame)
+            recs[i].phase = 0 if r.phase == "D" else (1 if r.phase == "S" else 2)
+            recs[i].has_m1 = r.measurement_1 is not None
+            recs[i].has_m2 = r.measurement_2 is not None
+            recs[i].m1 = 0.0 if r.measurement_1 is None else float(r.measurement_1)
+            recs[i].m2 = 0.0 if r.measurement_2 is None else float(r.measurement_2)
+    h = C.c_void_p()
+    n_of = lambda a: 0 if a is None else a.shape[0]
+    N.check(L.mm_build_geometry(N._ptr(lum), lum.shape[0], N._ptr(flags), N._ptr(eem), n_of(eem), N._ptr(calc), n_of(calc),
+                                N._ptr(side), n_of(side), N._ptr(ref), recs, 0 if d.record is None else len(d.record),
+                                int(bool(d.diastole)), float(image_center[0]), float(image_center[1]), float(radius),
+                                int(n_points), C.byref(h)), "build_geometry_from_inputdata")
+    try:
+        F, nl, nc, ne = C.c_int32(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        N.check(L.mm_built_dims(h, C.byref(F), C.byref(nl), C.byref(nc), C.byref(ne)), "mm_built_dims")
+        F, nl, nc, ne = F.value, nl.value, nc.value, ne.value
+        g = FlatGeometry(ids=np.zeros(F, np.uint32), lumen_ids=np.zeros(F, np.uint32), orig_frames=np.zeros(F, np.uint32),
+                         centroids=np.zeros((F, 3)), lumen_off=np.zeros(F + 1, np.int64), lumen=np.zeros((nl, 3)),
+                         has_ref=np.zeros(F, np.uint8), ref=np.zeros((F, 3)), label=d.label or label)
+        if nc:
+            g.cath_off, g.cath = np.zeros(F + 1, np.int64), np.zeros((nc, 3))
+        if ne:
+            g.extra_off, g.extra = np.zeros(F + 1, np.int64), np.zeros((ne, 3))
+        counts = np.zeros((F, 3), dtype=np.int64)
+        a_th, p_th = np.zeros(F), np.zeros(F)
+        has_a, has_p = np.zeros(F, np.uint8), np.zeros(F, np.uint8)
+        fl_out = np.zeros(nl, dtype=np.uint8) if flags is not None else None
+        st = N.MMGeometry()
+        p = N._ptr
+        st.id, st.lumen_id, st.orig_frame, st.centroid = p(g.ids), p(g.lumen_ids), p(g.orig_frames), p(g.centroids)
+        st.lumen_off, st.lumen, st.cath_off, st.cath = p(g.lumen_off), p(g.lumen), p(g.cath_off), p(g.cath)
+        st.extra_off, st.extra, st.has_ref, st.ref = p(g.extra_off), p(g.extra), p(g.has_ref), p(g.ref)
+        N.check(L.mm_built_export(h, C.byref(st), p(counts), p(a_th), p(has_a), p(p_th), p(has_p), p(fl_out)), "mm_built_export")
+    finally:
+        L.mm_built_destroy(h)
+    g.meta["extra_counts"] = {"eem": counts[:, 0].copy(), "calcification": counts[:, 1].copy(),
+                              "sidebranch": counts[:, 2].copy(), "wall": np.zeros(F, dtype=np.int64)}
+    if fl_out is not None and fl_out.any():
+        g.meta["lumen_aortic"] = fl_out.astype(bool)
+    g.meta["aortic_thickness"] = [float(a_th[i]) if has_a[i] else None for i in range(F)]
+    g.meta["pulmonary_thickness"] = [float(p_th[i]) if has_p[i] else None for i in range(F)]
+    return g
+
+
+def build_geometry_python(d: InputData, label: str = "", image_center=(4.5, 4.5), radius: float = 0.5,
+                          n_points: int = 20) -> FlatGeometry:
+    """The same builder in Python (checker of the native one)."""
 
     # build.rs:37-71 shared original-frame -> sequential-id mapping
     originals = set(int(f) for f in np.unique(d.lumen[:, 0]))

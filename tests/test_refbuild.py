@@ -14,9 +14,15 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 FOLDERS = ["ivus_rest", "ivus_stress", "idealized_geometry", "examples_ivus_rest", "examples_ivus_stress"]
 
 
+@pytest.mark.parametrize("builder", ["native", "python"])
 @pytest.mark.parametrize("diastole", [True, False])
 @pytest.mark.parametrize("folder", FOLDERS)
-def test_product_builder_equals_independent_builder(mm, folder, diastole):
+def test_product_builder_equals_independent_builder(mm, folder, diastole, builder, monkeypatch):
+    """native = mm_build_geometry behind the C ABI (the product path); python = its in-package checker."""
+    import __graft_entry__ as ge
+    ge.build()
+    if builder == "python":
+        monkeypatch.setenv("MM_PY_BUILDER", "1")
     path = os.path.join(GOLD, folder)
     g = mm.build_geometry_from_inputdata(None, path, folder, diastole)
     b = refbuild.build_geometry(path, diastole)
@@ -39,3 +45,48 @@ def test_rows_the_reference_reader_skips(tmp_path):
     p.write_text("1,1.0,2.0,3.0\n1.0,1.0,2.0,3.0\n2,1e0,2.5,3\n 3,1,2,3\n4,1_0,2,3\n5,1,2,3,true\n6,1,2,3,maybe\n7,1,2\n8,1,2,3abc\n")
     rows = refbuild.read_contour_data(str(p))
     assert [(r["frame"], r["x"], r["aortic"]) for r in rows] == [(1, 1.0, False), (2, 1.0, False), (5, 1.0, True)]
+
+
+def test_native_builder_equals_python_builder_with_extras_and_ragged_input(mm, monkeypatch):
+    """EEM / calcification / sidebranch contours (also for frames without a lumen and a lumen-less reference frame),
+    ragged contours, records that reorder, duplicate and skip frames, per-point aortic flags, no catheter."""
+    import math
+    import __graft_entry__ as ge
+    ge.build()
+    rng = np.random.default_rng(3)
+
+    def ring(frame, n, r, z, jitter=0.02):
+        t = np.sort(rng.uniform(0, 2 * math.pi, n))
+        return np.stack([np.full(n, float(frame)), 4.5 + r * np.cos(t) + rng.normal(0, jitter, n),
+                         4.4 + 0.8 * r * np.sin(t) + rng.normal(0, jitter, n), np.full(n, z)], 1)
+    frames = [12, 15, 19, 23, 31, 40]
+    lum = np.concatenate([ring(f, 40 + 3 * k, 2.0, 0.4 * f) for k, f in enumerate(frames)])
+    rng.shuffle(lum)                                                     # rows of a frame are not contiguous in the file
+    eem = np.concatenate([ring(f, 30, 2.6, 0.4 * f) for f in (12, 19, 23, 77)])    # 77: no lumen -> dropped, but mapped
+    calc = np.concatenate([ring(f, 7, 1.0, 0.4 * f) for f in (15, 40)])
+    side = ring(31, 9, 0.7, 0.4 * 31)
+    flags = lum[:, 1] > 4.5
+    recs = [mm.Record(23, "D", 1.1, None), mm.Record(12, "S", None, 2.0), mm.Record(40, "D", None, None),
+            mm.Record(23, "D", 0.9, 1.9), mm.Record(99, "D", 1.0, 1.0), mm.Record(15, "X", 3.0, 3.0)]
+    for n_points in (20, 0):
+        for dia in (True, False):
+            for ref_frame in (19, 14):                                    # 14: a frame index no contour has
+                d = mm.InputData(lumen=lum, ref_point=np.array([ref_frame, 6.5, 4.4, 7.6]), diastole=dia, label="x",
+                                 eem=eem, calcification=calc, sidebranch=side, record=recs, lumen_aortic=flags)
+                monkeypatch.delenv("MM_PY_BUILDER", raising=False)
+                a = mm.build_geometry_from_inputdata(d, n_points=n_points)
+                monkeypatch.setenv("MM_PY_BUILDER", "1")
+                b = mm.build_geometry_from_inputdata(d, n_points=n_points)
+                for name in ("ids", "lumen_ids", "orig_frames", "centroids", "lumen_off", "lumen", "cath_off", "cath",
+                             "extra_off", "extra", "has_ref", "ref"):
+                    x, y = getattr(a, name), getattr(b, name)
+                    assert (x is None) == (y is None), name
+                    if x is not None:
+                        assert np.array_equal(x, y), (name, n_points, dia, ref_frame)
+                assert a.label == b.label
+                for k in ("eem", "calcification", "sidebranch", "wall"):
+                    assert np.array_equal(a.meta["extra_counts"][k], b.meta["extra_counts"][k])
+                assert a.meta["aortic_thickness"] == b.meta["aortic_thickness"]
+                assert a.meta["pulmonary_thickness"] == b.meta["pulmonary_thickness"]
+                assert np.array_equal(a.meta["lumen_aortic"], b.meta["lumen_aortic"])
+                assert np.array_equal(a.meta["lumen_aortic"], a.lumen[:, 0] > 4.5)
