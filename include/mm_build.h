@@ -54,6 +54,48 @@ int  mm_built_export(const mm_built* b, mm_geometry* dst, int64_t* extra_counts,
                      uint8_t* lumen_aortic_out);
 void mm_built_destroy(mm_built* b);
 
+/* Contour::compute_centroid (contour.rs:213-224) of n CSR contours of xyz triples: sequential sums / count, the
+ * reference's fold; out [n*3] (a contour without points yields zeros).  Contours are independent: worker pool. */
+int  mm_contour_centroids(const double* xyz, const int64_t* off, int64_t n_contours, double* out);
+
+/* ---- the bookkeeping around the searches on a frame list (csrc/mm_frames.cpp) -----------------------------------
+ * Reference interfaces replaced:
+ *   src/intravascular/processing/align_within.rs:136-160  the post-steps of align_frames_in_geometry
+ *        (fill_holes :330-653, is_anomalous_coronary :249-254, angle_ref_point_to_right :256-314, rotate_geometry
+ *         geometry.rs:241-250, assign_aortic :316-328, wall::create_wall_frames wall.rs:7-213, smooth_frames
+ *         geometry.rs:165-239)
+ *   src/intravascular/processing/postprocessing.rs:12-476  postprocess_geom_pair (same-rate check, resampling,
+ *        z-translation, trim_geom_pair, adjust_walls_anomalous_geom_pair)
+ * A frame list changes its shape (holes get frames, walls get contours, pairs get trimmed), so it is a
+ * library-owned object filled from and exported to flat arrays. */
+typedef struct {
+    mm_geometry g;                  /* extras per frame in the order eem, calcification, sidebranch, wall            */
+    int64_t*  extra_counts;         /* [F*4] points of those four kinds per frame                                    */
+    uint8_t*  has_lumen_centroid;   /* [F] Frame.lumen.centroid.is_some(); NULL on input = all Some if the next is set */
+    double*   lumen_centroid;       /* [F*3]; NULL on input = all None                                               */
+    double*   aortic_thickness;     /* [F] Contour.aortic_thickness of the lumen ...                                 */
+    uint8_t*  has_aortic;           /* [F] ... and whether it is Some                                                */
+    double*   pulmonary_thickness;
+    uint8_t*  has_pulmonary;
+    uint8_t*  lumen_aortic;         /* [lumen points] ContourPoint.aortic; NULL on input = all false                 */
+    uint8_t*  wall_aortic;          /* [wall points]; NULL on input = all false                                      */
+} mm_flat_geometry;
+
+typedef struct mm_frames mm_frames;
+int  mm_frames_from_flat(const mm_flat_geometry* in, mm_frames** out);
+int  mm_frames_dims(const mm_frames* f, int32_t* n_frames, int64_t* n_lumen, int64_t* n_cath, int64_t* n_extra,
+                    int64_t* n_wall);
+/* every array of `out` caller-allocated to the sizes of mm_frames_dims (cath / extra arrays only where > 0) */
+int  mm_frames_export(const mm_frames* f, mm_flat_geometry* out);
+void mm_frames_destroy(mm_frames* f);
+/* The post-steps of align_frames_in_geometry (align_within.rs:136-160) on the chain's result.  ref_idx = the
+ * reference frame index taken BEFORE the chain (:42-44).  Lumen contour centroids: the mean of the points after
+ * the rotation (the reference keeps the value Frame::translate left, i.e. the mean before the chain's last
+ * rotation; x, y differ by that rotation, z is exact) and, with smooth, the mean of the smoothed points. */
+int  mm_frames_finish_within(mm_frames* f, int64_t ref_idx, int smooth, int* anomalous);
+/* postprocess_geom_pair(pair, tolerance, anomalous) (postprocessing.rs:12-87), both lists replaced */
+int  mm_frames_postprocess_pair(mm_frames* a, mm_frames* b, double tolerance, int anomalous);
+
 #ifdef __cplusplus
 }
 #endif

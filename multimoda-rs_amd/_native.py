@@ -66,13 +66,23 @@ class MMGeometry(C.Structure):
 
 
 # include/mm_build.h
-EXPORTS_BUILD = ["mm_build_geometry", "mm_built_dims", "mm_built_export", "mm_built_destroy"]
+EXPORTS_BUILD = ["mm_build_geometry", "mm_built_dims", "mm_built_export", "mm_built_destroy", "mm_contour_centroids",
+                 "mm_frames_from_flat", "mm_frames_dims", "mm_frames_export", "mm_frames_destroy",
+                 "mm_frames_finish_within", "mm_frames_postprocess_pair"]
 
 
 class MMRecord(C.Structure):
     """``mm_record`` (include/mm_build.h)."""
     _fields_ = [("frame", C.c_uint32), ("phase", C.c_uint8), ("has_m1", C.c_uint8), ("has_m2", C.c_uint8),
                 ("pad_", C.c_uint8), ("m1", C.c_double), ("m2", C.c_double)]
+
+
+class MMFlatGeometry(C.Structure):
+    """``mm_flat_geometry`` (include/mm_build.h)."""
+    _fields_ = [("g", MMGeometry), ("extra_counts", C.c_void_p), ("has_lumen_centroid", C.c_void_p),
+                ("lumen_centroid", C.c_void_p), ("aortic_thickness", C.c_void_p), ("has_aortic", C.c_void_p),
+                ("pulmonary_thickness", C.c_void_p), ("has_pulmonary", C.c_void_p), ("lumen_aortic", C.c_void_p),
+                ("wall_aortic", C.c_void_p)]
 
 
 # include/mm_ccta.h
@@ -297,6 +307,20 @@ def lib():
     L.mm_built_export.argtypes = [P, C.POINTER(MMGeometry), P, P, P, P, P, P]
     L.mm_built_destroy.restype = None
     L.mm_built_destroy.argtypes = [P]
+    L.mm_contour_centroids.restype = I
+    L.mm_contour_centroids.argtypes = [P, P, I64, P]
+    L.mm_frames_from_flat.restype = I
+    L.mm_frames_from_flat.argtypes = [C.POINTER(MMFlatGeometry), C.POINTER(P)]
+    L.mm_frames_dims.restype = I
+    L.mm_frames_dims.argtypes = [P, C.POINTER(I32), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)]
+    L.mm_frames_export.restype = I
+    L.mm_frames_export.argtypes = [P, C.POINTER(MMFlatGeometry)]
+    L.mm_frames_destroy.restype = None
+    L.mm_frames_destroy.argtypes = [P]
+    L.mm_frames_finish_within.restype = I
+    L.mm_frames_finish_within.argtypes = [P, I64, I, C.POINTER(I)]
+    L.mm_frames_postprocess_pair.restype = I
+    L.mm_frames_postprocess_pair.argtypes = [P, P, D, I]
     # include/mm_ccta.h
     L.mm_nn_min_sq_batch.restype = I
     L.mm_nn_min_sq_batch.argtypes = [P, I, P, P, I, P, P, P, P]
@@ -386,6 +410,15 @@ def filter_points_in_region(points_xyz, start_xyz, end_xyz) -> np.ndarray:
     idx = np.empty(pts.shape[0], dtype=np.int64)
     m = lib().mm_filter_points_in_region(_ptr(pts), pts.shape[0], _ptr(s), _ptr(e), _ptr(idx), pts.shape[0])
     return idx[:m].copy()
+
+
+def contour_centroids(xyz: np.ndarray, off: np.ndarray) -> np.ndarray:
+    """Contour::compute_centroid (contour.rs:213-224) of CSR contours: sequential sums / count (``mm_contour_centroids``)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    out = np.zeros((off.shape[0] - 1, 3), dtype=np.float64)
+    check(lib().mm_contour_centroids(_ptr(xyz), _ptr(off), off.shape[0] - 1, _ptr(out)), "contour_centroids")
+    return out
 
 
 def refine_downsample_count(n_filtered: int, n_points_per_frame: int, n_frames: int) -> int:

@@ -284,6 +284,16 @@ def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
     from . import frames as FR
     from . import postproc as PP
     from .centerline import with_lumen_centroids
+    if not os.environ.get("MM_PY_POSTPROC"):
+        # the product path: behind the C ABI (mm_frames_finish_within, csrc/mm_frames.cpp); the Python below is the
+        # same logic and stays as its checker (tests/test_native_frames.py)
+        from . import native_frames as NF
+        with_lumen_centroids(g)
+        h, anomalous = NF.finish_within(g, ref_idx, smooth)
+        _replace(g, h)
+        g.meta["anomalous"] = bool(anomalous)
+        g.meta["lumen_centroid_fresh"] = bool(smooth)
+        return bool(anomalous)
     hole, _ = _detect_holes(g)
     if hole:                                                                   # :136
         with_lumen_centroids(g)
@@ -361,7 +371,12 @@ def _prepare_from_paths(paths: Sequence[str], labels, n_expected, image_center, 
 
 
 def _prepare_from_inputs(inputs: Sequence[InputData], image_center, radius, n_points):
-    return [build_geometry_from_inputdata(d, None, d.label, d.diastole, image_center, radius, n_points) for d in inputs]
+    build = lambda d: build_geometry_from_inputdata(d, None, d.label, d.diastole, image_center, radius, n_points)
+    if len(inputs) > 1:              # the native builder releases the interpreter lock: the pullbacks build in parallel
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(inputs)) as ex:
+            return list(ex.map(build, inputs))
+    return [build(d) for d in inputs]
 
 
 def _write_pairs(write_obj: bool, pairs, paths, interpolation_steps: int, watertight: bool, contour_types):
@@ -393,6 +408,13 @@ def _maybe_postprocess(pair: GeometryPair, anomalous: bool, postprocessing: bool
     from . import frames as FR
     from . import postproc as PP
     from .postproc_flat import postprocess_pair_regular
+    if not os.environ.get("MM_PY_POSTPROC"):
+        from . import native_frames as NF             # mm_frames_postprocess_pair (csrc/mm_frames.cpp)
+        try:
+            a, b = NF.postprocess_pair(pair.geom_a, pair.geom_b, TOLERANCE, anomalous)
+        except RuntimeError as e:
+            raise RuntimeError(f"Failed postprocessing of {pair.label}: {e}") from e
+        return GeometryPair(a, b, pair.label)
     try:
         fast = postprocess_pair_regular(pair.geom_a, pair.geom_b, TOLERANCE, anomalous)
         if fast is not None:

@@ -192,13 +192,7 @@ def preprocess_centerline(centerline: Centerline, ref_mesh: G.FlatGeometry) -> T
 def with_lumen_centroids(g: G.FlatGeometry) -> G.FlatGeometry:
     """Contour::compute_centroid (contour.rs:213-224) for every lumen: what a PyContour carries."""
     F = g.n_frames
-    cnt = np.diff(g.lumen_off)
-    if F and cnt[0] > 0 and np.all(cnt == cnt[0]):          # equal contours: the same sequential sums, batched
-        lc = np.ascontiguousarray(np.add.accumulate(g.lumen.reshape(F, int(cnt[0]), 3), axis=1)[:, -1, :] / float(cnt[0]))
-    else:
-        lc = np.zeros((F, 3), dtype=np.float64)
-        for i in range(F):
-            lc[i] = G.contour_centroid(g.frame_lumen(i))
+    lc = N.contour_centroids(g.lumen, g.lumen_off)          # the same sequential sums, all contours in one call
     g.has_lumen_centroid = np.ones(F, dtype=np.uint8)
     g.lumen_centroids = lc
     return g

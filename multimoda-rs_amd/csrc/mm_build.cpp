@@ -317,4 +317,20 @@ int mm_built_export(const mm_built* h, mm_geometry* dst, int64_t* extra_counts, 
 
 void mm_built_destroy(mm_built* h) { delete reinterpret_cast<Built*>(h); }
 
+int mm_contour_centroids(const double* xyz, const int64_t* off, int64_t n, double* out)
+{
+    if (n < 0 || (n > 0 && (!xyz || !off || !out))) return set_error(MM_ERR_INVALID, "mm_contour_centroids: bad arguments");
+    constexpr int64_t kBlock = 64;
+    parallel_for((int)((n + kBlock - 1) / kBlock), [&](int blk) {
+        for (int64_t c = (int64_t)blk * kBlock; c < std::min(n, ((int64_t)blk + 1) * kBlock); ++c) {
+            double sx = 0.0, sy = 0.0, sz = 0.0;
+            const int64_t lo = off[c], hi = off[c + 1];
+            for (int64_t i = lo; i < hi; ++i) { sx += xyz[3 * i]; sy += xyz[3 * i + 1]; sz += xyz[3 * i + 2]; }
+            const double m = (double)(hi - lo);
+            out[3 * c] = hi > lo ? sx / m : 0.0; out[3 * c + 1] = hi > lo ? sy / m : 0.0; out[3 * c + 2] = hi > lo ? sz / m : 0.0;
+        }
+    });
+    return MM_OK;
+}
+
 }  // extern "C"

@@ -259,7 +259,7 @@ def offset_contours_batched(P: np.ndarray, distance: float) -> np.ndarray:
     arithmetic per element is that of the per-contour version (sequential centroid sums, the same
     elementwise operations), so the result is bit-identical; only the Python loop over frames is gone."""
     F, m, _ = P.shape
-    c = np.add.accumulate(P, axis=1)[:, -1, :] / float(m)                     # compute_centroid per contour
+    c = centroids_batched(P)                                                  # compute_centroid per contour
     d = P - c[:, None, :]
     ln = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
     ok = ln > F64_EPS
@@ -283,7 +283,9 @@ def smooth_batched(P: np.ndarray) -> np.ndarray:
 
 def centroids_batched(P: np.ndarray) -> np.ndarray:
     """compute_centroid (contour.rs:213-224) of F contours of equal length: sequential sums / m."""
-    return np.add.accumulate(P, axis=1)[:, -1, :] / float(P.shape[1])
+    from . import _native as N
+    F, m, _ = P.shape
+    return N.contour_centroids(np.ascontiguousarray(P).reshape(F * m, 3), np.arange(F + 1, dtype=np.int64) * m)
 
 
 # ======================================================================================
