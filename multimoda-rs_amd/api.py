@@ -440,13 +440,22 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
     b.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True         # moved last by a translation
     pair_ab = _make_pair(a.copy(), b.copy())
     pair_cd = _make_pair(c.copy(), d.copy())
+    def post_all(pairs):
+        # the pairs are independent (maybe_postprocess x4, entry.rs:282-290); the native post-processing releases
+        # the interpreter lock
+        if not postprocessing or len(pairs) < 2:
+            return [post(p) for p in pairs]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(pairs)) as ex:
+            return list(ex.map(post, pairs))
+
     if not both_batches:
-        return post(pair_ab), post(pair_cd), tuple(logs)
+        return (*post_all([pair_ab, pair_cd]), tuple(logs))
     G.align_between(eng, [(a, c), (b, d)], rng, step, sample_size)                 # entry.rs:243-277
     c.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True
     pair_ac = _make_pair(a.copy(), c.copy())
     pair_bd = _make_pair(b.copy(), d.copy())
-    return post(pair_ab), post(pair_cd), post(pair_ac), post(pair_bd), tuple(logs)
+    return (*post_all([pair_ab, pair_cd, pair_ac, pair_bd]), tuple(logs))
 
 
 def from_array_full(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData, input_data_d: InputData,
