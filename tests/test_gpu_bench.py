@@ -1,0 +1,49 @@
+"""bench.py end to end on the GPU box with a small workload: the driver's command form, the JSON contract
+(roofline + cpu_baseline objects, the extra legs agreeing with the headline result), and `--gpus 2` started
+plainly (bench.py launches its own ranks; `gloo` because two ranks share the one GPU here)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_contract_on_a_small_workload():
+    d = run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "config2", "--cpu-threads", "4"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["pose_evals_per_step"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] + 1
+    assert d["config"]["pose_evals_per_step"] > 4 * 127 * 361         # within stage + the between stage's coarse->fine evaluations
+    assert d["config"]["staged_cases_in_timed_region"] == 3          # K stagings inside the timed region
+    r = d["roofline"]
+    assert r["unit"] == "TFLOP/s" and 0 < r["frac"] <= 1.0 and 0 < r["executed_op_frac"] < r["frac"]
+    assert r["dominant_launch"]["launches"] == 3
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["bounded_search"]["identical_to_bruteforce_result"] is True
+    assert d["f64_exact"]["identical_to_headline_result"] is True and d["f64_exact"]["dtype"] == "f64"
+    assert d["sequential"]["ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("exchange", ["device", "gather"])
+def test_bench_starts_its_own_ranks(exchange):
+    d = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny", "--no-extra-legs", "--no-cpu-baseline"],
+                  {"MM_BENCH_BACKEND": "gloo", "MM_EXCHANGE": exchange, "OMP_NUM_THREADS": "4"})
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "candidate-axis x2"
+    assert d["config"]["exchange"].startswith(exchange)
