@@ -89,9 +89,10 @@ int  mm_frames_dims(const mm_frames* f, int32_t* n_frames, int64_t* n_lumen, int
 int  mm_frames_export(const mm_frames* f, mm_flat_geometry* out);
 void mm_frames_destroy(mm_frames* f);
 /* The post-steps of align_frames_in_geometry (align_within.rs:136-160) on the chain's result.  ref_idx = the
- * reference frame index taken BEFORE the chain (:42-44).  Lumen contour centroids: the mean of the points after
- * the rotation (the reference keeps the value Frame::translate left, i.e. the mean before the chain's last
- * rotation; x, y differ by that rotation, z is exact) and, with smooth, the mean of the smoothed points. */
+ * reference frame index taken BEFORE the chain (:42-44).  Lumen contour centroids are carried like the reference
+ * carries them: untouched by the rotation (Frame::rotate, frame.rs:40-63), averaged / interpolated into frames that
+ * fill holes, recomputed from the points only by smoothing (geometry.rs:204) -- i.e. with smooth == 0 they are what
+ * the chain's last Frame::translate left (mm_geometry.lumen_centroid, maintained by mm_align_within). */
 int  mm_frames_finish_within(mm_frames* f, int64_t ref_idx, int smooth, int* anomalous);
 /* postprocess_geom_pair(pair, tolerance, anomalous) (postprocessing.rs:12-87), both lists replaced */
 int  mm_frames_postprocess_pair(mm_frames* a, mm_frames* b, double tolerance, int anomalous);

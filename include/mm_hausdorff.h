@@ -240,6 +240,10 @@ typedef struct {
     double*   extra;
     uint8_t*  has_ref;     /* [F]   Frame.reference_point.is_some()    */
     double*   ref;         /* [F*3]                                    */
+    double*   lumen_centroid; /* [F*3] or NULL: Frame.lumen.centroid (Contour.centroid).  Frame::translate recomputes
+                            * it from the points (frame.rs:19-20), Frame::rotate leaves it alone (frame.rs:40-63) --
+                            * so after the chain it is the mean of a frame's lumen BEFORE the step's last rotation;
+                            * mm_frame_translate / the chain / mm_align_between maintain it when it is given.      */
 } mm_geometry;
 
 /* AlignLog (align_within.rs:14-22), returned to Python as 7-tuples (functions.rs:26-40) */

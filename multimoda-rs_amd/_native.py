@@ -62,6 +62,7 @@ class MMGeometry(C.Structure):
         ("extra", C.c_void_p),
         ("has_ref", C.c_void_p),
         ("ref", C.c_void_p),
+        ("lumen_centroid", C.c_void_p),
     ]
 
 

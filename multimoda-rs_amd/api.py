@@ -54,13 +54,15 @@ def _with_contour_centroids(g: G.FlatGeometry) -> G.FlatGeometry:
     The reference recomputes it as the mean of the points in smooth_frames (geometry.rs:204) and in
     every Frame::translate (frame.rs:20), and leaves it stale in Frame::rotate: it is the fresh mean
     after smoothing and for every geometry moved by align_between (which ends with a translation,
-    align_between.rs:68).  Otherwise (smooth=False, reference side of a pair) it is stale in the
-    reference and not tracked here: the field stays None and ``centerline.with_lumen_centroids`` is the
-    caller's choice."""
+    align_between.rs:68).  Otherwise (smooth=False, reference side of a pair) it is the value the chain's
+    last translation of the frame left -- the mean of the lumen BEFORE the step's rotation and before the
+    post-step rotation; geometries built by ``build_geometry_from_inputdata`` carry it through the chain
+    (``mm_geometry.lumen_centroid``) and the post-steps and return exactly that.  A geometry that entered
+    without contour centroids (hand-made FlatGeometry) keeps None."""
     if g.meta.get("lumen_centroid_fresh"):
         from .centerline import with_lumen_centroids
         with_lumen_centroids(g)
-    else:
+    elif g.lumen_centroids is None or not g.meta.get("lumen_centroid_tracked"):
         g.has_lumen_centroid, g.lumen_centroids = None, None
     return g
 
@@ -271,8 +273,9 @@ def _finish_within_batched(g: G.FlatGeometry, anomalous: bool, smooth: bool) -> 
     else:
         meta.pop("wall_aortic", None)
     g.meta = meta
-    g.has_lumen_centroid = np.ones(F, dtype=np.uint8)
-    g.lumen_centroids = np.ascontiguousarray(PP.centroids_batched(L))
+    if smooth or g.lumen_centroids is None:              # smooth_frames recomputes the contour centroid (geometry.rs:204)
+        g.has_lumen_centroid = np.ones(F, dtype=np.uint8)
+        g.lumen_centroids = np.ascontiguousarray(PP.centroids_batched(L))
     return True
 
 
@@ -288,15 +291,21 @@ def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
         # the product path: behind the C ABI (mm_frames_finish_within, csrc/mm_frames.cpp); the Python below is the
         # same logic and stays as its checker (tests/test_native_frames.py)
         from . import native_frames as NF
-        with_lumen_centroids(g)
+        tracked = g.lumen_centroids is not None and (g.has_lumen_centroid is None or bool(np.all(g.has_lumen_centroid)))
+        if not tracked:
+            with_lumen_centroids(g)                  # no contour centroids came in: the mean of the points stands in
         h, anomalous = NF.finish_within(g, ref_idx, smooth)
         _replace(g, h)
         g.meta["anomalous"] = bool(anomalous)
         g.meta["lumen_centroid_fresh"] = bool(smooth)
+        g.meta["lumen_centroid_tracked"] = bool(tracked)
         return bool(anomalous)
+    # ---- the same in Python (MM_PY_POSTPROC=1: the checker of the native path) ----
+    tracked = g.lumen_centroids is not None and (g.has_lumen_centroid is None or bool(np.all(g.has_lumen_centroid)))
+    if not tracked:
+        with_lumen_centroids(g)
     hole, _ = _detect_holes(g)
     if hole:                                                                   # :136
-        with_lumen_centroids(g)
         fr = PP.fill_holes(FR.to_frames(g))
         _replace(g, FR.from_frames(fr, g.label, g.meta))
     if ref_idx >= g.n_frames:
@@ -306,9 +315,8 @@ def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
     p_th = g.meta.get("pulmonary_thickness")
     anomalous = (_elliptic_ratio(lum) > 2.0 or (a_th is not None and a_th[ref_idx] is not None)
                  or (p_th is not None and p_th[ref_idx] is not None))        # align_within.rs:249-254
-    _rotate_geometry(g, _angle_ref_point_to_right(g, ref_idx, anomalous))      # :139-142
+    _rotate_geometry(g, _angle_ref_point_to_right(g, ref_idx, anomalous))      # :139-142 (contour centroids untouched)
     if not _finish_within_batched(g, anomalous, smooth):
-        with_lumen_centroids(g)
         fr = FR.to_frames(g)
         if anomalous:
             PP.assign_aortic(fr)                                               # :144-148
@@ -319,6 +327,7 @@ def _finish_within(g: G.FlatGeometry, ref_idx: int, smooth: bool) -> bool:
         _replace(g, FR.from_frames(fr, g.label, meta))
     g.meta["anomalous"] = bool(anomalous)
     g.meta["lumen_centroid_fresh"] = bool(smooth)        # geometry.rs:204
+    g.meta["lumen_centroid_tracked"] = bool(tracked)
     return bool(anomalous)
 
 

@@ -780,8 +780,7 @@ int mm_frames_finish_within(mm_frames* h, int64_t ref_idx, int smooth, int* anom
     const bool anomalous = elliptic_ratio(rf.lumen) > 2.0 || rf.lumen.has_a || rf.lumen.has_p;   // :249-254
     double rot;
     if ((rc = angle_ref_point_to_right(rf, anomalous, rot))) return rc;           // :139
-    rotate_geometry(fr, rot);                                                     // :141
-    for (FFrame& f : fr) f.lumen.compute_centroid();                              // product convention (mm_build.h)
+    rotate_geometry(fr, rot);                                                     // :141 (contour centroids stay as they are)
     if (anomalous)                                                                // :143-147 assign_aortic
         for (FFrame& f : fr) { const int64_t n = f.lumen.n(), half = n / 2; for (int64_t i = 0; i < n; ++i) f.lumen.aortic[(size_t)i] = i >= half; }
     if ((rc = create_walls(fr, anomalous))) return rc;                            // :149-153

@@ -824,7 +824,6 @@ int64_t mm_refine_downsample_count(int64_t n_filtered, int64_t n_points_per_fram
     return n;
 }
 
-// frame.rs:17-38
 // One plain decimal number [+-]digits[.digits][(e|E)[+-]digits] starting at p (end = text end); on success
 // *val is its correctly rounded double and the position after it is returned, else nullptr.
 // Clinger's fast path: a mantissa below 2^53 times or divided by an exactly representable power of ten
@@ -908,6 +907,18 @@ int64_t mm_parse_contour_table(const char* text, int64_t len, char delim, double
     return rows;
 }
 
+// Contour::compute_centroid (contour.rs:213-224) of frame i's lumen into g->lumen_centroid: sequential sums / n
+static void lumen_mean(mm_geometry* g, int32_t i)
+{
+    const int64_t lo = g->lumen_off[i], hi = g->lumen_off[i + 1];
+    if (hi <= lo) return;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int64_t k = lo; k < hi; ++k) { sx += g->lumen[3 * k]; sy += g->lumen[3 * k + 1]; sz += g->lumen[3 * k + 2]; }
+    const double n = (double)(hi - lo);
+    g->lumen_centroid[3 * i] = sx / n; g->lumen_centroid[3 * i + 1] = sy / n; g->lumen_centroid[3 * i + 2] = sz / n;
+}
+
+// frame.rs:17-38
 void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double dz)
 {
     span_translate(g->lumen, g->lumen_off[i], g->lumen_off[i + 1], dx, dy, dz);
@@ -915,6 +926,7 @@ void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double 
     if (g->extra_off) span_translate(g->extra, g->extra_off[i], g->extra_off[i + 1], dx, dy, dz);
     if (g->has_ref && g->has_ref[i]) { g->ref[3 * i] += dx; g->ref[3 * i + 1] += dy; g->ref[3 * i + 2] += dz; }
     g->centroid[3 * i] += dx; g->centroid[3 * i + 1] += dy; g->centroid[3 * i + 2] += dz;
+    if (g->lumen_centroid) lumen_mean(g, i);   // frame.rs:19-20: self.lumen.compute_centroid()
 }
 
 // frame.rs:40-63
@@ -1308,6 +1320,7 @@ int mm_align_between(mm_engine* eh, int n_pairs, mm_geometry** a, mm_geometry** 
             if (B->cath_off) for (int64_t k = B->cath_off[i]; k < B->cath_off[i + 1]; ++k) mv(B->cath + 3 * k);
             if (B->extra_off) for (int64_t k = B->extra_off[i]; k < B->extra_off[i + 1]; ++k) mv(B->extra + 3 * k);
             if (B->has_ref && B->has_ref[i]) mv(B->ref + 3 * i);
+            if (B->lumen_centroid) lumen_mean(B, i);   // the move ends with Frame::translate (:68): recomputed
         }
     };
     {

@@ -186,6 +186,7 @@ class FlatGeometry:
     def c_struct(self) -> N.MMGeometry:
         """Borrowed view for the C ABI (arrays stay owned by this object)."""
         self._validate()
+        F = self.n_frames
         g = N.MMGeometry()
         p = N._ptr
         g.n_frames = self.n_frames
@@ -196,6 +197,12 @@ class FlatGeometry:
         g.cath_off = p(self.cath_off); g.cath = p(self.cath)
         g.extra_off = p(self.extra_off); g.extra = p(self.extra)
         g.has_ref = p(self.has_ref); g.ref = p(self.ref)
+        # Frame.lumen.centroid, tracked through translations when every frame carries one
+        lc = self.lumen_centroids
+        if lc is not None and (self.has_lumen_centroid is None or bool(np.all(self.has_lumen_centroid))):
+            if lc.dtype != np.float64 or lc.shape != (F, 3) or not lc.flags.c_contiguous:
+                raise ValueError("FlatGeometry.lumen_centroids: expected C-contiguous float64 (F,3)")
+            g.lumen_centroid = p(lc)
         return g
 
 

@@ -362,6 +362,9 @@ def _build_geometry_native(d: InputData, label: str, image_center, radius: float
         N.check(L.mm_built_export(h, C.byref(st), p(counts), p(a_th), p(has_a), p(p_th), p(has_p), p(fl_out)), "mm_built_export")
     finally:
         L.mm_built_destroy(h)
+    # Contour.centroid of every lumen as the builder leaves it: compute_centroid at build.rs:113 (the value the frame
+    # centroid is copied from), z rewritten together with the frame's (geometry.rs:119-121,361-363)
+    g.has_lumen_centroid, g.lumen_centroids = np.ones(F, dtype=np.uint8), g.centroids.copy()
     g.meta["extra_counts"] = {"eem": counts[:, 0].copy(), "calcification": counts[:, 1].copy(),
                               "sidebranch": counts[:, 2].copy(), "wall": np.zeros(F, dtype=np.int64)}
     if fl_out is not None and fl_out.any():
@@ -500,6 +503,7 @@ def _to_flat(flist: Sequence[_Frame], label: str) -> FlatGeometry:
             off[i + 1] = off[i] + tot
         g.extra_off = off
         g.extra = np.ascontiguousarray(np.concatenate(chunks, axis=0))
+    g.has_lumen_centroid, g.lumen_centroids = np.ones(F, dtype=np.uint8), g.centroids.copy()
     g.meta["extra_counts"] = counts
     if any(fr.lumen_aortic is not None and fr.lumen_aortic.any() for fr in flist):
         g.meta["lumen_aortic"] = np.concatenate([fr.lumen_aortic if fr.lumen_aortic is not None

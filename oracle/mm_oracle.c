@@ -303,6 +303,12 @@ void orc_frame_translate(orc_geometry* g, int32_t i, double dx, double dy, doubl
     g->centroid[3 * i + 0] += dx;                                                   /* :35-37 */
     g->centroid[3 * i + 1] += dy;
     g->centroid[3 * i + 2] += dz;
+    if (g->lumen_centroid && g->lumen_off[i + 1] > g->lumen_off[i]) {               /* :20 self.lumen.compute_centroid() */
+        double sx = 0.0, sy = 0.0, sz = 0.0;                                        /* contour.rs:219-223: sequential fold */
+        for (int64_t k = g->lumen_off[i]; k < g->lumen_off[i + 1]; ++k) { sx += g->lumen[k].x; sy += g->lumen[k].y; sz += g->lumen[k].z; }
+        const double n = (double)(g->lumen_off[i + 1] - g->lumen_off[i]);
+        g->lumen_centroid[3 * i] = sx / n; g->lumen_centroid[3 * i + 1] = sy / n; g->lumen_centroid[3 * i + 2] = sz / n;
+    }
 }
 
 void orc_frame_rotate(orc_geometry* g, int32_t i, double angle, double cx, double cy)

@@ -60,6 +60,8 @@ typedef struct {
     orc_point* extra;
     uint8_t*   has_ref;     /* [F]   Frame.reference_point.is_some()            */
     orc_point* ref;         /* [F]                                              */
+    double*    lumen_centroid; /* [F*3] or NULL: Frame.lumen.centroid -- recomputed by Frame::translate
+                             * (frame.rs:19-20), untouched by Frame::rotate (frame.rs:40-63)        */
 } orc_geometry;
 
 /* ---- process_utils.rs ------------------------------------------------------------ */

@@ -70,6 +70,7 @@ class _Geometry(C.Structure):
         ("extra", C.c_void_p),
         ("has_ref", C.c_void_p),
         ("ref", C.c_void_p),
+        ("lumen_centroid", C.c_void_p),
     ]
 
 
@@ -334,6 +335,9 @@ class OracleGeometry:
         g.extra = _p(self.extra)
         g.has_ref = _p(self.has_ref)
         g.ref = _p(self.ref)
+        if self.lumen_centroids is not None and (self.has_lumen_centroid is None or bool(np.all(self.has_lumen_centroid))):
+            assert self.lumen_centroids.dtype == np.float64 and self.lumen_centroids.flags.c_contiguous
+            g.lumen_centroid = _p(self.lumen_centroids)        # Frame.lumen.centroid, tracked through translations
         return g
 
 

@@ -231,5 +231,10 @@ def build_geometry(path, diastole, image_center=(4.5, 4.5), radius=0.5, n_points
 def oracle_geometry(orc, path, diastole, label="", **kw):
     """The oracle's geometry container filled from the independent builder."""
     b = build_geometry(path, diastole, **kw)
-    return orc.OracleGeometry.from_frames(b["lumens"], catheters=b["catheters"], centroids=b["centroids"], ids=b["ids"],
-                                          orig_frames=b["orig_frames"], ref_points=b["ref_points"], label=label)
+    og = orc.OracleGeometry.from_frames(b["lumens"], catheters=b["catheters"], centroids=b["centroids"], ids=b["ids"],
+                                        orig_frames=b["orig_frames"], ref_points=b["ref_points"], label=label)
+    # Frame.lumen.centroid as the builder leaves it: the value the frame centroid was copied from (build.rs:113-117),
+    # its z rewritten together with the frame's (geometry.rs:119-121,361-363)
+    og.lumen_centroids = og.centroids.copy()
+    og.has_lumen_centroid = np.ones(og.n_frames, dtype=np.uint8)
+    return og

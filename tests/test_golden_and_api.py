@@ -244,3 +244,53 @@ def test_config1_example_data_singlepair_matches_oracle(engine, mm, oracle, brut
         og = refbuild.oracle_geometry(oracle, path, dia, "x")
         assert list(logs) == oracle.align_within_chain(og, 0.5, 90.0, bruteforce, 500, n_threads=8)
     assert len(logs_d) == 19 and len(logs_s) == 16
+
+
+# ---------------------------------------------------------------------------------------
+# Frame.lumen.centroid: recomputed by Frame::translate, left alone by Frame::rotate (frame.rs:17-63)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("folder", ["idealized_geometry", "examples_ivus_rest"])
+def test_lumen_contour_centroid_is_carried_like_the_reference(engine, mm, oracle, folder, mode):
+    """After the chain a frame's lumen.centroid is the mean of its lumen BEFORE the step's rotation (the last
+    Frame::translate computed it); align_between ends with a translation, so the moved geometry carries fresh
+    means.  Product (mm_geometry.lumen_centroid through mm_align_within / mm_align_between) against the oracle's
+    restatement fed by the independent builder, bit for bit."""
+    import refbuild
+    path = os.path.join(GOLD, folder)
+    ga = mm.build_geometry_from_inputdata(None, path, "x", True)
+    gb = mm.build_geometry_from_inputdata(None, path, "x", False)
+    oa = refbuild.oracle_geometry(oracle, path, True, "x")
+    ob = refbuild.oracle_geometry(oracle, path, False, "x")
+    assert np.array_equal(ga.lumen_centroids, oa.lumen_centroids) and np.array_equal(ga.lumen_centroids, ga.centroids)
+    mm.align_within(engine, [ga, gb], 0.5, 90.0, False, 500, mode=mode)
+    for o in (oa, ob):
+        oracle.align_within_chain(o, 0.5, 90.0, False, 500, n_threads=8)
+    for g, o in ((ga, oa), (gb, ob)):
+        assert np.array_equal(g.lumen_centroids, o.lumen_centroids)
+        assert np.array_equal(g.lumen_centroids[0], g.centroids[0])          # frame 0 is never translated
+        fresh = np.array([mm.contour_centroid(g.frame_lumen(i)) for i in range(g.n_frames)])
+        assert not np.array_equal(g.lumen_centroids[1:, :2], fresh[1:, :2])   # stale in x, y ...
+        assert np.allclose(g.lumen_centroids[:, 2], fresh[:, 2], atol=1e-9)   # ... z agrees up to the mean's rounding
+    mm.align_between(engine, [(ga, gb)], 90.0, 0.5, 500)
+    oracle.align_between(oa, ob, 90.0, 0.5, 500, n_threads=8)
+    assert np.array_equal(gb.lumen_centroids, ob.lumen_centroids)
+    assert np.array_equal(gb.lumen_centroids, np.array([mm.contour_centroid(gb.frame_lumen(i)) for i in range(gb.n_frames)]))
+    assert np.array_equal(ga.lumen_centroids, oa.lumen_centroids)             # the reference side is not touched
+
+
+@pytest.mark.gpu
+def test_from_file_single_without_smoothing_returns_the_tracked_centroid(engine, mm, oracle):
+    """smooth = False: the returned Frame.lumen.centroid is what the chain left, untouched by the post-step rotation
+    (geometry.rs:241-250 -> Frame::rotate); smooth = True: the mean of the smoothed points (geometry.rs:204)."""
+    import refbuild
+    path = os.path.join(GOLD, "idealized_geometry")
+    g, _logs = mm.from_file_single(path, diastole=True, step_rotation_deg=0.5, range_rotation_deg=90.0, smooth=False,
+                                   write_obj=False, engine=engine)
+    o = refbuild.oracle_geometry(oracle, path, True, "x")
+    oracle.align_within_chain(o, 0.5, 90.0, False, 500, n_threads=8)
+    assert g.lumen_centroids is not None and np.array_equal(g.lumen_centroids, o.lumen_centroids)
+    s, _ = mm.from_file_single(path, diastole=True, step_rotation_deg=0.5, range_rotation_deg=90.0, smooth=True,
+                               write_obj=False, engine=engine)
+    assert np.array_equal(s.lumen_centroids, np.array([mm.contour_centroid(s.frame_lumen(i)) for i in range(s.n_frames)]))

@@ -149,8 +149,10 @@ def test_from_file_pair_then_align_manual(engine, oracle, ocl, mm):
         assert g.ids.tolist() == list(range(g.n_frames)) and g.has_ref.sum() == 1
         assert g.meta["extra_counts"]["wall"].tolist() == [int(g.lumen_off[1])] * g.n_frames
         assert np.allclose(g.lumen_centroids, [mm.contour_centroid(g.frame_lumen(i)) for i in range(g.n_frames)], atol=1e-9)
-    nocen, _ = mm.from_file_single(gold, smooth=False, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
-    assert nocen.lumen_centroids is None                         # stale in the reference, not tracked here
+    stale, _ = mm.from_file_single(gold, smooth=False, step_rotation_deg=1.0, range_rotation_deg=30.0, engine=engine)
+    # smooth = False: Frame.lumen.centroid is what the chain's last Frame::translate left (the reference never recomputes it
+    # after that); carried exactly -- see test_golden_and_api.py::test_lumen_contour_centroid_is_carried_like_the_reference
+    assert stale.lumen_centroids is not None and np.array_equal(stale.lumen_centroids[0], stale.centroids[0])
     a = pair.geom_a
     s = np.arange(0.0, 40.0, 0.25)
     cl = mm.Centerline.from_contour_points(np.stack([20.0 + 4.0 * np.sin(s / 11.0), -150.0 + 0.2 * s, 900.0 - 0.9 * s], axis=1))

@@ -46,11 +46,10 @@ def python_finish(mm, g, ref_idx, smooth, monkeypatch):
 
 
 def native_finish(mm, g, ref_idx, smooth):
-    from multimoda_rs_amd import native_frames as NF
-    from multimoda_rs_amd.centerline import with_lumen_centroids
+    from multimoda_rs_amd import api
     h = g.copy()
-    with_lumen_centroids(h)
-    return NF.finish_within(h, ref_idx, smooth)
+    an = api._finish_within(h, ref_idx, smooth)          # the product path: mm_frames_finish_within
+    return h, an
 
 
 def variants(mm):
