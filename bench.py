@@ -77,14 +77,17 @@ def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     return logs, rot, evals + e2, unresolved
 
 
-def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2):
+def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None):
     """Run steps `ks`: search(k) then finish(k), and -- if `stage` is given -- stage(k + lookahead) after
     finish(k) (the caller has staged the first `lookahead` steps of `ks` itself: priming), so a call over K steps
     does K stagings, K searches and K finishes.
     pipelined: steps are independent cases, so the search of step k+1 (the GPU-heavy half, and the only half with
     collectives) overlaps the chain walk and between alignment of step k and the staging of step k+2 on a second
     host thread; step k lives on engine k % 2, so step k+2 is staged only after step k is finished, and searched
-    only after it is staged.  Every step's work completes inside the call."""
+    only after it is staged.  Every step's work completes inside the call.
+    begin (optional, pipelined only): the search split in two -- begin(k, prev) enqueues step k's launch behind step
+    prev's long kernel and returns, search(k) then only collects -- so that step k+1 is already queued on the
+    device when step k's launch ends: the device does not idle while the host fetches, commits and launches."""
     ks = list(ks)
     if not pipelined:
         out = []
@@ -117,12 +120,25 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2):
     th = threading.Thread(target=worker, name="bench-finish")
     th.start()
     try:
+        if begin is not None and ks:
+            begin(ks[0], None)
         for i, k in enumerate(ks):
-            if i >= 2:
-                done[ks[i - 2]].wait()    # step k shares its engine with step k-2: that one must be finished
-            if err:
-                break
-            search(k)
+            if begin is None:
+                if i >= 2:
+                    done[ks[i - 2]].wait()    # step k shares its engine with step k-2: that one must be finished
+                if err:
+                    break
+                search(k)
+            else:
+                if i + 1 < len(ks):
+                    if i >= 1:
+                        done[ks[i - 1]].wait()    # step k+1 shares its engine with step k-1 (finished, and k+1 staged)
+                    if err:
+                        break
+                    begin(ks[i + 1], k)           # queued on the device behind step k's long kernel
+                if err:
+                    break
+                search(k)                         # collect step k (waits for its kernels), remaining levels, commit
             q.put(k)
     finally:
         q.put(None)
@@ -231,9 +247,17 @@ class Runner:
         self.stage_s += time.perf_counter() - t0
         self.staged += 1
 
+    def begin(self, k, prev):
+        """world == 1: enqueue step k's search behind step prev's long kernel (Engine.wait_search) and return."""
+        if self.plans[k] is not None and self.ext is None:
+            self.plans[k].search_begin(after=None if prev is None else self.engs[prev % 2])
+
     def search(self, k):
         if self.plans[k] is not None and self.ext is None:
-            self.plans[k].search()                       # levels: local search -> exchange -> commit
+            if getattr(self.plans[k], "_begun", False):
+                self.plans[k].search_end()               # collect level 0, remaining levels, commit
+            else:
+                self.plans[k].search()                   # levels: local search -> exchange -> commit
 
     def finish(self, k):
         mm, cfg = self.mm, self.cfg
@@ -371,7 +395,8 @@ def main():
         r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK)
         for k in range(LOOK):
             r.stage(k)                                   # priming (setup, untimed)
-        run_steps(range(warmup), r.search, r.finish, pipe, r.stage, LOOK)
+        begin = r.begin if (pipe and world == 1 and mode == 1 and ext is None and not os.environ.get("MM_BENCH_NO_LOOKAHEAD")) else None
+        run_steps(range(warmup), r.search, r.finish, pipe, r.stage, LOOK, begin)
         barrier()
         for e in engs:
             e.profile(True)
@@ -380,7 +405,7 @@ def main():
         gc.collect()
         gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
         t0 = time.perf_counter()
-        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, r.stage, LOOK)
+        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, r.stage, LOOK, begin)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -492,7 +517,10 @@ def main():
                        "step_pipeline": ("3 pieces per step over consecutive (independent) cases: search of step k+1 || chain "
                                          "walk + between alignment of step k, then staging of step k+2 (second host thread; "
                                          "engine k % 2; staging and the small kernels on a high-priority stream); K stagings, K "
-                                         "searches, K finishes inside the timed region, the pipeline primed before it") if pipelined else "sequential"},
+                                         "searches, K finishes inside the timed region, the pipeline primed before it"
+                                         + ("; step k+1's launch is queued on the device behind step k's long kernel "
+                                            "(mm_engine_wait_search), so the device does not idle across the hand-over" if world == 1 else "")
+                                         ) if pipelined else "sequential"},
             "roofline": {
                 "bound": "valu", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak,

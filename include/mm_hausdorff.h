@@ -89,6 +89,12 @@ int  mm_engine_create(int device, void* stream, mm_engine** out);
 void mm_engine_destroy(mm_engine* e);
 int  mm_engine_synchronize(mm_engine* e);
 void* mm_engine_stream(mm_engine* e);
+/* Order `waiter`'s main stream behind the dominant (long) kernel of the search most recently enqueued on `other`
+ * (same device): whatever is enqueued on `waiter` next starts when that launch ends, beside the short tail of
+ * `other`'s search (shortlist, re-score, argmin, result copy).  A driver that aligns independent cases back to back
+ * uses it to keep the device busy across the hand-over: launch case k+1, then collect case k.  No-op if `other` has
+ * not searched yet. */
+int  mm_engine_wait_search(mm_engine* waiter, mm_engine* other);
 
 /* Per-launch timing of the dominant (candidate-scoring) kernel with hipEvents recorded on
  * the engine's stream around every launch.  mm_engine_profile_read synchronizes, returns
@@ -306,6 +312,9 @@ int  mm_within_plan_create_sharded(mm_engine* e, int n_geoms, mm_geometry** geom
 int  mm_within_plan_dims(mm_within_plan* p, int32_t* n_jobs, int32_t* n_levels, double* tol);
 int  mm_within_plan_level_local(mm_within_plan* p, int level, double* cost, int32_t* uniform,
                                 double* angle, int32_t* idx, int32_t* active);
+/* level_local == level_launch (below; asynchronous) + level_collect (waits, copies the per-job records out) */
+int  mm_within_plan_level_collect(mm_within_plan* p, int level, double* cost, int32_t* uniform,
+                                  double* angle, int32_t* idx, int32_t* active);
 int  mm_within_plan_level_commit(mm_within_plan* p, int level, const uint8_t* ok, const double* angle);
 int  mm_within_plan_walk(mm_within_plan* p, mm_alignlog** logs, int64_t* pose_evals,
                          int64_t* n_unresolved);

@@ -24,7 +24,7 @@ MM_SEARCH_SKIP_ZERO = 1
 
 EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
-    "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream",
+    "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream", "mm_engine_wait_search",
     "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches", "mm_engine_bound_stats",
     "mm_engine_set_bound_min_candidates",
     "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
@@ -33,7 +33,7 @@ EXPORTS = [
     "mm_plan_result_dev", "mm_plan_time", "mm_plan_stats",
     "mm_align_within", "mm_align_between", "mm_within_plan_create", "mm_within_plan_create_sharded", "mm_within_plan_run", "mm_within_plan_destroy", "mm_within_plan_fetch_set",
     "mm_within_plan_set_shard", "mm_within_plan_dims", "mm_within_plan_level_local", "mm_within_plan_level_commit",
-    "mm_within_plan_walk", "mm_within_plan_level_launch", "mm_within_plan_level_export_cost",
+    "mm_within_plan_walk", "mm_within_plan_level_collect", "mm_within_plan_level_launch", "mm_within_plan_level_export_cost",
     "mm_within_plan_level_export_keys", "mm_within_plan_level_commit_dev", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
     "mm_frame_translate", "mm_frame_rotate", "mm_parse_contour_table",
 ]
@@ -183,6 +183,8 @@ def lib():
     L.mm_engine_synchronize.argtypes = [P]
     L.mm_engine_stream.restype = P
     L.mm_engine_stream.argtypes = [P]
+    L.mm_engine_wait_search.restype = I
+    L.mm_engine_wait_search.argtypes = [P, P]
     L.mm_engine_profile.restype = I
     L.mm_engine_profile.argtypes = [P, I]
     L.mm_engine_profile_read.restype = I
@@ -247,6 +249,8 @@ def lib():
     L.mm_within_plan_dims.argtypes = [P, C.POINTER(I32), C.POINTER(I32), P]
     L.mm_within_plan_level_local.restype = I
     L.mm_within_plan_level_local.argtypes = [P, I, P, P, P, P, P]
+    L.mm_within_plan_level_collect.restype = I
+    L.mm_within_plan_level_collect.argtypes = [P, I, P, P, P, P, P]
     L.mm_within_plan_level_commit.restype = I
     L.mm_within_plan_level_commit.argtypes = [P, I, P, P]
     L.mm_within_plan_fetch_set.restype = I64
@@ -504,6 +508,11 @@ class Engine:
 
     def synchronize(self):
         check(lib().mm_engine_synchronize(self._h), "mm_engine_synchronize")
+
+    def wait_search(self, other: "Engine"):
+        """Whatever this engine enqueues next on its main stream starts when `other`'s most recent search launch
+        ends (``mm_engine_wait_search``)."""
+        check(lib().mm_engine_wait_search(self._h, other._h), "mm_engine_wait_search")
 
     def profile(self, enable: bool = True):
         """hipEvent timing around every launch of the scoring kernel (mm_engine_profile)."""

@@ -447,6 +447,7 @@ int Plan::run(bool screen_only)
             if (e != hipSuccess) return hip_error(e, "screen kernel launch");
             if ((prc = eng->profile_end(s, pair_evals, A))) return prc;
         }
+        if ((prc = mark_search_done())) return prc;
         if (screen_only) return MM_OK;
         MM_HIP(hipMemsetAsync(dev.n_items, 0, 16, s));
         e = launch_shortlist(dev, s);
@@ -460,10 +461,20 @@ int Plan::run(bool screen_only)
         e = launch_exact_all(dev, max_na, max_nbp, s);
         if (e != hipSuccess) return hip_error(e, "exact kernel launch");
         if ((prc = eng->profile_end(s, pair_evals, A))) return prc;
+        if ((prc = mark_search_done())) return prc;
         if (screen_only) return MM_OK;
         e = launch_finalize(dev, 0, s);
         if (e != hipSuccess) return hip_error(e, "finalize kernel launch");
     }
+    return MM_OK;
+}
+
+int Plan::mark_search_done()
+{
+    if (transient) return MM_OK;
+    if (!eng->search_done) MM_HIP(hipEventCreateWithFlags(&eng->search_done, hipEventDisableTiming));
+    MM_HIP(hipEventRecord(eng->search_done, stream));
+    eng->search_done_recorded = true;
     return MM_OK;
 }
 
@@ -824,6 +835,7 @@ void mm_engine_destroy(mm_engine* h)
     for (Engine::Buf* b : {&e->dev_pts, &e->dev_lvl, &e->dev_raw}) if (b->p) (void)hipFree(b->p);
     for (Engine::Buf& b : e->blob_cache) (void)hipFree(b.p);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->search_done) (void)hipEventDestroy(e->search_done);
     if (e->dev_stats) (void)hipFree(e->dev_stats);
     if (e->own_aux) (void)hipStreamDestroy(e->aux);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -836,6 +848,16 @@ int mm_engine_synchronize(mm_engine* h)
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     MM_HIP(hipSetDevice(e->device));
     if (int src = e->sync_all()) return src;
+    return MM_OK;
+}
+
+int mm_engine_wait_search(mm_engine* waiter, mm_engine* other)
+{
+    Engine *w = reinterpret_cast<Engine*>(waiter), *o = reinterpret_cast<Engine*>(other);
+    if (!w || !o) return set_error(MM_ERR_INVALID, "engine == NULL");
+    if (w->device != o->device) return set_error(MM_ERR_INVALID, "mm_engine_wait_search: engines on different devices");
+    MM_HIP(hipSetDevice(w->device));
+    if (o->search_done_recorded) MM_HIP(hipStreamWaitEvent(w->stream, o->search_done, 0));
     return MM_OK;
 }
 

@@ -31,6 +31,11 @@ struct Engine {
     // 30 ms launch.  Equals `stream` when the caller supplied the stream.
     hipStream_t aux = nullptr;
     bool own_aux = false;
+    // recorded on `stream` right after the dominant kernel of a resident plan's search: another engine's stream can
+    // wait for it (mm_engine_wait_search) and start ITS search exactly when this one's long launch ends, while the
+    // short tail (shortlist, re-score, argmin, fetch) and the host work of this case proceed beside it
+    hipEvent_t search_done = nullptr;
+    bool search_done_recorded = false;
     Buf host_pts, host_lvl;   // pinned staging: point pool / level (+ results)
     Buf dev_pts, dev_lvl;     // device buffers of transient plans
     Buf dev_raw;              // raw pullbacks of a within-plan while its search sets are built on the device
@@ -127,6 +132,7 @@ struct Plan {
     int stage_level(const std::vector<PairSpec>& pairs, int precision, int32_t angle_begin, int32_t angle_end,
                     bool want_costs, hipStream_t st = nullptr);
     int run(bool screen_only);
+    int mark_search_done();   // resident plans: record Engine::search_done behind the dominant kernel
     int fetch(BatchResult& out, double* all_costs_plan_order);
     size_t hbm_bytes() const { return pts_bytes + lvl_bytes; }
     std::vector<int32_t> pair_slice_end;      // per pair: end of the candidate slice this plan owns

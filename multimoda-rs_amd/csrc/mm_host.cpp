@@ -286,6 +286,7 @@ struct WithinPlan {
     int build_sets_device(int32_t n_sets);
     int level_launch(size_t l);
     int level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
+    int level_collect(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
     int level_commit(size_t l, const uint8_t* ok, const double* angle);
     int level_export_cost(size_t l, double* cost_dev);
     int level_export_keys(size_t l, const double* gcost_dev, long long* keys_dev);
@@ -524,13 +525,25 @@ int WithinPlan::level_launch(size_t l)
 
 int WithinPlan::level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active)
 {
+    int rc;
+    {
+        TraceTimer t("within: search kernels (launch)");
+        if ((rc = level_launch(l))) return rc;
+    }
+    return level_collect(l, cost, uniform, angle, idx, active);
+}
+
+// The fetch half of level_local: waits for the level enqueued by level_launch and fills the per-job records.
+int WithinPlan::level_collect(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active)
+{
+    (void)l;
+    if (!searched) return set_error(MM_ERR_INVALID, "level_collect before level_launch");
     const int J = (int)job_geom.size();
     for (int j = 0; j < J; ++j) { cost[j] = INFINITY; uniform[j] = 1; angle[j] = 0.0; idx[j] = -1; active[j] = 0; }
     int rc;
     BatchResult res;
     {
-        TraceTimer t("within: search kernels");
-        if ((rc = level_launch(l))) return rc;
+        TraceTimer t("within: search kernels (wait + fetch)");
         if (lvl_active.empty()) return MM_OK;
         if ((rc = plan.fetch(res, nullptr))) return rc;
     }
@@ -1175,6 +1188,15 @@ int mm_within_plan_level_commit_dev(mm_within_plan* h, int level, const double* 
         return set_error(MM_ERR_INVALID, "bad level / buffer");
     if (int drc = select_device(wp->e)) return drc;
     return wp->level_commit_dev((size_t)level, gcost_dev, (const long long*)keys_dev);
+}
+
+int mm_within_plan_level_collect(mm_within_plan* h, int level, double* cost, int32_t* uniform, double* angle,
+                                 int32_t* idx, int32_t* active)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
+    if (int drc = select_device(wp->e)) return drc;
+    return wp->level_collect((size_t)level, cost, uniform, angle, idx, active);
 }
 
 int mm_within_plan_level_commit(mm_within_plan* h, int level, const uint8_t* ok, const double* angle)

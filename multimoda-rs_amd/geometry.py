@@ -292,6 +292,33 @@ class WithinPlan:
                 "mm_within_plan_level_local")
         return out
 
+    def level_collect(self, level: int, n_jobs: int):
+        """The fetch half of level_local (after level_launch)."""
+        out = {"cost": np.zeros(n_jobs), "uniform": np.zeros(n_jobs, dtype=np.int32), "angle": np.zeros(n_jobs),
+               "idx": np.zeros(n_jobs, dtype=np.int32), "active": np.zeros(n_jobs, dtype=np.int32)}
+        N.check(N.lib().mm_within_plan_level_collect(self._h, int(level), N._ptr(out["cost"]), N._ptr(out["uniform"]),
+                                                     N._ptr(out["angle"]), N._ptr(out["idx"]), N._ptr(out["active"])),
+                "mm_within_plan_level_collect")
+        return out
+
+    def search_begin(self, after: Optional[N.Engine] = None):
+        """Single rank: enqueue level 0 of the search and return at once; ``search_end`` collects it and runs the
+        remaining levels.  after = an engine whose current search this one's launch should follow on the device
+        (``Engine.wait_search``): the launch then starts when that one's long kernel ends, beside its short tail."""
+        if after is not None and after is not self.engine:
+            self.engine.wait_search(after)
+        self.level_launch(0)
+        self._begun = True
+
+    def search_end(self):
+        from . import distributed as D
+        n_jobs, n_levels, tol = self.dims()
+        for l in range(n_levels):
+            local = self.level_collect(l, n_jobs) if (l == 0 and getattr(self, "_begun", False)) else self.level_local(l, n_jobs)
+            ok, angle, _idx, _cost = D.merge_shards(1, local["cost"], local["uniform"], local["angle"], local["idx"], tol)
+            self.level_commit(l, ok, angle)
+        self._begun = False
+
     def level_commit(self, level: int, ok: np.ndarray, angle: np.ndarray):
         ok = np.ascontiguousarray(ok, dtype=np.uint8)
         angle = np.ascontiguousarray(angle, dtype=np.float64)

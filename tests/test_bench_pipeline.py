@@ -71,3 +71,41 @@ def test_an_error_in_the_finishing_thread_reaches_the_caller(run_steps):
 
     with pytest.raises(ValueError, match="boom"):
         run_steps(range(5), lambda k: time.sleep(0.001), finish, True)
+
+
+def test_split_search_queues_the_next_step_before_collecting_this_one(run_steps):
+    """begin(k+1, k) is issued before search(k) collects, after step k-1 is finished (engine k+1 mod 2 is free) --
+    and every step is begun exactly once, in order."""
+    log, lock = [], threading.Lock()
+
+    def begin(k, prev):
+        with lock:
+            log.append(("b", k, prev))
+
+    def search(k):
+        time.sleep(0.003)
+        with lock:
+            log.append(("s", k))
+
+    def finish(k):
+        time.sleep(0.001)
+        with lock:
+            log.append(("f", k))
+        return k
+
+    def stage(k):
+        with lock:
+            log.append(("st", k))
+
+    out = run_steps(range(3, 10), search, finish, True, stage, 2, begin)
+    assert out == list(range(3, 10))
+    pos = {e[:2]: i for i, e in enumerate(log)}
+    begun = [e for e in log if e[0] == "b"]
+    assert [e[1] for e in begun] == list(range(3, 10)) and begun[0][2] is None and all(e[2] == e[1] - 1 for e in begun[1:])
+    for k in range(3, 10):
+        assert pos[("b", k)] < pos[("s", k)] < pos[("f", k)]
+        if k + 1 < 10:
+            assert pos[("b", k + 1)] < pos[("s", k)]                 # the next launch is queued before this one is collected
+        if k + 2 < 10:
+            assert pos[("f", k)] < pos[("b", k + 2)]                 # steps k and k+2 share an engine
+            assert pos[("st", k + 2)] < pos[("b", k + 2)]            # and k+2 is staged before it is begun
