@@ -212,9 +212,9 @@ void orc_find_points_by_cl_region(const orc_clpoint* cl, const uint32_t* cl_fram
             if (sq_dist(centroids[3 * f], centroids[3 * f + 1], centroids[3 * f + 2], cl[k].x, cl[k].y, cl[k].z) <= mean_dz * mean_dz)
                 sel[k] = 1;
     const double* dref = centroids + 3 * (n_frames - 1);           /* :279 */
-    orc_point* prox = (orc_point*)malloc((n ? n : 1) * sizeof(orc_point));
-    orc_point* dist = (orc_point*)malloc((n ? n : 1) * sizeof(orc_point));
-    orc_point* betw = (orc_point*)malloc((n ? n : 1) * sizeof(orc_point));
+    orc_point* prox = (orc_point*)calloc(n ? n : 1, sizeof(orc_point));
+    orc_point* dist = (orc_point*)calloc(n ? n : 1, sizeof(orc_point));
+    orc_point* betw = (orc_point*)calloc(n ? n : 1, sizeof(orc_point));
     size_t* ip = (size_t*)malloc((n ? n : 1) * sizeof(size_t));
     size_t* id = (size_t*)malloc((n ? n : 1) * sizeof(size_t));
     size_t np = 0, nd = 0, nb = 0;
