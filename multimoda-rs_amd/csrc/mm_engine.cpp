@@ -13,6 +13,7 @@
 // call on linux-gnu) and shared by pairs with identical candidate lists.
 #include "mm_engine.h"
 #include "mm_pool.h"
+#include "mm_trace.h"
 
 #include <algorithm>
 #include <cmath>
@@ -219,6 +220,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     const bool expanded = precision == MM_PRECISION_F32_FAST || precision == MM_PRECISION_F32_BOUNDED;
     if (angle_begin < 0) angle_begin = 0;
 
+    TraceTimer tt_desc("stage_level: descriptors");
     host_pairs.assign(P, PairDesc{});
     trivial.assign(P, 0);
     pair_slice_end.assign(P, 0);
@@ -296,22 +298,36 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         return set_error(MM_ERR_TOO_LARGE, "target set does not fit the kernel's LDS budget (" +
                                                std::to_string(max_target_points_f64()) + " points)");
 
+    tt_desc.stop();
+    TraceTimer tt_work("stage_level: work list");
     // ---- work decomposition: one workgroup = `apb` consecutive candidates of one pair ----
     const int64_t target_wgs = 256 * 24;
     // at most 8 candidates per workgroup: measured on config3 (apb 2/4/8/16/64/128: 140.6/145.0/146.3/
     // 144.6/138.2/122.3 TFLOP/s) -- many short workgroups keep the co-resident ones out of phase
     // (rotation / epilogue of one overlaps the micro-tile loop of the others) and balance the tail
     int apb = (int)std::min<int64_t>(8, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
-    host_work.clear();
-    for (int p = 0; p < P; ++p) {
+    {
         // balanced chunks: ceil(n / apb) workgroups whose sizes differ by at most one (a 90-candidate
-        // slice is 12 x 7-8 candidates, not 11 x 8 + 2: the short tail would cost a full staging)
-        const PairDesc& d = host_pairs[p];
-        const int nw = (d.n_ang + apb - 1) / apb;
-        for (int k = 0; k < nw; ++k) {
-            const int a0 = (int)((int64_t)d.n_ang * k / nw), a1 = (int)((int64_t)d.n_ang * (k + 1) / nw);
-            host_work.push_back(WorkItem{p, a0, a1 - a0, 0});
-        }
+        // slice is 12 x 7-8 candidates, not 11 x 8 + 2: the short tail would cost a full staging).
+        // 186 k items for config3: sized by a prefix sum and filled over the worker pool (one push_back at a time
+        // this was half of a case's staging time)
+        std::vector<int64_t> wstart((size_t)P + 1, 0);
+        for (int p = 0; p < P; ++p) wstart[(size_t)p + 1] = wstart[(size_t)p] + (host_pairs[p].n_ang + apb - 1) / apb;
+        if (wstart[(size_t)P] > INT32_MAX) return set_error(MM_ERR_TOO_LARGE, "too many work items");
+        host_work.resize((size_t)wstart[(size_t)P]);
+        WorkItem* hw = host_work.data();
+        constexpr int kBlk = 64;
+        parallel_for((P + kBlk - 1) / kBlk, [&](int blk) {
+            for (int p = blk * kBlk; p < std::min(P, (blk + 1) * kBlk); ++p) {
+                const PairDesc& d = host_pairs[p];
+                const int nw = (int)(wstart[(size_t)p + 1] - wstart[(size_t)p]);
+                WorkItem* o = hw + wstart[(size_t)p];
+                for (int k = 0; k < nw; ++k) {
+                    const int a0 = (int)((int64_t)d.n_ang * k / nw), a1 = (int)((int64_t)d.n_ang * (k + 1) / nw);
+                    o[k] = WorkItem{p, a0, a1 - a0, 0};
+                }
+            }
+        });
     }
     W = (int)host_work.size();
     host_work_lb.clear();
@@ -336,6 +352,8 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         W_lb = (int)host_work_lb.size();
     }
 
+    tt_work.stop();
+    TraceTimer tt_copy("stage_level: layout + tables + copies");
     // ---- layout ---------------------------------------------------------------------------
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + std::max<size_t>(bytes, 16)); return at; };

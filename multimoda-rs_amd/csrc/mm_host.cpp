@@ -370,9 +370,11 @@ int WithinPlan::build_sets_device(int32_t n_sets)
             lens[(size_t)(set_base[g] + i)] = d.n;
         }
     }
+    TraceTimer t_alloc("prepare:   descriptors + pool");
     int rc = plan.alloc_pool(e, lens, /*transient=*/false);
     if (rc) return rc;
     for (int32_t s = 0; s < n_sets; ++s) src[(size_t)s].dst_off = plan.set_off[(size_t)s];
+    t_alloc.stop();
 
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t raw_bytes = (size_t)raw_pts * 24, o_src = up(raw_bytes), o_out = up(o_src + (size_t)n_sets * sizeof(SetSrc));
@@ -382,6 +384,7 @@ int WithinPlan::build_sets_device(int32_t n_sets)
     unsigned char* h = (unsigned char*)e->host_pts.p;
     unsigned char* d = (unsigned char*)e->dev_raw.p;
     {
+        TraceTimer t_cp("prepare:   pageable -> pinned");
         // pageable -> pinned, 1 MiB pieces over the worker pool (the runtime's own pageable path is one thread)
         struct Piece { const double* from; size_t at, bytes; };
         std::vector<Piece> pieces;
@@ -398,6 +401,7 @@ int WithinPlan::build_sets_device(int32_t n_sets)
         parallel_for((int)pieces.size(), [&](int k) { std::memcpy(h + pieces[(size_t)k].at, pieces[(size_t)k].from, pieces[(size_t)k].bytes); });
         std::memcpy(h + o_src, src.data(), (size_t)n_sets * sizeof(SetSrc));
     }
+    TraceTimer t_dev("prepare:   H2D + build kernel + sync");
     hipStream_t st = e->aux;
     hipError_t he = hipMemcpyAsync(d, h, o_out, hipMemcpyHostToDevice, st);
     if (he != hipSuccess) return hip_error(he, "raw pullbacks H2D");
