@@ -1,8 +1,10 @@
 """Worker of test_distributed_gloo.py: world_size-2 (or more) `gloo` run of the candidate-axis
 sharding on CPU.  Each rank takes its slice of every pair's candidate list, computes the
-slice's exact first minimum from oracle costs, exchanges through
-multimoda_rs_amd.distributed.merge_level (all_gather + all_reduce(MIN)) and checks the merged
-winner against the unsharded first minimum."""
+slice's exact first minimum from oracle costs (no GPU here, so the product's local search cannot run: the
+real sharded search on the device is tests/test_gpu_sharded.py), exchanges through
+multimoda_rs_amd.distributed.merge_level (all_gather) and checks the merged winner against the unsharded
+first minimum; then the key encoding of the device-side exchange is reduced with two all_reduce(MIN) over
+the same process group and must decode to the same winners and decided flags."""
 import math
 import os
 import sys
@@ -64,6 +66,35 @@ def main():
         local_from_costs(cs, short_angles, tol[n - 1], rank, world, D)
 
     ok, angle, idx, cost = D.merge_level(local, tol)
+
+    # The device-side exchange (multimoda_rs_amd.distributed.search_device) reduces the same records with two
+    # all_reduce(MIN) calls; on the GPU the records are written by k_export_cost / k_export_keys and decoded by
+    # mm_within_plan_level_commit_dev.  Here the same encoding is written in numpy and reduced over the real process
+    # group: the reduced keys must give the winner and the decided / undecided flag of mm_merge_shards.
+    import torch
+    I64MAX, I64MIN = np.iinfo(np.int64).max, np.iinfo(np.int64).min
+    g = torch.from_numpy(local["cost"].copy())
+    dist.all_reduce(g, op=dist.ReduceOp.MIN)
+    g = g.numpy()
+    keys = np.full(3 * n, I64MAX, dtype=np.int64)
+    abits = local["angle"].view(np.int64)
+    for j in range(n):
+        if local["idx"][j] < 0:
+            continue
+        if local["cost"][j] == g[j]:
+            keys[j] = local["idx"][j]
+        if local["cost"][j] <= g[j] + tol[j]:
+            keys[n + j] = abits[j] if local["uniform"][j] else I64MIN
+            keys[2 * n + j] = ~abits[j] if local["uniform"][j] else I64MIN
+    k = torch.from_numpy(keys)
+    dist.all_reduce(k, op=dist.ReduceOp.MIN)
+    k = k.numpy()
+    for j in range(n):
+        assert g[j] == cost[j]
+        assert k[j] == idx[j], (j, k[j], idx[j])
+        assert bool(k[n + j] == ~k[2 * n + j]) == bool(ok[j]), j
+        if ok[j]:
+            assert k[n + j] == np.float64(angle[j]).view(np.int64)
 
     for j, cj in enumerate(jobs):
         k = int(np.argmin(cj))
