@@ -130,6 +130,16 @@ int Engine::profile_end(hipStream_t stream, double pair_evals, int64_t candidate
 // -------------------------------------------------------------------------------------
 // plan: point pool
 // -------------------------------------------------------------------------------------
+// Pinned host -> HBM.  Small uploads of transient batches often follow a kernel on the side stream (the second level
+// of a between search behind the first level's kernels); the runtime executes such a copy as a 512-thread blit
+// kernel, which is not dispatched beside another engine's screen launch (see k_copy_small): those go through the
+// 256-thread copy kernel (pinned host memory is device-accessible).  Everything else is a plain async copy (SDMA).
+static hipError_t upload(void* dst, const void* src, size_t bytes, bool transient, hipStream_t st)
+{
+    if (transient && bytes <= ((size_t)1 << 20)) return launch_copy_small(dst, src, bytes, st);
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+}
+
 // Layout and allocation of the point pool for sets of the given sizes; no data yet.
 int Plan::alloc_pool(Engine* e, const std::vector<int32_t>& lens, bool transient_)
 {
@@ -187,7 +197,7 @@ int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_
         }
         set_rho[s] = std::sqrt(rho2) * (1.0 + 1e-12);
     }
-    if (pts_bytes) MM_HIP(hipMemcpyAsync(pts_blob, h, pts_bytes, hipMemcpyHostToDevice, st));
+    if (pts_bytes) MM_HIP(upload(pts_blob, h, pts_bytes, transient, st));
     if (!transient) MM_HIP(hipStreamSynchronize(st));
     return MM_OK;
 }
@@ -403,7 +413,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         if ((rc = e->blob_alloc((void**)&lvl_blob, lvl_bytes, &lvl_cap))) return rc;
         own_lvl = true;
     }
-    MM_HIP(hipMemcpyAsync(lvl_blob, h, lvl_in_bytes, hipMemcpyHostToDevice, st));
+    MM_HIP(upload(lvl_blob, h, lvl_in_bytes, transient, st));
     if (!transient) MM_HIP(hipStreamSynchronize(st));  // host staging buffer is reused
 
     unsigned char* B = lvl_blob;

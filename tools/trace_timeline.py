@@ -20,4 +20,4 @@ for r in rows:
     if s < lo:
         continue
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
-    print(f"{s:.3f},{d:.3f},{r.get('Queue_Id', '?')},{short(r['Kernel_Name'])},{r.get('Grid_Size_X') or r.get('Grid_Size')},{r.get('Workgroup_Size_X') or r.get('Workgroup_Size')}")
+    print(f"{s:.3f},{d:.3f},{r.get('Queue_Id', '?')},\"{short(r['Kernel_Name'])}\",{r.get('Grid_Size_X') or r.get('Grid_Size')},{r.get('Workgroup_Size_X') or r.get('Workgroup_Size')}")
