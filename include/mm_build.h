@@ -4,6 +4,7 @@
  *
  * Reference interfaces replaced (paths relative to the reference checkout):
  *   src/intravascular/io/build.rs:9-205            build_geometry_from_inputdata (from an InputData)
+ *   src/intravascular/io/integrity_check.rs:8-256  check_geometry_integrity, the builder's last step
  *   src/types/native/contour.rs:158-224,368-405    build_contour_with_mapping, compute_centroid, sort_contour_points
  *   src/types/native/frame.rs:69-82,163-204        set_value(id), create_catheter_points
  *   src/types/native/geometry.rs:42-59,72-155,325-381  find_proximal_end_idx, reorder_frames,
@@ -36,6 +37,16 @@ typedef struct mm_built mm_built;   /* a built Geometry, owned by the library */
  * sidebranch may be NULL (None).  lumen_aortic (nullable): ContourPoint.aortic per lumen row.  records == NULL
  * (n_records ignored) <=> InputData.record is None.  n_points == 0 -> no catheter contours (build.rs:152). */
 int  mm_build_geometry(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aortic,
+                       const double* eem4, int64_t n_eem, const double* calc4, int64_t n_calc,
+                       const double* side4, int64_t n_side, const double ref4[4],
+                       const mm_record* records, int64_t n_records, int diastole,
+                       double image_center_x, double image_center_y, double radius, uint32_t n_points,
+                       mm_built** out);
+/* The same builder without its last step, check_geometry_integrity (build.rs:199, integrity_check.rs:8-33): frames
+ * whose contours differ in point count and a reference point no frame carries are let through.  NOT the reference's
+ * behaviour (mm_build_geometry fails with MM_ERR_INTEGRITY and the reference's message) -- for hosts that validate
+ * their contours themselves, and for this repository's builder tests on ragged input. */
+int  mm_build_geometry_lenient(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aortic,
                        const double* eem4, int64_t n_eem, const double* calc4, int64_t n_calc,
                        const double* side4, int64_t n_side, const double ref4[4],
                        const mm_record* records, int64_t n_records, int diastole,

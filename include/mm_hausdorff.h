@@ -41,7 +41,9 @@ typedef enum {
     MM_ERR_NO_POINTS    = -5,  /* "Lumen contours have no points"    (align_within.rs:35-37) */
     MM_ERR_SAMPLE_SIZE  = -6,  /* "sample_size must be > 0"          (align_within.rs:38-40) */
     MM_ERR_HIP          = -7,
-    MM_ERR_REF_INDEX    = -8   /* reference-frame index out of range (Rust would panic)      */
+    MM_ERR_REF_INDEX    = -8,  /* reference-frame index out of range (Rust would panic)      */
+    MM_ERR_INTEGRITY    = -9   /* a check of check_geometry_integrity failed (integrity_check.rs:8-33);
+                                  mm_last_error() holds the reference's message                */
 } mm_status;
 
 /* precision of the candidate scoring */

@@ -67,7 +67,7 @@ class MMGeometry(C.Structure):
 
 
 # include/mm_build.h
-EXPORTS_BUILD = ["mm_build_geometry", "mm_built_dims", "mm_built_export", "mm_built_destroy", "mm_contour_centroids",
+EXPORTS_BUILD = ["mm_build_geometry", "mm_build_geometry_lenient", "mm_built_dims", "mm_built_export", "mm_built_destroy", "mm_contour_centroids",
                  "mm_frames_from_flat", "mm_frames_dims", "mm_frames_export", "mm_frames_destroy",
                  "mm_frames_finish_within", "mm_frames_postprocess_pair"]
 
@@ -306,6 +306,8 @@ def lib():
     # include/mm_build.h
     L.mm_build_geometry.restype = I
     L.mm_build_geometry.argtypes = [P, I64, P, P, I64, P, I64, P, I64, P, P, I64, I, D, D, D, C.c_uint32, C.POINTER(P)]
+    L.mm_build_geometry_lenient.restype = I
+    L.mm_build_geometry_lenient.argtypes = L.mm_build_geometry.argtypes
     L.mm_built_dims.restype = I
     L.mm_built_dims.argtypes = [P, C.POINTER(I32), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)]
     L.mm_built_export.restype = I

@@ -2,6 +2,7 @@
 // (src/intravascular/io/build.rs:9-205) and the Geometry / Contour / Frame helpers it calls, host f64 in the
 // reference's operation order (built with -ffp-contract=off).  Reference lines are cited per step.
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -36,6 +37,19 @@ struct BFrame {
     bool has_a = false, has_p = false;         // Contour.aortic_thickness / pulmonary_thickness of the lumen
     double a_th = 0.0, p_th = 0.0;
 };
+
+// Rust's `{}` / `{:?}` of an f64: the shortest digits that round-trip, never an exponent for Display; `{:?}` adds ".0"
+// to integral values.  (Only the z / centroid messages of the integrity check print floats.)
+std::string rust_f64(double v, bool debug)
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[400];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    std::string s(buf, r.ptr);
+    if (debug && s.find('.') == std::string::npos) s += ".0";
+    return s;
+}
 
 // Contour::compute_centroid (contour.rs:213-224): sequential sums / n
 void centroid_of(const BContour& c, double out[3])
@@ -103,16 +117,74 @@ void group_rows(const double* rows4, int64_t n, const uint8_t* flags, std::map<u
 
 struct Built { std::vector<BFrame> frames; bool any_flags = false; };
 
+namespace {
+// check_geometry_integrity (integrity_check.rs:8-33) on a built geometry, the reference's messages.  Empty string =
+// Ok.  By construction of this builder the frame ids are the positions (:35-46), every extras contour and the
+// reference point carry their frame's original index (:169-200) and Frame.lumen.centroid is the value the frame
+// centroid was copied from (:49-81, which therefore only trips on non-finite coordinates); those are still walked
+// so that the order of the reported failure is the reference's.
+std::string integrity_error(const Built& B)
+{
+    const std::vector<BFrame>& fr = B.frames;
+    const size_t n = fr.size();
+    auto tup = [](const double c[3]) {
+        return "(" + rust_f64(c[0], true) + ", " + rust_f64(c[1], true) + ", " + rust_f64(c[2], true) + ")";
+    };
+    auto at = [](size_t i, const BFrame& f) { return std::to_string(i) + " (ID " + std::to_string(f.id) + ")"; };
+    for (size_t i = 0; i < n; ++i)                                        // :35-46
+        if (fr[i].id != (uint32_t)i)
+            return "Frame IDs are not consecutive. Expected ID " + std::to_string(i) + ", found ID " + std::to_string(fr[i].id);
+    for (size_t i = 0; i < n; ++i)                                        // :49-81 (EPSILON 1e-6, strict)
+        for (int k = 0; k < 3; ++k)
+            if (!(std::fabs(fr[i].centroid[k] - fr[i].centroid[k]) < 1e-6))
+                return "Frame centroid does not match lumen centroid in frame " + at(i, fr[i]) + ". Frame: " +
+                       tup(fr[i].centroid) + ", Lumen: " + tup(fr[i].centroid);
+    for (size_t i = 0; i < n; ++i)                                        // :84-104
+        if (fr[i].lumen.n() == 0) return "Lumen contour has no points in frame " + at(i, fr[i]);
+    size_t n_ref = 0;                                                     // :107-118
+    for (const BFrame& f : fr) n_ref += f.has_ref ? 1 : 0;
+    if (n_ref != 1) return "Expected exactly one reference point, found " + std::to_string(n_ref);
+    static const char* kKind[4] = {"Eem", "Calcification", "Sidebranch", "Catheter"};
+    int64_t expect_lumen = -1, expect[4] = {-1, -1, -1, -1};              // :121-166
+    for (size_t i = 0; i < n; ++i) {
+        const BFrame& f = fr[i];
+        if (expect_lumen < 0) expect_lumen = f.lumen.n();
+        else if (f.lumen.n() != expect_lumen)
+            return "Lumen point count mismatch in frame " + at(i, f) + ". Expected " + std::to_string(expect_lumen) +
+                   ", found " + std::to_string(f.lumen.n());
+        for (int k = 0; k < 4; ++k) {
+            const bool has = k < 3 ? f.has_ext[k] : f.has_cath;
+            if (!has) continue;
+            const int64_t c = k < 3 ? f.ext[k].n() : f.cath.n();
+            if (expect[k] < 0) expect[k] = c;
+            else if (c != expect[k])
+                return std::string(kKind[k]) + " contour point count mismatch in frame " + at(i, f) + ". Expected " +
+                       std::to_string(expect[k]) + ", found " + std::to_string(c);
+        }
+    }
+    // :203-221 find_proximal_end_idx (geometry.rs:42-59; lumen ids are the frame ids after build.rs:194-197)
+    const size_t prox = n == 1 ? fr[0].id : (fr[0].orig > fr[n - 1].orig ? fr[0].id : fr[n - 1].id);
+    double min_z = INFINITY; size_t min_idx = 0;
+    for (size_t i = 0; i < n; ++i) if (fr[i].centroid[2] < min_z) { min_z = fr[i].centroid[2]; min_idx = i; }
+    if (prox != min_idx)
+        return "Proximal end index is " + std::to_string(prox) + ", but frame with minimum z is " + std::to_string(min_idx) +
+               " (z=" + rust_f64(min_z, false) + ").";
+    if (fr[0].centroid[2] > fr[n - 1].centroid[2])                        // :224-234
+        return "First frame has higher z-coords " + rust_f64(fr[0].centroid[2], false) + " than last frame " +
+               rust_f64(fr[n - 1].centroid[2], false);
+    return std::string();
+}
+}  // namespace
+
 }  // namespace mm
 
 using namespace mm;
 
-extern "C" {
-
-int mm_build_geometry(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aortic, const double* eem4, int64_t n_eem,
-                      const double* calc4, int64_t n_calc, const double* side4, int64_t n_side, const double ref4[4],
-                      const mm_record* records, int64_t n_records, int diastole, double icx, double icy, double radius,
-                      uint32_t n_points, mm_built** out)
+namespace {
+int build_impl(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aortic, const double* eem4, int64_t n_eem,
+               const double* calc4, int64_t n_calc, const double* side4, int64_t n_side, const double ref4[4],
+               const mm_record* records, int64_t n_records, int diastole, double icx, double icy, double radius,
+               uint32_t n_points, bool check, mm_built** out)
 {
     if (!out) return set_error(MM_ERR_INVALID, "mm_build_geometry: out == NULL");
     *out = nullptr;
@@ -243,8 +315,33 @@ int mm_build_geometry(const double* lumen4, int64_t n_lumen, const uint8_t* lume
         }
     }
     if (n == 0) { delete B; return set_error(MM_ERR_NO_FRAMES, "Geometry has no frames"); }   // integrity_check.rs:9-11
+    if (check) {
+        const std::string why = integrity_error(*B);                  // build.rs:199
+        if (!why.empty()) { delete B; return set_error(MM_ERR_INTEGRITY, why); }
+    }
     *out = reinterpret_cast<mm_built*>(B);
     return MM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mm_build_geometry(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aortic, const double* eem4, int64_t n_eem,
+                      const double* calc4, int64_t n_calc, const double* side4, int64_t n_side, const double ref4[4],
+                      const mm_record* records, int64_t n_records, int diastole, double icx, double icy, double radius,
+                      uint32_t n_points, mm_built** out)
+{
+    return build_impl(lumen4, n_lumen, lumen_aortic, eem4, n_eem, calc4, n_calc, side4, n_side, ref4, records, n_records,
+                      diastole, icx, icy, radius, n_points, true, out);
+}
+
+int mm_build_geometry_lenient(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aortic, const double* eem4,
+                              int64_t n_eem, const double* calc4, int64_t n_calc, const double* side4, int64_t n_side,
+                              const double ref4[4], const mm_record* records, int64_t n_records, int diastole, double icx,
+                              double icy, double radius, uint32_t n_points, mm_built** out)
+{
+    return build_impl(lumen4, n_lumen, lumen_aortic, eem4, n_eem, calc4, n_calc, side4, n_side, ref4, records, n_records,
+                      diastole, icx, icy, radius, n_points, false, out);
 }
 
 int mm_built_dims(const mm_built* h, int32_t* n_frames, int64_t* n_lumen, int64_t* n_cath, int64_t* n_extra)

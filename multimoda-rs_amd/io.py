@@ -300,20 +300,25 @@ def _group_by_frame(arr: np.ndarray) -> Dict[int, np.ndarray]:
 
 def build_geometry_from_inputdata(input_data: Optional[InputData] = None, path: Optional[str] = None, label: str = "",
                                   diastole: bool = True, image_center=(4.5, 4.5), radius: float = 0.5,
-                                  n_points: int = 20) -> FlatGeometry:
+                                  n_points: int = 20, check_integrity: bool = True) -> FlatGeometry:
     """``build_geometry_from_inputdata`` (io/build.rs:9-205): behind the C ABI (``mm_build_geometry``,
     include/mm_build.h, csrc/mm_build.cpp).  ``build_geometry_python`` below is the same builder in Python, kept as
-    a checker (tests/test_refbuild.py compares both with the independent restatement in tests/refbuild.py)."""
+    a checker (tests/test_refbuild.py compares both with the independent restatement in tests/refbuild.py).
+
+    ``check_integrity`` (not a reference parameter; default = the reference's behaviour): the builder ends with
+    ``check_geometry_integrity`` (build.rs:199) and raises RuntimeError with the reference's message when frames
+    differ in point count or no frame carries the reference point.  False = ``mm_build_geometry_lenient``."""
     if input_data is None:
         if path is None:
             raise RuntimeError("Either input_data or path must be provided")
         input_data = process_directory(path, diastole, label)
     if os.environ.get("MM_PY_BUILDER"):
-        return build_geometry_python(input_data, label, image_center, radius, n_points)
-    return _build_geometry_native(input_data, label, image_center, radius, n_points)
+        return build_geometry_python(input_data, label, image_center, radius, n_points, check_integrity)
+    return _build_geometry_native(input_data, label, image_center, radius, n_points, check_integrity)
 
 
-def _build_geometry_native(d: InputData, label: str, image_center, radius: float, n_points: int) -> FlatGeometry:
+def _build_geometry_native(d: InputData, label: str, image_center, radius: float, n_points: int,
+                           check_integrity: bool = True) -> FlatGeometry:
     import ctypes as C
     from . import _native as N
     L = N.lib()
@@ -335,10 +340,11 @@ def _build_geometry_native(d: InputData, label: str, image_center, radius: float
             recs[i].m2 = 0.0 if r.measurement_2 is None else float(r.measurement_2)
     h = C.c_void_p()
     n_of = lambda a: 0 if a is None else a.shape[0]
-    N.check(L.mm_build_geometry(N._ptr(lum), lum.shape[0], N._ptr(flags), N._ptr(eem), n_of(eem), N._ptr(calc), n_of(calc),
-                                N._ptr(side), n_of(side), N._ptr(ref), recs, 0 if d.record is None else len(d.record),
-                                int(bool(d.diastole)), float(image_center[0]), float(image_center[1]), float(radius),
-                                int(n_points), C.byref(h)), "build_geometry_from_inputdata")
+    build = L.mm_build_geometry if check_integrity else L.mm_build_geometry_lenient
+    N.check(build(N._ptr(lum), lum.shape[0], N._ptr(flags), N._ptr(eem), n_of(eem), N._ptr(calc), n_of(calc),
+                  N._ptr(side), n_of(side), N._ptr(ref), recs, 0 if d.record is None else len(d.record),
+                  int(bool(d.diastole)), float(image_center[0]), float(image_center[1]), float(radius),
+                  int(n_points), C.byref(h)), "build_geometry_from_inputdata")
     try:
         F, nl, nc, ne = C.c_int32(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         N.check(L.mm_built_dims(h, C.byref(F), C.byref(nl), C.byref(nc), C.byref(ne)), "mm_built_dims")
@@ -374,8 +380,30 @@ def _build_geometry_native(d: InputData, label: str, image_center, radius: float
     return g
 
 
+def _integrity_error(flist) -> Optional[str]:
+    """check_geometry_integrity (integrity_check.rs:8-33) on the checker builder's frames: the checks that a built
+    geometry can fail, with the reference's messages (ids, original frames and stored centroids hold by
+    construction; csrc/mm_build.cpp walks all eight)."""
+    n_ref = sum(1 for fr in flist if fr.ref is not None)               # :107-118
+    if n_ref != 1:
+        return f"Expected exactly one reference point, found {n_ref}"
+    names = {"eem": "Eem", "calcification": "Calcification", "sidebranch": "Sidebranch", "catheter": "Catheter"}
+    expected = {}                                                      # :121-166
+    for i, fr in enumerate(flist):
+        n = fr.lumen.shape[0]
+        if expected.setdefault("lumen", n) != n:
+            return f"Lumen point count mismatch in frame {i} (ID {fr.id}). Expected {expected['lumen']}, found {n}"
+        for k in ("eem", "calcification", "sidebranch", "catheter"):
+            if k in fr.extras:
+                n = fr.extras[k].shape[0]
+                if expected.setdefault(k, n) != n:
+                    return (f"{names[k]} contour point count mismatch in frame {i} (ID {fr.id}). "
+                            f"Expected {expected[k]}, found {n}")
+    return None
+
+
 def build_geometry_python(d: InputData, label: str = "", image_center=(4.5, 4.5), radius: float = 0.5,
-                          n_points: int = 20) -> FlatGeometry:
+                          n_points: int = 20, check_integrity: bool = True) -> FlatGeometry:
     """The same builder in Python (checker of the native one)."""
 
     # build.rs:37-71 shared original-frame -> sequential-id mapping
@@ -478,6 +506,10 @@ def build_geometry_python(d: InputData, label: str = "", image_center=(4.5, 4.5)
                 fr.ref[2] = z
     if n == 0:
         raise RuntimeError("Geometry has no frames")               # integrity_check.rs:9-11
+    if check_integrity:                                            # build.rs:199
+        why = _integrity_error(flist)
+        if why:
+            raise RuntimeError(f"build_geometry_from_inputdata: {why}")
     return _to_flat(flist, d.label or label)
 
 

@@ -74,9 +74,11 @@ def test_native_builder_equals_python_builder_with_extras_and_ragged_input(mm, m
                 d = mm.InputData(lumen=lum, ref_point=np.array([ref_frame, 6.5, 4.4, 7.6]), diastole=dia, label="x",
                                  eem=eem, calcification=calc, sidebranch=side, record=recs, lumen_aortic=flags)
                 monkeypatch.delenv("MM_PY_BUILDER", raising=False)
-                a = mm.build_geometry_from_inputdata(d, n_points=n_points)
+                # ragged frames / a lumen-less reference frame are what check_geometry_integrity rejects
+                # (test_builder_ends_with_the_integrity_check below): the builder's mechanics are compared without it
+                a = mm.build_geometry_from_inputdata(d, n_points=n_points, check_integrity=False)
                 monkeypatch.setenv("MM_PY_BUILDER", "1")
-                b = mm.build_geometry_from_inputdata(d, n_points=n_points)
+                b = mm.build_geometry_from_inputdata(d, n_points=n_points, check_integrity=False)
                 for name in ("ids", "lumen_ids", "orig_frames", "centroids", "lumen_off", "lumen", "cath_off", "cath",
                              "extra_off", "extra", "has_ref", "ref"):
                     x, y = getattr(a, name), getattr(b, name)
@@ -90,3 +92,46 @@ def test_native_builder_equals_python_builder_with_extras_and_ragged_input(mm, m
                 assert a.meta["pulmonary_thickness"] == b.meta["pulmonary_thickness"]
                 assert np.array_equal(a.meta["lumen_aortic"], b.meta["lumen_aortic"])
                 assert np.array_equal(a.meta["lumen_aortic"], a.lumen[:, 0] > 4.5)
+
+
+def test_builder_ends_with_the_integrity_check(mm, monkeypatch):
+    """build.rs:199 -> integrity_check.rs:8-33: what a built geometry can fail -- no frame carries the reference point
+    (:107-118), frames differ in lumen / extras point count (:121-166) -- is an error with the reference's message,
+    from the native builder and from the Python checker alike; a consistent input passes both."""
+    import math
+    import __graft_entry__ as ge
+    ge.build()
+
+    def ring(frame, n, r, z):
+        t = np.linspace(0, 2 * math.pi, n, endpoint=False)
+        return np.stack([np.full(n, float(frame)), 4.5 + r * np.cos(t), 4.4 + 0.8 * r * np.sin(t), np.full(n, z)], 1)
+
+    def lumen(counts):
+        return np.concatenate([ring(f, n, 2.0, 0.5 * f) for f, n in counts])
+    ok_lum = lumen([(3, 40), (5, 40), (9, 40)])
+    ref = np.array([5.0, 6.5, 4.4, 2.5])
+    cases = [
+        (dict(lumen=ok_lum, ref_point=ref), None),
+        (dict(lumen=ok_lum, ref_point=np.array([4.0, 6.5, 4.4, 2.0])), "Expected exactly one reference point, found 0"),
+        (dict(lumen=lumen([(3, 40), (5, 40), (9, 37)]), ref_point=ref),
+         "Lumen point count mismatch in frame 1 (ID 1). Expected 37, found 40"),         # frame 0 = the highest original frame
+        (dict(lumen=ok_lum, ref_point=ref, eem=np.concatenate([ring(3, 30, 2.6, 1.5), ring(9, 31, 2.6, 4.5)])),
+         "Eem contour point count mismatch in frame 2 (ID 2). Expected 31, found 30"),
+    ]
+    for kw, msg in cases:
+        got = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("MM_PY_BUILDER", env)
+            else:
+                monkeypatch.delenv("MM_PY_BUILDER", raising=False)
+            d = mm.InputData(diastole=True, label="x", **kw)
+            if msg is None:
+                assert mm.build_geometry_from_inputdata(d).n_frames == 3
+                continue
+            with pytest.raises(RuntimeError) as e:
+                mm.build_geometry_from_inputdata(d)
+            assert msg in str(e.value)
+            got.append(str(e.value).split(" (mm_status")[0])
+            assert mm.build_geometry_from_inputdata(d, check_integrity=False).n_frames == 3
+        assert len(set(got)) <= 1, got
