@@ -49,6 +49,12 @@ typedef struct {
     double*   lumen_centroid;      /* [F*3]                                                    */
     int32_t   n_extra_kinds;       /* K extras contours per frame inside g->extra (catheter excluded) */
     int64_t*  extra_kind_off;      /* [F*K+1] CSR over (frame, kind) into g->extra; NULL = one contour per frame */
+    /* ContourPoint.aortic of the lumen and of the Wall contour (nullable = all false).  A sort moves whole
+     * ContourPoints (contour.rs:385-390), so these are permuted with their points by every function here that
+     * sorts contours; mm_align_walls reads the wall's (align.rs:385-407). */
+    uint8_t*  lumen_aortic;        /* [lumen points]                                                          */
+    uint8_t*  wall_aortic;         /* [wall points, frame by frame]                                           */
+    int32_t   wall_kind1;          /* 1 + index of the Wall contour among the K kinds; 0 = no Wall contours   */
 } mm_cl_geometry;
 
 /* Centerline::from_contour_points (centerline.rs:14-42): tangents = normalised forward
@@ -94,10 +100,17 @@ int     mm_refine_alignment_hausdorff(mm_engine* e, mm_cl_geometry** geoms, int 
                                       double* best_angle, int64_t* best_idx, double* min_hausdorff,
                                       double* all_costs, int64_t cap, int64_t* n_evals);
 
+/* align_walls (align.rs:381-595): with anomalous != 0 and at least two frames in geoms[0], the Wall contour of every
+ * frame (but the first) of every geometry is rotated about its lumen normal so that its aortic side -- or, without
+ * aortic flags, its major axis -- follows the direction of frame 0's wall, parallel-transported along the vessel.
+ * Lumen and all other contours stay.  The reference holds no test of this function: parity is against
+ * oracle/mm_oracle_cl.c's restatement only ("parity unpinned"). */
+int     mm_align_walls(mm_cl_geometry** geoms, int n_geoms, int anomalous);
+
 /* align_three_point_rs / align_manual_rs / align_combined_rs (align.rs:63-124, 126-166, 169-285)
  * with write = false.  geoms (1 or 2) are transformed in place; angles in radians except
  * rotation_angle_deg; *total_rotation is in radians (the binding converts, align.rs:125).
- * align_wall_anomalous != 0 is not supported yet (MM_ERR_INVALID). */
+ * align_wall_anomalous != 0: mm_align_walls as the last step (align.rs:105-107,147-149,266-268). */
 int     mm_align_three_point(const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geoms, int n_geoms,
                              uint32_t ref_point_index, const double p_main[3], const double p_ccw[3],
                              const double p_cw[3], double angle_step, int align_wall_anomalous,

@@ -41,7 +41,7 @@ EXPORTS = [
 EXPORTS_CENTERLINE = [
     "mm_centerline_from_points", "mm_centerline_find_ref_idx", "mm_centerline_preprocess",
     "mm_sort_contour_points", "mm_rotate_geometry", "mm_apply_transformations", "mm_best_rotation_three_point",
-    "mm_refine_alignment_hausdorff", "mm_align_three_point", "mm_align_manual", "mm_align_combined",
+    "mm_refine_alignment_hausdorff", "mm_align_three_point", "mm_align_manual", "mm_align_combined", "mm_align_walls",
 ]
 
 
@@ -102,6 +102,9 @@ class MMClGeometry(C.Structure):
         ("lumen_centroid", C.c_void_p),
         ("n_extra_kinds", C.c_int32),
         ("extra_kind_off", C.c_void_p),
+        ("lumen_aortic", C.c_void_p),
+        ("wall_aortic", C.c_void_p),
+        ("wall_kind1", C.c_int32),
     ]
 
 
@@ -298,6 +301,8 @@ def lib():
                                                 C.POINTER(I64), C.POINTER(D), P, I64, C.POINTER(I64)]
     L.mm_align_three_point.restype = I
     L.mm_align_three_point.argtypes = [P, I64, P, I, U32, P, P, P, D, I, C.POINTER(D), C.POINTER(D)]
+    L.mm_align_walls.restype = I
+    L.mm_align_walls.argtypes = [P, I, I]
     L.mm_align_manual.restype = I
     L.mm_align_manual.argtypes = [P, I64, P, I, D, P, I, C.POINTER(D), C.POINTER(D)]
     L.mm_align_combined.restype = I

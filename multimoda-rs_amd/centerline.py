@@ -8,13 +8,14 @@ Same argument names, meaning, defaults and error behaviour; geometries are ``Fla
 copies (the reference clones at the boundary too).  The three-point sweep and the frame placement
 are host f64 (csrc/mm_centerline.cpp); every Hausdorff evaluation of ``align_combined``'s
 refinement grid runs on the GPU; ``align_wall_anomalous=True`` applies the wall twist compensation
-(align.rs:381-595, postproc.align_walls) after the placement; ``write=True`` writes the OBJ / MTL /
+(align.rs:381-595, mm_align_walls) after the placement; ``write=True`` writes the OBJ / MTL /
 texture files (export.py).
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -203,6 +204,7 @@ class _ClPack:
 
     def __init__(self, geoms: Sequence[G.FlatGeometry]):
         self.keep = []
+        self._flags = []
         self.gs = [g.c_struct() for g in geoms]
         self.cls = []
         for g, cg in zip(geoms, self.gs):
@@ -227,12 +229,32 @@ class _ClPack:
                 self.keep.append(ko)
                 c.n_extra_kinds = len(kinds)
                 c.extra_kind_off = N._ptr(ko)
+                if "wall" in kinds and int(np.sum(counts["wall"])) > 0:
+                    c.wall_kind1 = kinds.index("wall") + 1
+            # ContourPoint.aortic: the flags follow their points through every sort inside the library
+            for key, n_pts, field in (("lumen_aortic", g.lumen.shape[0], "lumen_aortic"),
+                                      ("wall_aortic", int(np.sum(counts["wall"])) if counts and "wall" in counts else 0,
+                                       "wall_aortic")):
+                fl = g.meta.get(key)
+                if fl is None or n_pts == 0:
+                    continue
+                fl = np.ascontiguousarray(fl, dtype=np.uint8).reshape(-1)
+                if fl.shape[0] != n_pts:
+                    raise ValueError(f"meta['{key}'] does not match the contour points")
+                self.keep.append(fl)
+                self._flags.append((g, key, fl))
+                setattr(c, field, N._ptr(fl))
             self.cls.append(c)
         self.arr = (C.POINTER(N.MMClGeometry) * len(geoms))(*[C.pointer(c) for c in self.cls])
 
     @property
     def ptr(self):
         return C.cast(self.arr, C.c_void_p)
+
+    def commit_flags(self) -> None:
+        """Write the (possibly permuted) per-point aortic flags back into the geometries' meta."""
+        for g, key, fl in self._flags:
+            g.meta[key] = fl.astype(bool)
 
 
 def _v3(p) -> np.ndarray:
@@ -269,10 +291,16 @@ def _process_and_write(write: bool, result, case_name: str, output_dir: str, int
         raise RuntimeError(f"Failed to write obj: {e}") from e
 
 
+def _py_walls() -> bool:
+    """MM_PY_POSTPROC=1: the wall twist compensation runs in postproc.align_walls (the Python checker) instead of
+    mm_align_walls."""
+    return bool(os.environ.get("MM_PY_POSTPROC"))
+
+
 def _align_walls(geoms: Sequence[G.FlatGeometry], anomalous: bool) -> None:
-    """align_walls (align.rs:589-595): the Wall contours of every geometry follow the parallel-transported
-    direction of their frame 0 (postproc.align_walls); nothing happens with fewer than two frames."""
-    if not anomalous or geoms[0].n_frames < 2:
+    """align_walls (align.rs:589-595) through the Python checker (postproc.align_walls); the product path is
+    mm_align_walls inside mm_align_three_point / _manual / _combined (their align_wall_anomalous argument)."""
+    if not anomalous or not _py_walls() or geoms[0].n_frames < 2:
         return
     from . import frames as FR
     from . import postproc as PP
@@ -280,6 +308,15 @@ def _align_walls(geoms: Sequence[G.FlatGeometry], anomalous: bool) -> None:
         fr = PP.align_walls(FR.to_frames(g), True)
         h = FR.from_frames(fr, g.label, g.meta)
         g.extra_off, g.extra = h.extra_off, h.extra        # only wall points move
+
+
+def align_walls(geometry, anomalous: bool = True):
+    """``align_walls`` (align.rs:589-595) on a FlatGeometry or a GeometryPair -> a new object (mm_align_walls)."""
+    geoms, rebuild = _unpack(geometry)
+    pk = _ClPack(geoms)
+    N.check(N.lib().mm_align_walls(pk.ptr, len(geoms), int(bool(anomalous))), "align_walls")
+    pk.commit_flags()
+    return rebuild()
 
 
 def _ref_point_index(g: G.FlatGeometry) -> int:
@@ -291,6 +328,7 @@ def rotate_geometry(g: G.FlatGeometry, angle_rad: float) -> None:
     """Geometry::rotate_geometry (geometry.rs:241-250), in place."""
     pk = _ClPack([g])
     N.check(N.lib().mm_rotate_geometry(C.byref(pk.cls[0]), float(angle_rad)), "rotate_geometry")
+    pk.commit_flags()
 
 
 def apply_transformations(geoms: Sequence[G.FlatGeometry], centerline: Centerline, ref_pt) -> int:
@@ -353,9 +391,11 @@ def align_three_point(centerline: Centerline, geometry, main_ref_pt, countercloc
     sp, rot = C.c_double(0.0), C.c_double(0.0)
     N.check(N.lib().mm_align_three_point(N._ptr(centerline.points), len(centerline), pk.ptr, len(geoms),
                                          _ref_point_index(geoms[0]), N._ptr(a), N._ptr(b), N._ptr(d),
-                                         math.radians(angle_step_deg), 0, C.byref(sp), C.byref(rot)),
+                                         math.radians(angle_step_deg), int(bool(align_wall_anomalous) and not _py_walls()),
+                                         C.byref(sp), C.byref(rot)),
             "align_three_point")
-    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:105-107
+    pk.commit_flags()
+    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:105-107 (checker only)
     out = rebuild()
     _process_and_write(write, out, case_name, output_dir, interpolation_steps, watertight, contour_types)  # :109-121
     return out, sp.value, rot.value * (180.0 / math.pi)
@@ -370,9 +410,11 @@ def align_manual(centerline: Centerline, geometry, rotation_angle_deg: float, re
     r = _v3(ref_point)
     sp, rot = C.c_double(0.0), C.c_double(0.0)
     N.check(N.lib().mm_align_manual(N._ptr(centerline.points), len(centerline), pk.ptr, len(geoms),
-                                    float(rotation_angle_deg), N._ptr(r), 0, C.byref(sp), C.byref(rot)),
+                                    float(rotation_angle_deg), N._ptr(r), int(bool(align_wall_anomalous) and not _py_walls()),
+                                    C.byref(sp), C.byref(rot)),
             "align_manual")
-    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:147-149
+    pk.commit_flags()
+    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:147-149 (checker only)
     out = rebuild()
     _process_and_write(write, out, case_name, output_dir, interpolation_steps, watertight, contour_types)  # :151-163
     return out, sp.value, rot.value * (180.0 / math.pi)
@@ -396,9 +438,11 @@ def align_combined(centerline: Centerline, geometry, main_ref_pt, counterclockwi
     N.check(N.lib().mm_align_combined(engine.handle, N._ptr(centerline.points), len(centerline), pk.ptr, len(geoms),
                                       _ref_point_index(geoms[0]), N._ptr(a), N._ptr(b), N._ptr(d), N._ptr(pts),
                                       pts.shape[0], math.radians(angle_step_deg), math.radians(angle_range_deg),
-                                      int(index_range), 0, C.byref(sp), C.byref(rot), C.byref(ri), C.byref(ne)),
+                                      int(index_range), int(bool(align_wall_anomalous) and not _py_walls()),
+                                      C.byref(sp), C.byref(rot), C.byref(ri), C.byref(ne)),
             "align_combined")
-    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:266-268
+    pk.commit_flags()
+    _align_walls(geoms, align_wall_anomalous)                                   # align.rs:266-268 (checker only)
     out = rebuild()
     first = out.geom_a if hasattr(out, "geom_a") else out
     first.meta["refined_cl_ref_idx"] = int(ri.value)

@@ -137,8 +137,8 @@ FrameTf align_frame(const double* xyz, int64_t n, bool has_c, const double* c_in
 }
 
 // Contour::sort_contour_points (contour.rs:368-405).  `key`/`perm`/`tmp` are caller scratch.
-struct SortScratch { std::vector<double> key, tmp; std::vector<int32_t> perm; };
-void sort_contour(double* xyz, int64_t n, SortScratch& sc)
+struct SortScratch { std::vector<double> key, tmp; std::vector<int32_t> perm; std::vector<uint8_t> tf; };
+void sort_contour(double* xyz, int64_t n, SortScratch& sc, uint8_t* flags = nullptr)   // flags: ContourPoint.aortic
 {
     if (n == 0) return;
     double sx = 0.0, sy = 0.0;
@@ -158,6 +158,11 @@ void sort_contour(double* xyz, int64_t n, SortScratch& sc)
         sc.tmp[3 * i] = xyz[3 * src]; sc.tmp[3 * i + 1] = xyz[3 * src + 1]; sc.tmp[3 * i + 2] = xyz[3 * src + 2];
     }
     std::memcpy(xyz, sc.tmp.data(), (size_t)n * 24);
+    if (flags) {
+        sc.tf.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) sc.tf[(size_t)i] = flags[sc.perm[(size_t)((i + start) % n)]];
+        std::memcpy(flags, sc.tf.data(), (size_t)n);
+    }
 }
 
 // ContourPoint::rotate (contour_point.rs:38-52) with the sin/cos pair hoisted out of the loop
@@ -272,6 +277,8 @@ int check_geoms(mm_cl_geometry** geoms, int n_geoms)
         if (G->n_frames < 0 || !G->lumen_off || !G->centroid) return set_error(MM_ERR_INVALID, "malformed geometry");
         if (geoms[g]->extra_kind_off && geoms[g]->n_extra_kinds <= 0)
             return set_error(MM_ERR_INVALID, "extra_kind_off given with n_extra_kinds <= 0");
+        if (geoms[g]->wall_kind1 < 0 || geoms[g]->wall_kind1 > (geoms[g]->extra_kind_off ? geoms[g]->n_extra_kinds : 1))
+            return set_error(MM_ERR_INVALID, "wall_kind1 is not one of the extras kinds");
     }
     return MM_OK;
 }
@@ -309,30 +316,187 @@ void apply_transforms(mm_cl_geometry* cg, const std::vector<FrameTf>& tfs)
     }
 }
 
+// The Wall contour of frame i: its span in g->extra and its offset into wall_aortic (`wall_at`[i], a prefix sum).
+struct WallIndex {
+    std::vector<int64_t> at;   // [F+1] wall points before frame i
+    int32_t K = 1, k = -1;
+    explicit WallIndex(const mm_cl_geometry* cg)
+    {
+        const mm_geometry* g = cg->g;
+        if (!cg->wall_kind1 || !g->extra_off) return;
+        K = cg->extra_kind_off ? cg->n_extra_kinds : 1;
+        k = cg->wall_kind1 - 1;
+        at.assign((size_t)g->n_frames + 1, 0);
+        for (int32_t i = 0; i < g->n_frames; ++i) at[(size_t)i + 1] = at[(size_t)i] + (hi(cg, i) - lo(cg, i));
+    }
+    bool any() const { return k >= 0; }
+    int64_t lo(const mm_cl_geometry* cg, int32_t i) const
+    { return cg->extra_kind_off ? cg->extra_kind_off[(int64_t)i * K + k] : cg->g->extra_off[i]; }
+    int64_t hi(const mm_cl_geometry* cg, int32_t i) const
+    { return cg->extra_kind_off ? cg->extra_kind_off[(int64_t)i * K + k + 1] : cg->g->extra_off[i + 1]; }
+};
+
 void rotate_geometry(mm_cl_geometry* cg, double angle)
 {
     if (angle == 0.0) return;                                                                  // geometry.rs:242-244
     mm_geometry* g = cg->g;
+    const WallIndex wi(cg);
+    auto wall_flags = [&](int32_t i) -> uint8_t* {
+        return (wi.any() && cg->wall_aortic) ? cg->wall_aortic + wi.at[(size_t)i] : nullptr;
+    };
     constexpr int kFrames = 8;   // frames are independent: chunks of them over the worker pool
     parallel_for((g->n_frames + kFrames - 1) / kFrames, [&](int c) {
         SortScratch sc;
         for (int32_t i = c * kFrames; i < std::min<int32_t>(g->n_frames, (c + 1) * kFrames); ++i) {
             mm_frame_rotate(g, i, angle, g->centroid[3 * i], g->centroid[3 * i + 1]);          // :246-247
-            sort_contour(g->lumen + 3 * g->lumen_off[i], g->lumen_off[i + 1] - g->lumen_off[i], sc);  // frame.rs:123-129
+            sort_contour(g->lumen + 3 * g->lumen_off[i], g->lumen_off[i + 1] - g->lumen_off[i], sc,   // frame.rs:123-129
+                         cg->lumen_aortic ? cg->lumen_aortic + g->lumen_off[i] : nullptr);
             if (g->cath_off) sort_contour(g->cath + 3 * g->cath_off[i], g->cath_off[i + 1] - g->cath_off[i], sc);
             if (g->extra_off) {
                 if (cg->extra_kind_off) {
                     const int32_t K = cg->n_extra_kinds;
                     for (int32_t k = 0; k < K; ++k) {
                         const int64_t lo = cg->extra_kind_off[(int64_t)i * K + k], hi = cg->extra_kind_off[(int64_t)i * K + k + 1];
-                        sort_contour(g->extra + 3 * lo, hi - lo, sc);
+                        sort_contour(g->extra + 3 * lo, hi - lo, sc, k == wi.k ? wall_flags(i) : nullptr);
                     }
                 } else {
-                    sort_contour(g->extra + 3 * g->extra_off[i], g->extra_off[i + 1] - g->extra_off[i], sc);
+                    sort_contour(g->extra + 3 * g->extra_off[i], g->extra_off[i + 1] - g->extra_off[i], sc,
+                                 wi.k == 0 ? wall_flags(i) : nullptr);
                 }
             }
         }
     });
+}
+
+// ---- align_walls (align.rs:381-595): wall twist compensation -----------------------------------------------------
+struct WallView { double* p; const uint8_t* aortic; int64_t n; };
+
+// aortic_centroid_direction (:385-407)
+bool aortic_direction(const WallView& w, const double* c, Vec3& out)
+{
+    int64_t m = 0;
+    if (w.aortic) for (int64_t i = 0; i < w.n; ++i) m += w.aortic[i] ? 1 : 0;
+    if (m == 0) return false;
+    const double n = (double)m;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int64_t i = 0; i < w.n; ++i) if (w.aortic[i]) sx += w.p[3 * i];
+    for (int64_t i = 0; i < w.n; ++i) if (w.aortic[i]) sy += w.p[3 * i + 1];
+    for (int64_t i = 0; i < w.n; ++i) if (w.aortic[i]) sz += w.p[3 * i + 2];
+    out = Vec3{{sx / n - c[0], sy / n - c[1], sz / n - c[2]}};
+    return !(norm(out) < 1e-9);
+}
+
+// wall_major_axis (:410-437): the farthest pair, first maximum in (i, j) order
+bool major_axis(const WallView& w, Vec3& out)
+{
+    if (w.n < 2) return false;
+    double best = 0.0;
+    int64_t fa = 0, fb = 0;
+    for (int64_t i = 0; i < w.n; ++i) {
+        const double xi = w.p[3 * i], yi = w.p[3 * i + 1], zi = w.p[3 * i + 2];
+        for (int64_t j = i + 1; j < w.n; ++j) {
+            const double dx = xi - w.p[3 * j], dy = yi - w.p[3 * j + 1], dz = zi - w.p[3 * j + 2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 > best) { best = d2; fa = i; fb = j; }
+        }
+    }
+    out = Vec3{{w.p[3 * fb] - w.p[3 * fa], w.p[3 * fb + 1] - w.p[3 * fa + 1], w.p[3 * fb + 2] - w.p[3 * fa + 2]}};
+    return !(norm(out) < 1e-9);
+}
+
+// project_onto_plane_normalized (:465-472)
+bool project_normalized(const Vec3& v, const Vec3& t, Vec3& out)
+{
+    const double k = dot(v, t);
+    const Vec3 p{{v[0] - t[0] * k, v[1] - t[1] * k, v[2] - t[2] * k}};
+    const double n = norm(p);
+    if (n < 1e-9) return false;
+    out = Vec3{{p[0] / n, p[1] / n, p[2] / n}};
+    return true;
+}
+
+// parallel_transport (:476-492)
+Vec3 parallel_transport(const Vec3& v, const Vec3& tf, const Vec3& tt)
+{
+    const double ang = angle_between(tf, tt);
+    if (ang < 1e-9) return v;
+    const Vec3 axis = cross(tf, tt);
+    if (norm(axis) < 1e-9) {                       // anti-parallel tangents: half a turn about a perpendicular
+        Vec3 perp = std::fabs(tf[0]) < 0.9 ? Vec3{{1.0 - tf[0] * tf[0], 0.0 - tf[1] * tf[0], 0.0 - tf[2] * tf[0]}}
+                                           : Vec3{{0.0 - tf[0] * tf[1], 1.0 - tf[1] * tf[1], 0.0 - tf[2] * tf[1]}};
+        const double n = norm(perp);
+        perp = Vec3{{perp[0] / n, perp[1] / n, perp[2] / n}};
+        return Mat3::axis_angle(perp, kPiCl) * v;
+    }
+    return Mat3::axis_angle(axis, ang) * v;
+}
+
+// signed_angle_around_axis (:495-497)
+inline double signed_angle(const Vec3& from, const Vec3& to, const Vec3& axis)
+{
+    return std::atan2(dot(cross(from, to), axis), dot(from, to));
+}
+
+// align_walls_on_geometry (:507-584).  The lumen normals (Newell about the frame centroid, :440-461) and the wall
+// directions of the frames are independent of each other and of the walk: they are computed over the worker pool
+// (the farthest-pair scan is the O(n^2) part), then the transported direction is walked frame by frame.
+void align_walls_on_geometry(mm_cl_geometry* cg)
+{
+    mm_geometry* g = cg->g;
+    const int32_t F = g->n_frames;
+    if (F < 1) return;
+    const WallIndex wi(cg);
+    if (!wi.any()) return;                                        // no frame has a Wall contour (:512-515)
+    auto wall_of = [&](int32_t i) {
+        const int64_t lo = wi.lo(cg, i), hi = wi.hi(cg, i);
+        return WallView{g->extra + 3 * lo, cg->wall_aortic ? cg->wall_aortic + wi.at[(size_t)i] : nullptr, hi - lo};
+    };
+    std::vector<Vec3> normal((size_t)F), dir((size_t)F);
+    std::vector<uint8_t> kind((size_t)F, 0);                      // 0 = no usable direction, 1 = aortic side, 2 = major axis
+    parallel_for(F, [&](int i) {
+        const double* c = g->centroid + 3 * i;
+        normal[(size_t)i] = newell_normal(g->lumen + 3 * g->lumen_off[i], g->lumen_off[i + 1] - g->lumen_off[i],
+                                          Vec3{{c[0], c[1], c[2]}});
+        const WallView w = wall_of(i);
+        if (w.n <= 0) return;
+        if (aortic_direction(w, c, dir[(size_t)i])) kind[(size_t)i] = 1;
+        else if (major_axis(w, dir[(size_t)i])) kind[(size_t)i] = 2;
+    });
+    if (wall_of(0).n <= 0 || !kind[0]) return;                    // :512-520
+    Vec3 u;
+    if (!project_normalized(dir[0], normal[0], u)) return;        // :521-524
+    for (int32_t i = 1; i < F; ++i) {
+        const Vec3& tc = normal[(size_t)i];
+        u = parallel_transport(u, normal[(size_t)i - 1], tc);     // :531 (kept when the projection below fails)
+        Vec3 pu;
+        if (!project_normalized(u, tc, pu)) continue;             // :532-535
+        u = pu;
+        if (!kind[(size_t)i]) continue;                           // no wall / no direction (:540-550)
+        Vec3 v;
+        if (!project_normalized(dir[(size_t)i], tc, v)) continue; // :552-555
+        double ang;
+        if (kind[(size_t)i] == 1) ang = signed_angle(v, u, tc);   // :557-559
+        else {                                                    // :560-569 the sign of a major axis is ambiguous
+            const double a1 = signed_angle(v, u, tc), a2 = signed_angle(Vec3{{-v[0], -v[1], -v[2]}}, u, tc);
+            ang = std::fabs(a1) <= std::fabs(a2) ? a1 : a2;
+        }
+        if (std::fabs(ang) < 1e-6) continue;                      // :571-573
+        const Mat3 r = Mat3::axis_angle(tc, ang);                 // :575-587
+        const double* c = g->centroid + 3 * i;
+        const WallView w = wall_of(i);
+        for (int64_t k = 0; k < w.n; ++k) {
+            double* q = w.p + 3 * k;
+            const Vec3 rot = r * Vec3{{q[0] - c[0], q[1] - c[1], q[2] - c[2]}};
+            q[0] = c[0] + rot[0]; q[1] = c[1] + rot[1]; q[2] = c[2] + rot[2];
+        }
+    }
+}
+
+// align_walls (:589-595)
+void align_walls(mm_cl_geometry** geoms, int n_geoms, bool anomalous)
+{
+    if (!anomalous || geoms[0]->g->n_frames < 2) return;
+    for (int g = 0; g < n_geoms; ++g) align_walls_on_geometry(geoms[g]);
 }
 
 // best_rotation_three_point (align_algorithms.rs:263-336)
@@ -638,6 +802,14 @@ int mm_rotate_geometry(mm_cl_geometry* g, double angle)
     return MM_OK;
 }
 
+int mm_align_walls(mm_cl_geometry** geoms, int n_geoms, int anomalous)
+{
+    int rc = check_geoms(geoms, n_geoms);
+    if (rc) return rc;
+    align_walls(geoms, n_geoms, anomalous != 0);
+    return MM_OK;
+}
+
 int64_t mm_apply_transformations(mm_cl_geometry** geoms, int n_geoms, const mm_clpoint* cl, int64_t ncl,
                                  const double ref_pt[3])
 {
@@ -694,7 +866,6 @@ int mm_align_three_point(const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geo
 {
     int rc = check_geoms(geoms, n_geoms);
     if (rc) return rc;
-    if (align_wall_anomalous) return set_error(MM_ERR_INVALID, "align_wall_anomalous is not supported yet");
     if (!p_main || !p_ccw || !p_cw) return set_error(MM_ERR_INVALID, "mm_align_three_point: bad arguments");
     std::vector<mm_clpoint> rcl;
     double sp = 0.0;
@@ -705,6 +876,7 @@ int mm_align_three_point(const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geo
     std::vector<FrameTf> tfs;
     frame_transforms(geoms[0], rcl.data(), (int64_t)rcl.size(), p_main, tfs);                  // :103
     for (int g = 0; g < n_geoms; ++g) apply_transforms(geoms[g], tfs);
+    align_walls(geoms, n_geoms, align_wall_anomalous != 0);                                    // :105-107 / :147-149
     if (spacing) *spacing = sp;
     if (total_rotation) *total_rotation = rot;
     return MM_OK;
@@ -715,7 +887,6 @@ int mm_align_manual(const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geoms, i
 {
     int rc = check_geoms(geoms, n_geoms);
     if (rc) return rc;
-    if (align_wall_anomalous) return set_error(MM_ERR_INVALID, "align_wall_anomalous is not supported yet");
     if (!ref_pt) return set_error(MM_ERR_INVALID, "mm_align_manual: bad arguments");
     std::vector<mm_clpoint> rcl;
     double sp = 0.0;
@@ -725,6 +896,7 @@ int mm_align_manual(const mm_clpoint* cl, int64_t ncl, mm_cl_geometry** geoms, i
     std::vector<FrameTf> tfs;
     frame_transforms(geoms[0], rcl.data(), (int64_t)rcl.size(), ref_pt, tfs);                  // :145
     for (int g = 0; g < n_geoms; ++g) apply_transforms(geoms[g], tfs);
+    align_walls(geoms, n_geoms, align_wall_anomalous != 0);                                    // :105-107 / :147-149
     if (spacing) *spacing = sp;
     if (total_rotation) *total_rotation = rot;
     return MM_OK;
@@ -740,7 +912,6 @@ int mm_align_combined(mm_engine* h, const mm_clpoint* cl, int64_t ncl, mm_cl_geo
     if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
     int rc = check_geoms(geoms, n_geoms);
     if (rc) return rc;
-    if (align_wall_anomalous) return set_error(MM_ERR_INVALID, "align_wall_anomalous is not supported yet");
     if (!p_main || !p_ccw || !p_cw || n_points < 0 || (n_points > 0 && !points_xyz) || refine_index_range < 0)
         return set_error(MM_ERR_INVALID, "mm_align_combined: bad arguments");
     { const hipError_t he = hipSetDevice(e->device); if (he != hipSuccess) return hip_error(he, "hipSetDevice"); }
@@ -790,6 +961,7 @@ int mm_align_combined(mm_engine* h, const mm_clpoint* cl, int64_t ncl, mm_cl_geo
     for (int g = 0; g < n_geoms; ++g) rotate_geometry(geoms[g], total);                        // :260-264
     frame_transforms(geoms[0], rcl.data(), (int64_t)rcl.size(), ref_pt, tfs);
     for (int g = 0; g < n_geoms; ++g) apply_transforms(geoms[g], tfs);
+    align_walls(geoms, n_geoms, align_wall_anomalous != 0);                                    // :266-268
     if (spacing) *spacing = sp;
     if (total_rotation) *total_rotation = total;
     if (refined_idx) *refined_idx = ridx;

@@ -225,7 +225,9 @@ static int sort_cmp(const void* a, const void* b)
     return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);   /* sort_by is stable */
 }
 
-void orc_sort_contour_points(orc_point* pts, size_t n)
+void orc_sort_contour_points(orc_point* pts, size_t n) { orc_sort_contour_points_flags(pts, NULL, n); }
+
+void orc_sort_contour_points_flags(orc_point* pts, uint8_t* flags, size_t n)
 {
     if (n == 0) return;
     double sx = 0.0, sy = 0.0;
@@ -239,7 +241,25 @@ void orc_sort_contour_points(orc_point* pts, size_t n)
     size_t start = 0;                                                                /* :393-401: max_by keeps the LAST maximum */
     for (size_t i = 1; i < n; ++i) if (!(tmp[i].y < tmp[start].y)) start = i;
     for (size_t i = 0; i < n; ++i) pts[i] = tmp[(i + start) % n];                    /* rotate_left */
+    if (flags) {                                                                     /* the flag is a field of the point */
+        uint8_t* tf = (uint8_t*)malloc(n);
+        for (size_t i = 0; i < n; ++i) tf[i] = flags[e[(i + start) % n].idx];
+        memcpy(flags, tf, n);
+        free(tf);
+    }
     free(tmp); free(e);
+}
+
+/* wall points of the frames before `frame` = the frame's offset into wall_aortic */
+static int64_t wall_points_before(const orc_clgeom* cg, int32_t frame)
+{
+    if (!cg->wall_kind1 || !cg->g->extra_off) return 0;
+    const int32_t K = cg->extra_kind_off ? cg->n_extra_kinds : 1, w = cg->wall_kind1 - 1;
+    int64_t n = 0;
+    for (int32_t i = 0; i < frame; ++i)
+        n += cg->extra_kind_off ? cg->extra_kind_off[(int64_t)i * K + w + 1] - cg->extra_kind_off[(int64_t)i * K + w]
+                                : cg->g->extra_off[i + 1] - cg->g->extra_off[i];
+    return n;
 }
 
 /* ---- geometry.rs:241-250 ---------------------------------------------------------------- */
@@ -250,18 +270,21 @@ void orc_rotate_geometry(orc_clgeom* cg, double angle)
     for (int32_t i = 0; i < g->n_frames; ++i) {
         orc_frame_rotate(g, i, angle, g->centroid[3 * i], g->centroid[3 * i + 1]);   /* :246-247 */
         /* frame.rs:123-129 sort_frame_points: lumen and every extras contour */
-        orc_sort_contour_points(g->lumen + g->lumen_off[i], (size_t)(g->lumen_off[i + 1] - g->lumen_off[i]));
+        orc_sort_contour_points_flags(g->lumen + g->lumen_off[i], cg->lumen_aortic ? cg->lumen_aortic + g->lumen_off[i] : NULL,
+                                      (size_t)(g->lumen_off[i + 1] - g->lumen_off[i]));
         if (g->cath_off)
             orc_sort_contour_points(g->cath + g->cath_off[i], (size_t)(g->cath_off[i + 1] - g->cath_off[i]));
         if (g->extra_off) {
+            uint8_t* wf = cg->wall_aortic && cg->wall_kind1 ? cg->wall_aortic + wall_points_before(cg, i) : NULL;
             if (cg->extra_kind_off && cg->n_extra_kinds > 0) {
                 for (int32_t k = 0; k < cg->n_extra_kinds; ++k) {
                     int64_t lo = cg->extra_kind_off[(int64_t)i * cg->n_extra_kinds + k];
                     int64_t hi = cg->extra_kind_off[(int64_t)i * cg->n_extra_kinds + k + 1];
-                    orc_sort_contour_points(g->extra + lo, (size_t)(hi - lo));
+                    orc_sort_contour_points_flags(g->extra + lo, k == cg->wall_kind1 - 1 ? wf : NULL, (size_t)(hi - lo));
                 }
             } else {
-                orc_sort_contour_points(g->extra + g->extra_off[i], (size_t)(g->extra_off[i + 1] - g->extra_off[i]));
+                orc_sort_contour_points_flags(g->extra + g->extra_off[i], cg->wall_kind1 == 1 ? wf : NULL,
+                                              (size_t)(g->extra_off[i + 1] - g->extra_off[i]));
             }
         }
     }
@@ -567,12 +590,147 @@ static int three_point_initial(const orc_clpoint* rcl, size_t nrcl, orc_clgeom**
     return 0;
 }
 
+/* ---- align.rs:381-595 wall twist compensation -------------------------------------------- */
+typedef struct { const orc_point* p; const uint8_t* aortic; size_t n; int present; } wall_view;
+
+static wall_view wall_of(const orc_clgeom* cg, int32_t i)
+{
+    wall_view w = { NULL, NULL, 0, 0 };
+    const orc_geometry* g = cg->g;
+    if (!cg->wall_kind1 || !g->extra_off) return w;
+    const int32_t K = cg->extra_kind_off ? cg->n_extra_kinds : 1, k = cg->wall_kind1 - 1;
+    int64_t lo = cg->extra_kind_off ? cg->extra_kind_off[(int64_t)i * K + k] : g->extra_off[i];
+    int64_t hi = cg->extra_kind_off ? cg->extra_kind_off[(int64_t)i * K + k + 1] : g->extra_off[i + 1];
+    w.p = g->extra + lo; w.n = (size_t)(hi - lo); w.present = hi > lo;
+    w.aortic = cg->wall_aortic ? cg->wall_aortic + wall_points_before(cg, i) : NULL;
+    return w;
+}
+/* :385-407 aortic_centroid_direction */
+static int aortic_direction(wall_view w, const double c[3], double out[3])
+{
+    size_t m = 0;
+    if (w.aortic) for (size_t i = 0; i < w.n; ++i) m += w.aortic[i] ? 1 : 0;
+    if (m == 0) return 0;
+    double n = (double)m, sx = 0.0, sy = 0.0, sz = 0.0;
+    for (size_t i = 0; i < w.n; ++i) if (w.aortic[i]) sx += w.p[i].x;
+    for (size_t i = 0; i < w.n; ++i) if (w.aortic[i]) sy += w.p[i].y;
+    for (size_t i = 0; i < w.n; ++i) if (w.aortic[i]) sz += w.p[i].z;
+    out[0] = sx / n - c[0]; out[1] = sy / n - c[1]; out[2] = sz / n - c[2];
+    return !(v3_norm(out) < 1e-9);
+}
+/* :410-437 wall_major_axis */
+static int major_axis(wall_view w, double out[3])
+{
+    if (w.n < 2) return 0;
+    double best = 0.0; size_t fa = 0, fb = 0;
+    for (size_t i = 0; i < w.n; ++i)
+        for (size_t j = i + 1; j < w.n; ++j) {
+            double dx = w.p[i].x - w.p[j].x, dy = w.p[i].y - w.p[j].y, dz = w.p[i].z - w.p[j].z;
+            double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 > best) { best = d2; fa = i; fb = j; }
+        }
+    out[0] = w.p[fb].x - w.p[fa].x; out[1] = w.p[fb].y - w.p[fa].y; out[2] = w.p[fb].z - w.p[fa].z;
+    return !(v3_norm(out) < 1e-9);
+}
+/* :440-461 lumen_normal: Newell about the FRAME centroid */
+static void lumen_normal(const orc_geometry* g, int32_t i, double out[3])
+{
+    orc_newell_normal(g->lumen + g->lumen_off[i], (size_t)(g->lumen_off[i + 1] - g->lumen_off[i]), &g->centroid[3 * i], out);
+}
+/* :465-472 */
+static int project_normalized(const double v[3], const double t[3], double out[3])
+{
+    double k = v3_dot(v, t);
+    double p[3] = { v[0] - t[0] * k, v[1] - t[1] * k, v[2] - t[2] * k };
+    double n = v3_norm(p);
+    if (n < 1e-9) return 0;
+    out[0] = p[0] / n; out[1] = p[1] / n; out[2] = p[2] / n;
+    return 1;
+}
+/* :476-492 */
+static void parallel_transport(const double v[3], const double tf[3], const double tt[3], double out[3])
+{
+    double ang = v3_angle(tf, tt);
+    if (ang < 1e-9) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; return; }
+    double axis[3], r[9];
+    v3_cross(tf, tt, axis);
+    if (v3_norm(axis) < 1e-9) {
+        double perp[3];
+        if (fabs(tf[0]) < 0.9) { perp[0] = 1.0 - tf[0] * tf[0]; perp[1] = 0.0 - tf[1] * tf[0]; perp[2] = 0.0 - tf[2] * tf[0]; }
+        else                   { perp[0] = 0.0 - tf[0] * tf[1]; perp[1] = 1.0 - tf[1] * tf[1]; perp[2] = 0.0 - tf[2] * tf[1]; }
+        double n = v3_norm(perp);
+        perp[0] /= n; perp[1] /= n; perp[2] /= n;
+        m3_axis_angle(perp, 3.14159265358979323846, r);
+    } else {
+        m3_axis_angle(axis, ang, r);
+    }
+    double o[3];
+    m3_mul(r, v, o);
+    out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
+}
+/* :495-497 */
+static double signed_angle(const double from[3], const double to[3], const double axis[3])
+{
+    double c[3];
+    v3_cross(from, to, c);
+    return atan2(v3_dot(c, axis), v3_dot(from, to));
+}
+/* :507-584 align_walls_on_geometry */
+static void align_walls_on_geometry(orc_clgeom* cg)
+{
+    orc_geometry* g = cg->g;
+    if (g->n_frames < 1) return;
+    double t0[3], d0[3], u[3];
+    lumen_normal(g, 0, t0);
+    wall_view w0 = wall_of(cg, 0);
+    if (!w0.present) return;
+    if (!aortic_direction(w0, &g->centroid[0], d0) && !major_axis(w0, d0)) return;
+    if (!project_normalized(d0, t0, u)) return;
+    for (int32_t i = 1; i < g->n_frames; ++i) {
+        double tp[3], tc[3], tr[3], pu[3];
+        lumen_normal(g, i - 1, tp);
+        lumen_normal(g, i, tc);
+        parallel_transport(u, tp, tc, tr);
+        u[0] = tr[0]; u[1] = tr[1]; u[2] = tr[2];                  /* `u = parallel_transport(..)` is kept even when ... */
+        if (!project_normalized(u, tc, pu)) continue;              /* ... the projection fails (:537-540) */
+        u[0] = pu[0]; u[1] = pu[1]; u[2] = pu[2];
+        const double* c = &g->centroid[3 * i];
+        wall_view w = wall_of(cg, i);
+        if (!w.present) continue;
+        double d[3], v[3];
+        int has_aortic = aortic_direction(w, c, d);
+        if (!has_aortic && !major_axis(w, d)) continue;
+        if (!project_normalized(d, tc, v)) continue;
+        double ang;
+        if (has_aortic) ang = signed_angle(v, u, tc);
+        else {
+            double nv[3] = { -v[0], -v[1], -v[2] };
+            double a1 = signed_angle(v, u, tc), a2 = signed_angle(nv, u, tc);
+            ang = fabs(a1) <= fabs(a2) ? a1 : a2;
+        }
+        if (fabs(ang) < 1e-6) continue;
+        double r[9];
+        m3_axis_angle(tc, ang, r);
+        orc_point* wp = (orc_point*)w.p;
+        for (size_t k = 0; k < w.n; ++k) {
+            double rel[3] = { wp[k].x - c[0], wp[k].y - c[1], wp[k].z - c[2] }, o[3];
+            m3_mul(r, rel, o);
+            wp[k].x = c[0] + o[0]; wp[k].y = c[1] + o[1]; wp[k].z = c[2] + o[2];
+        }
+    }
+}
+/* :589-595 */
+void orc_align_walls(orc_clgeom** geoms, int n_geoms, int anomalous)
+{
+    if (!anomalous || geoms[0]->g->n_frames < 2) return;
+    for (int gi = 0; gi < n_geoms; ++gi) align_walls_on_geometry(geoms[gi]);
+}
+
 int orc_align_three_point(const orc_clpoint* cl, size_t ncl, orc_clgeom** geoms, int n_geoms,
                           uint32_t ref_point_index, const double p_main[3], const double p_ccw[3],
                           const double p_cw[3], double angle_step, int align_wall_anomalous,
                           double* spacing, double* total_rotation)
 {
-    if (align_wall_anomalous) return -6;  /* align_walls (align.rs:381-595) is not restated yet */
     orc_clpoint* rcl = NULL; size_t nrcl = 0;
     int rc = cl_prepare(cl, ncl, geoms[0]->g, &rcl, &nrcl, spacing);                 /* :78-80 */
     if (rc) return rc;
@@ -581,6 +739,7 @@ int orc_align_three_point(const orc_clpoint* cl, size_t ncl, orc_clgeom** geoms,
     if (rc) { free(rcl); return rc; }
     for (int gi = 0; gi < n_geoms; ++gi) orc_rotate_geometry(geoms[gi], rot);        /* :102 */
     orc_apply_transformations(geoms, n_geoms, rcl, nrcl, p_main);                    /* :103 */
+    orc_align_walls(geoms, n_geoms, align_wall_anomalous);                           /* :105-107 */
     *total_rotation = rot;
     free(rcl);
     return 0;
@@ -590,13 +749,13 @@ int orc_align_manual(const orc_clpoint* cl, size_t ncl, orc_clgeom** geoms, int 
                      double rotation_angle_deg, const double ref_pt[3], int align_wall_anomalous,
                      double* spacing, double* total_rotation)
 {
-    if (align_wall_anomalous) return -6;
     orc_clpoint* rcl = NULL; size_t nrcl = 0;
     int rc = cl_prepare(cl, ncl, geoms[0]->g, &rcl, &nrcl, spacing);                 /* :139-141 */
     if (rc) return rc;
     double rot = rotation_angle_deg * (3.14159265358979323846 / 180.0);              /* :143 to_radians */
     for (int gi = 0; gi < n_geoms; ++gi) orc_rotate_geometry(geoms[gi], rot);        /* :144 */
     orc_apply_transformations(geoms, n_geoms, rcl, nrcl, ref_pt);                    /* :145 */
+    orc_align_walls(geoms, n_geoms, align_wall_anomalous);                           /* :147-149 */
     *total_rotation = rot;
     free(rcl);
     return 0;
@@ -609,7 +768,6 @@ int orc_align_combined(const orc_clpoint* cl, size_t ncl, orc_clgeom** geoms, in
                        int align_wall_anomalous, double* spacing, double* total_rotation,
                        size_t* refined_idx_out)
 {
-    if (align_wall_anomalous) return -6;
     if (n_geoms > 2) return -7;
     orc_clpoint* rcl = NULL; size_t nrcl = 0;
     int rc = cl_prepare(cl, ncl, geoms[0]->g, &rcl, &nrcl, spacing);                 /* :191-195 */
@@ -633,6 +791,7 @@ int orc_align_combined(const orc_clpoint* cl, size_t ncl, orc_clgeom** geoms, in
     double refined_ref_pt[3] = { rcl[refined_idx].x, rcl[refined_idx].y, rcl[refined_idx].z }; /* :248-258 */
     for (int gi = 0; gi < n_geoms; ++gi) orc_rotate_geometry(geoms[gi], total);      /* :260-264 */
     orc_apply_transformations(geoms, n_geoms, rcl, nrcl, refined_ref_pt);
+    orc_align_walls(geoms, n_geoms, align_wall_anomalous);                           /* :266-268 */
     *total_rotation = total;
     if (refined_idx_out) *refined_idx_out = refined_idx;
     free(rcl);

@@ -56,6 +56,11 @@ typedef struct {
     double*   lumen_centroid;      /* [F*3]                                                   */
     int32_t   n_extra_kinds;       /* K: extras contours per frame inside g->extra (not cath) */
     int64_t*  extra_kind_off;      /* [F*K+1] CSR over (frame,kind) into g->extra, or NULL    */
+    /* ContourPoint.aortic of the lumen and the Wall contour: they travel with their points when a contour is
+     * sorted (contour.rs:385-390 moves whole ContourPoints); align_walls reads the wall's (align.rs:385-407) */
+    uint8_t*  lumen_aortic;        /* [lumen points] or NULL = all false                      */
+    uint8_t*  wall_aortic;         /* [wall points, frame by frame] or NULL = all false       */
+    int32_t   wall_kind1;          /* 1 + index of the Wall contour among the K kinds; 0 = no Wall contours */
 } orc_clgeom;
 
 /* centerline.rs:14-42.  Returns 0, or -1 when the reference would panic (n == 1). */
@@ -68,6 +73,11 @@ int64_t orc_preprocess_centerline(const orc_clpoint* cl, size_t n, const orc_geo
                                   orc_clpoint* out, size_t cap, double* spacing);
 
 void   orc_sort_contour_points(orc_point* pts, size_t n);               /* contour.rs:368-405   */
+void   orc_sort_contour_points_flags(orc_point* pts, uint8_t* flags, size_t n);  /* flags (nullable) follow their points */
+/* align_walls (align.rs:381-595): with anomalous != 0 and >= 2 frames in geoms[0], the Wall contour of every frame
+ * of every geometry is rotated about the lumen normal onto the parallel-transported direction of frame 0's wall.
+ * PARITY UNPINNED: the reference holds no test of it. */
+void   orc_align_walls(orc_clgeom** geoms, int n_geoms, int anomalous);
 void   orc_rotate_geometry(orc_clgeom* g, double angle);                /* geometry.rs:241-250  */
 void   orc_newell_normal(const orc_point* pts, size_t n, const double c[3], double out[3]); /* :206-235 */
 void   orc_align_frame(const orc_point* pts, size_t n, int has_centroid, const double centroid[3],

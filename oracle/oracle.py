@@ -252,6 +252,9 @@ class OracleGeometry:
     lumen_centroids: Optional[np.ndarray] = None      # (F,3) f64
     n_extra_kinds: int = 0
     extra_kind_off: Optional[np.ndarray] = None       # (F*K+1,) i64
+    lumen_aortic: Optional[np.ndarray] = None         # (lumen points,) u8  ContourPoint.aortic, follows its point in sorts
+    wall_aortic: Optional[np.ndarray] = None          # (wall points,) u8
+    wall_kind1: int = 0                               # 1 + index of the Wall contour among the K kinds; 0 = none
 
     @property
     def n_frames(self) -> int:
@@ -306,6 +309,7 @@ class OracleGeometry:
                            cp(self.extra_off), cp(self.extra), cp(self.has_ref), cp(self.ref), self.label)
         g.has_lumen_centroid, g.lumen_centroids = cp(self.has_lumen_centroid), cp(self.lumen_centroids)
         g.n_extra_kinds, g.extra_kind_off = self.n_extra_kinds, cp(self.extra_kind_off)
+        g.lumen_aortic, g.wall_aortic, g.wall_kind1 = cp(self.lumen_aortic), cp(self.wall_aortic), self.wall_kind1
         return g
 
     def frame_lumen(self, i) -> np.ndarray:

@@ -20,7 +20,8 @@ CL_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("tx", "<f8"), ("
 
 class _ClGeom(C.Structure):
     _fields_ = [("g", C.POINTER(O._Geometry)), ("has_lumen_centroid", C.c_void_p),
-                ("lumen_centroid", C.c_void_p), ("n_extra_kinds", C.c_int32), ("extra_kind_off", C.c_void_p)]
+                ("lumen_centroid", C.c_void_p), ("n_extra_kinds", C.c_int32), ("extra_kind_off", C.c_void_p),
+                ("lumen_aortic", C.c_void_p), ("wall_aortic", C.c_void_p), ("wall_kind1", C.c_int32)]
 
 
 class _FrameTf(C.Structure):
@@ -63,6 +64,8 @@ def lib():
     L.orc_refine_alignment_hausdorff.restype = C.c_int
     L.orc_refine_alignment_hausdorff.argtypes = [P, C.c_int, P, Z, Z, D, P, Z, D, D, Z, C.POINTER(D),
                                                  C.POINTER(Z), C.POINTER(D), P, Z, C.POINTER(Z)]
+    L.orc_align_walls.restype = None
+    L.orc_align_walls.argtypes = [P, C.c_int, C.c_int]
     L.orc_align_three_point.restype = C.c_int
     L.orc_align_three_point.argtypes = [P, Z, P, C.c_int, C.c_uint32, P, P, P, D, C.c_int, C.POINTER(D), C.POINTER(D)]
     L.orc_align_manual.restype = C.c_int
@@ -97,6 +100,12 @@ class _GeomPack:
             c.lumen_centroid = O._p(g.lumen_centroids)
             c.n_extra_kinds = int(g.n_extra_kinds)
             c.extra_kind_off = O._p(g.extra_kind_off)
+            for name in ("lumen_aortic", "wall_aortic"):
+                a = getattr(g, name)
+                if a is not None:
+                    assert a.dtype == np.uint8 and a.flags.c_contiguous, name
+                    setattr(c, name, O._p(a))
+            c.wall_kind1 = int(g.wall_kind1)
             self.cls.append(c)
         self.arr = (C.POINTER(_ClGeom) * len(geoms))(*[C.pointer(c) for c in self.cls])
 
@@ -248,7 +257,13 @@ def refine_alignment_hausdorff(geoms: Sequence[O.OracleGeometry], cl, initial_cl
 
 _ERR = {-1: "Centerline has no branch-0 points", -3: "Reference mesh has no frames",
         -4: "Couldn't find ref frame idx", -5: "missing reference point",
-        -6: "align_walls is not restated", -7: "at most two geometries"}
+        -7: "at most two geometries"}
+
+
+def align_walls(geoms, anomalous=True):
+    """align_walls (align.rs:589-595), in place.  PARITY UNPINNED (no reference test)."""
+    pk = _GeomPack(geoms)
+    lib().orc_align_walls(pk.ptr, len(geoms), int(anomalous))
 
 
 def align_three_point(cl, geoms, ref_point_index, p_main, p_ccw, p_cw, angle_step, align_wall_anomalous=False):

@@ -22,6 +22,12 @@ def to_oracle(orc, g):
         ko = np.zeros(per.size + 1, dtype=np.int64)
         ko[1:] = np.cumsum(per.reshape(-1))
         og.n_extra_kinds, og.extra_kind_off = len(kinds), ko
+        if "wall" in kinds and int(np.sum(counts["wall"])) > 0:
+            og.wall_kind1 = kinds.index("wall") + 1
+    for key in ("lumen_aortic", "wall_aortic"):                     # ContourPoint.aortic, per point
+        fl = g.meta.get(key) if hasattr(g, "meta") else None
+        if fl is not None:
+            setattr(og, key, np.ascontiguousarray(fl, dtype=np.uint8).copy())
     return og
 
 

@@ -189,3 +189,59 @@ def test_centerline_resample_and_branches(built, mm):              # centerline.
         r.get_branch(7)
     assert two.mean_spacing() == 10.0 and mm.Centerline.from_contour_points([[0.0, 0, 0], [3.0, 4.0, 0]]).mean_spacing() == 5.0
     assert len(cl.resample(0.0)) == 5
+
+
+def _walled(mm, case, thickness):
+    """The case's pullback after the post-steps of align_frames_in_geometry (host only): with an aortic thickness
+    it is an anomalous coronary -- lumen and wall points carry ContourPoint.aortic -- otherwise plain offset walls."""
+    from multimoda_rs_amd import native_frames as NF
+    g = case["geometry"].copy()
+    F = g.n_frames
+    g.meta["aortic_thickness"] = [thickness] * F
+    g.meta["pulmonary_thickness"] = [None] * F
+    w, anomalous = NF.finish_within(g, int(np.nonzero(g.has_ref)[0][0]), True)
+    assert anomalous == (thickness is not None) and int(w.meta["extra_counts"]["wall"].sum()) > 0
+    w.meta["ref_point_index"] = g.meta["ref_point_index"]
+    return w
+
+
+@pytest.mark.parametrize("thickness", [0.9, None])
+def test_align_walls_native_equals_oracle_and_python(built, mm, ocl, oracle, case, thickness, monkeypatch):
+    """align_walls (align.rs:381-595; the reference holds no test of it -> parity is against the restatements only):
+    mm_align_walls inside mm_align_manual == oracle == the Python checker, bit for bit, for walls with an aortic side
+    (unambiguous direction) and without (major axis, smaller rotation); the per-point aortic flags follow their
+    points through rotate_geometry's sort (contour.rs:385-390 moves whole ContourPoints)."""
+    g = _walled(mm, case, thickness)
+    ocl_cl = to_oracle_cl(ocl, case["centerline"])
+    ref = case["truth"]["placed"].centroids[0]
+    out, sp, rot = mm.align_manual(case["centerline"], g, -52.0, ref, align_wall_anomalous=True)
+    og = to_oracle(oracle, g)
+    assert og.wall_kind1 > 0 and (og.wall_aortic is not None) == (thickness is not None)
+    osp, orot = ocl.align_manual(ocl_cl, [og], -52.0, ref, align_wall_anomalous=True)
+    assert sp == osp and geoms_equal(out, og)
+    plain, _, _ = mm.align_manual(case["centerline"], g, -52.0, ref)
+    assert np.array_equal(plain.lumen, out.lumen) and not np.array_equal(plain.extra, out.extra)   # walls moved, only walls
+    if thickness is not None:
+        assert np.array_equal(out.meta["wall_aortic"].astype(np.uint8), og.wall_aortic)
+        assert np.array_equal(out.meta["lumen_aortic"].astype(np.uint8), og.lumen_aortic)
+        assert not np.array_equal(out.meta["wall_aortic"], g.meta["wall_aortic"])                   # the sort moved them
+        # the aortic side of every wall points along one parallel-transported direction: consecutive frames agree
+        F = out.n_frames
+        per = out.meta["extra_counts"]["wall"]
+        off = np.concatenate([[0], np.cumsum(per)])
+        walls = out.extra.reshape(-1, 3)[-int(per.sum()):] if out.meta["extra_counts"]["eem"].sum() == 0 else None
+        if walls is not None:
+            dirs = []
+            for i in range(F):
+                w, fl = walls[off[i]:off[i + 1]], out.meta["wall_aortic"][off[i]:off[i + 1]]
+                d = w[fl].mean(axis=0) - out.centroids[i]
+                dirs.append(d / np.linalg.norm(d))
+            assert min(float(np.dot(dirs[i], dirs[i + 1])) for i in range(F - 1)) > 0.99
+    monkeypatch.setenv("MM_PY_POSTPROC", "1")
+    py, _, _ = mm.align_manual(case["centerline"], g, -52.0, ref, align_wall_anomalous=True)
+    assert np.array_equal(py.extra, out.extra) and np.array_equal(py.lumen, out.lumen)
+    monkeypatch.delenv("MM_PY_POSTPROC")
+    # the standalone entry point, and anomalous = false / a single frame: nothing moves (:589-592)
+    again = mm.centerline.align_walls(plain, True)
+    assert np.array_equal(again.extra, out.extra)
+    assert np.array_equal(mm.centerline.align_walls(plain, False).extra, plain.extra)

@@ -9,7 +9,7 @@ import math
 import numpy as np
 import pytest
 
-from helpers import to_oracle, to_oracle_cl
+from helpers import geoms_equal, to_oracle, to_oracle_cl
 from test_golden_and_api import _array_input
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def test_full_workflow_synthetic(engine, mm, oracle):
     aligned, spacing_mm, rot_deg = mm.align_combined(case["centerline"], geo, case["main_ref_pt"], case["ccw_ref_pt"],
                                                      case["cw_ref_pt"], case["points"], angle_range_deg=6.0,
                                                      align_wall_anomalous=True, engine=engine)
-    # placement parity (without the wall step, which the oracle does not restate) and recovery of the pose
+    # placement parity, without and with the wall step, and recovery of the pose
     plain, sp2, rot2 = mm.align_combined(case["centerline"], geo, case["main_ref_pt"], case["ccw_ref_pt"],
                                          case["cw_ref_pt"], case["points"], angle_range_deg=6.0, engine=engine)
     oa, ob = to_oracle(oracle, geo.geom_a), to_oracle(oracle, geo.geom_b)
@@ -40,8 +40,16 @@ def test_full_workflow_synthetic(engine, mm, oracle):
                                          case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"], case["points"],
                                          math.radians(1.0), math.radians(6.0), 2)
     assert (sp2, rot2) == (osp, orot * (180.0 / math.pi)) == (spacing_mm, rot_deg)
-    assert np.array_equal(plain.geom_a.lumen, oa.lumen) and np.array_equal(plain.geom_b.lumen, ob.lumen)
+    assert geoms_equal(plain.geom_a, oa) and geoms_equal(plain.geom_b, ob)
+    wa, wb = to_oracle(oracle, geo.geom_a), to_oracle(oracle, geo.geom_b)
+    assert wa.wall_kind1 > 0 and wa.wall_aortic is not None and wa.wall_aortic.any()
+    ocl.align_combined(to_oracle_cl(ocl, case["centerline"]), [wa, wb], geo.geom_a.meta["ref_point_index"],
+                       case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"], case["points"],
+                       math.radians(1.0), math.radians(6.0), 2, align_wall_anomalous=True)
+    assert geoms_equal(aligned.geom_a, wa) and geoms_equal(aligned.geom_b, wb)
+    assert np.array_equal(aligned.geom_a.meta["wall_aortic"].astype(np.uint8), wa.wall_aortic)
     assert np.array_equal(aligned.geom_a.lumen, plain.geom_a.lumen)                  # align_walls moves walls only
+    assert not np.array_equal(aligned.geom_a.extra, plain.geom_a.extra)
     assert rot_deg == pytest.approx(21.0, abs=1.0 + 1e-9) and abs(oidx - 7) <= 2
     assert spacing_mm == pytest.approx(np.linalg.norm(np.diff(a.centroids, axis=0), axis=1).mean(), rel=1e-12)
 
