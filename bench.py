@@ -435,7 +435,8 @@ def main():
                         for g, h in zip(leg["last_case"], main_leg["last_case"])))
 
     extra = {}
-    if args.precision == "fast" and ext is None and mode == 1 and not args.no_extra_legs:
+    # (N = 1 only: at N > 1 the line is the scaling measurement and nothing else is put between it and the driver)
+    if args.precision == "fast" and ext is None and mode == 1 and not args.no_extra_legs and world == 1:
         # The same workload through MM_PRECISION_F32_BOUNDED (lower bounds rule most candidates out before the
         # screen; winners identical).  Reported beside the headline, never as `value`: a candidate that is ruled
         # out is resolved, not evaluated, so these are not pose-evals in SURVEY 8(d)'s sense.

@@ -14,7 +14,9 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmm_hausdorff.so")
+# MM_LIB_PATH: another build of the same library (tools/asan_host.sh runs the CPU suite on an AddressSanitizer build
+# of the host code); never a fallback -- a path that does not exist fails like a missing in-tree build
+LIB_PATH = os.environ.get("MM_LIB_PATH") or os.path.join(_HERE, "lib", "libmm_hausdorff.so")
 
 MM_PRECISION_F64 = 0
 MM_PRECISION_F32 = 1
