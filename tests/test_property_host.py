@@ -1,0 +1,144 @@
+"""Randomised parity of the host code behind the C ABI (hypothesis): the reader + geometry builder against the
+independent restatement in tests/refbuild.py on generated CSV directories, and the frame bookkeeping
+(mm_frames_finish_within / mm_frames_postprocess_pair) against its Python checker on generated pullbacks with
+holes, measured wall thicknesses and EEM contours.  Host only; every comparison is bit for bit."""
+import math
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import refbuild
+from test_native_frames import assert_same
+
+SET = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+SCALE = int(os.environ.get("MM_HYP_SCALE", "1"))      # MM_HYP_SCALE=20: a longer soak of the same properties
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+
+
+def _fmt(rng, v):
+    """One of the float spellings Rust's str::parse::<f64> and the product's reader must agree on."""
+    k = int(rng.integers(0, 5))
+    if k == 0:
+        return repr(float(v))
+    if k == 1:
+        return f"{v:.6f}"
+    if k == 2:
+        return f"{v:.9e}"
+    if k == 3:
+        return f"{v:.3f}".rstrip("0").rstrip(".") or "0"          # integers without a dot
+    return ("+" if v >= 0 else "") + f"{v:.12g}"
+
+
+@settings(max_examples=40 * SCALE, **SET)
+@given(seed=st.integers(0, 2**31 - 1), n_frames=st.integers(1, 9), m=st.integers(3, 24), tab=st.booleans(),
+       with_records=st.booleans(), diastole=st.booleans())
+def test_reader_and_builder_equal_the_independent_builder(built, mm, tmp_path_factory, seed, n_frames, m, tab, with_records,
+                                                          diastole):
+    rng = np.random.default_rng(seed)
+    d = tmp_path_factory.mktemp("csv")
+    sep = "\t" if tab else ","
+    frames = sorted(int(f) for f in rng.choice(np.arange(1, 60), size=n_frames, replace=False))
+    phase = "diastolic" if diastole else "systolic"
+    rows = []
+    for f in frames:
+        t = np.sort(rng.uniform(0, 2 * math.pi, m))
+        r = 2.0 + 0.4 * rng.standard_normal()
+        z = round(float(0.37 * f + rng.uniform(0, 0.01)), 4)
+        zs = _fmt(rng, z)
+        for a in t:
+            x, y = 4.5 + r * math.cos(a) + 0.05 * rng.standard_normal(), 4.4 + 0.8 * r * math.sin(a) + 0.05 * rng.standard_normal()
+            rows.append(sep.join([str(f), _fmt(rng, x), _fmt(rng, y), zs]))
+    order = rng.permutation(len(rows)) if rng.integers(0, 2) else np.arange(len(rows))    # rows of a frame need not be adjacent
+    junk = ["", sep.join(["x", "1", "2", "3"]), sep.join(["7.0", "1", "2", "3"]), sep.join(["3", "1", "2"])]
+    lines = [rows[i] for i in order]
+    for j in junk:                                                 # rows the reader must skip, anywhere but first
+        lines.insert(int(rng.integers(1, len(lines) + 1)), j)
+    (d / f"{phase}_contours.csv").write_text("\n".join(lines) + "\n")
+    rf = frames[int(rng.integers(0, len(frames)))]
+    (d / f"{phase}_reference_points.csv").write_text(sep.join([str(rf), _fmt(rng, 6.1), _fmt(rng, 4.2), _fmt(rng, 0.37 * rf)]) + "\n")
+    if with_records:
+        rec = ["frame" + sep + "phase" + sep + "measurement_1" + sep + "measurement_2"]
+        pool = frames + [int(f) for f in rng.integers(60, 70, size=2)]
+        for f in rng.choice(pool, size=int(rng.integers(1, len(pool) + 2)), replace=True):
+            rec.append(sep.join([str(int(f)), str(rng.choice(["D", "S", "X"])),
+                                 "" if rng.integers(0, 3) == 0 else _fmt(rng, rng.uniform(0.5, 3)),
+                                 "" if rng.integers(0, 3) == 0 else _fmt(rng, rng.uniform(0.5, 3))]))
+        (d / "combined_sorted_manual.csv").write_text("\n".join(rec) + "\n")
+    n_points = int(rng.choice([0, 5, 20]))
+    g = mm.build_geometry_from_inputdata(None, str(d), "x", diastole, n_points=n_points)
+    b = refbuild.build_geometry(str(d), diastole, n_points=n_points)
+    assert list(g.ids) == b["ids"] and list(g.orig_frames) == b["orig_frames"]
+    assert np.array_equal(g.centroids, np.array(b["centroids"]))
+    for i in range(len(b["ids"])):
+        assert np.array_equal(g.frame_lumen(i), b["lumens"][i]), i
+        if n_points:
+            assert np.array_equal(g.frame_cath(i), b["catheters"][i]), i
+    assert {i for i in range(g.n_frames) if g.has_ref[i]} == set(b["ref_points"])
+    for i, p in b["ref_points"].items():
+        assert list(g.ref[i]) == p
+
+
+def _pullback(mm, rng, F, m, holes, thick, eem):
+    """A pullback with `holes` missing original frame indices in the middle, optional measured thicknesses / EEM."""
+    s = mm.synthetic_pullback(F, m, pullback_id=int(rng.integers(0, 4)), seed=int(rng.integers(0, 1000)))
+    orig = np.arange(F, dtype=np.int64) * 1
+    for h in sorted(holes, reverse=True):
+        orig[orig > h] += 1                        # a gap in the original frame numbering: fill_holes inserts a frame
+    # the builder leaves frames proximal-first = descending original index
+    s.orig_frames[:] = orig[::-1].astype(np.uint32)
+    zero = lambda: np.zeros(F, dtype=np.int64)
+    s.meta["extra_counts"] = {"eem": zero(), "calcification": zero(), "sidebranch": zero(), "wall": zero()}
+    s.meta["aortic_thickness"] = [float(rng.uniform(0.5, 1.2)) if thick and rng.integers(0, 2) else None for _ in range(F)]
+    s.meta["pulmonary_thickness"] = [float(rng.uniform(0.8, 1.6)) if thick and rng.integers(0, 3) == 0 else None for _ in range(F)]
+    if eem:
+        L = s.lumen.reshape(F, m, 3)
+        c = s.centroids[:, None, :]
+        e = c + (L - c) * float(rng.uniform(1.15, 1.5))
+        e[..., 2] = L[..., 2]
+        s.extra = np.ascontiguousarray(e.reshape(-1, 3))
+        s.extra_off = np.arange(F + 1, dtype=np.int64) * m
+        s.meta["extra_counts"]["eem"] = np.full(F, m, dtype=np.int64)
+    return s
+
+
+@settings(max_examples=25 * SCALE, **SET)
+@given(seed=st.integers(0, 2**31 - 1), F=st.integers(3, 10), m=st.sampled_from([8, 12, 30, 41]), n_holes=st.integers(0, 2),
+       thick=st.booleans(), eem=st.booleans(), smooth=st.booleans())
+def test_finish_within_and_postprocess_pair_equal_the_python_checker(built, mm, seed, F, m, n_holes, thick, eem, smooth):
+    from multimoda_rs_amd import api
+    rng = np.random.default_rng(seed)
+    mp = pytest.MonkeyPatch()
+    try:
+        pair = []
+        for _ in range(2):
+            holes = sorted(int(h) for h in rng.choice(np.arange(1, max(F - 1, 2)), size=min(n_holes, max(F - 2, 0)), replace=False))
+            g = _pullback(mm, rng, F, m, holes, thick, eem)
+            ref_idx = int(np.nonzero(g.has_ref)[0][0]) if g.has_ref.any() else 0
+            nat, py = g.copy(), g.copy()
+            a_n = api._finish_within(nat, ref_idx, smooth)
+            mp.setenv("MM_PY_POSTPROC", "1")
+            a_p = api._finish_within(py, ref_idx, smooth)
+            mp.delenv("MM_PY_POSTPROC")
+            assert a_n == a_p
+            assert_same(nat, py, "finish_within")
+            pair.append((nat, a_n))
+        (ga, an_a), (gb, an_b) = pair
+        gb = gb.copy()
+        gb.lumen[:, 2] += float(rng.uniform(-0.4, 0.4)); gb.centroids[:, 2] = gb.lumen.reshape(gb.n_frames, -1, 3)[:, 0, 2]
+        anomalous = bool(an_a or an_b)
+        pr = api.GeometryPair(ga, gb, "p")
+        out_n = api._maybe_postprocess(pr, anomalous, True)
+        mp.setenv("MM_PY_POSTPROC", "1")
+        out_p = api._maybe_postprocess(api.GeometryPair(ga, gb, "p"), anomalous, True)
+        mp.delenv("MM_PY_POSTPROC")
+        assert_same(out_n.geom_a, out_p.geom_a, "postprocess a")
+        assert_same(out_n.geom_b, out_p.geom_b, "postprocess b")
+    finally:
+        mp.undo()
