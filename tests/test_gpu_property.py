@@ -1,0 +1,93 @@
+"""Randomised parity of the search primitive on the device (hypothesis, derandomised so that the GPU box runs the
+same examples every time): one brute-force rotation search through the C ABI at every precision against the oracle's
+threaded `bruteforce_rotation` (winner angle) and `cost_within` (its f64 cost), over shape families that stress the
+tie rules -- circles (every candidate ties), two-fold symmetric shapes (exact ties half a turn apart), duplicated and
+collinear points, single points -- and set sizes around the kernels' row-block / LDS-tile boundaries."""
+import math
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 15, 16, 17, 33, 63, 64, 65, 144, 160, 208, 224, 225, 287, 288, 289, 320, 352, 500, 520, 521, 528]
+
+
+def shape(rng, kind, n):
+    t = np.sort(rng.uniform(0, 2 * math.pi, n)) if kind != "regular" else np.arange(n) * (2 * math.pi / max(n, 1))
+    if kind == "blob":
+        r = 2.5 * (1 + 0.15 * np.cos(2 * t + rng.uniform(0, 6)) + 0.07 * np.sin(3 * t)) + rng.normal(0, 0.05, n)
+        return np.stack([4.5 + r * np.cos(t), 4.5 + 0.8 * r * np.sin(t)], 1)
+    if kind in ("circle", "regular"):
+        return np.stack([4.5 + 2.0 * np.cos(t), 4.5 + 2.0 * np.sin(t)], 1)
+    if kind == "ellipse2":                       # symmetric under a half turn: exact ties pi apart
+        h = np.arange((n + 1) // 2) * (2 * math.pi / max(n, 1))
+        p = np.stack([3.0 * np.cos(h), 1.2 * np.sin(h)], 1)
+        return (np.concatenate([p, -p])[:n]) + 4.5
+    if kind == "dups":                           # few distinct points, many repeats
+        base = rng.normal(4.5, 1.0, size=(max(1, min(5, n)), 2))
+        return base[rng.integers(0, base.shape[0], n)]
+    if kind == "line":
+        s = rng.uniform(-2, 2, n)
+        return np.stack([4.5 + s, 4.5 + 0.5 * s], 1)
+    raise AssertionError(kind)
+
+
+@settings(max_examples=150 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), na=st.sampled_from(SIZES), nb=st.sampled_from(SIZES),
+       kind_a=st.sampled_from(["blob", "circle", "regular", "ellipse2", "dups", "line"]),
+       same=st.booleans(), step=st.sampled_from([0.5, 1.0, 2.5, 7.0]), rng_deg=st.sampled_from([3.0, 45.0, 90.0, 180.0]),
+       twist=st.sampled_from([0.0, 7.3, 90.0, 180.0, -33.0]))
+def test_one_search_all_precisions_match_the_oracle(engine, oracle, mm, seed, na, nb, kind_a, same, step, rng_deg, twist):
+    rng = np.random.default_rng(seed)
+    ref = shape(rng, kind_a, na)
+    c = ref.mean(axis=0)
+    if same and na == nb:                         # the target is the reference turned by `twist` (exactly at 0 / 180)
+        th = math.radians(twist)
+        rot = np.array([[math.cos(th), math.sin(th)], [-math.sin(th), math.cos(th)]])
+        tgt = ref.copy() if twist == 0.0 else (2 * c - ref if twist == 180.0 else (ref - c) @ rot + c)
+    else:
+        tgt = shape(rng, str(rng.choice(["blob", "circle", "dups"])), nb)
+    centre = (float(c[0]), float(c[1]))
+    angles, degenerate, _ = mm.search_angles(step, rng_deg)
+    assert not degenerate
+    o_angle = oracle.bruteforce_rotation(ref, tgt, step, rng_deg, centre[0], centre[1], n_threads=8)
+    o_cost = oracle.cost_within(ref, tgt, o_angle, centre[0], centre[1])
+    # every candidate in exact f64: the winner is the FIRST index of minimal cost (process_utils.rs:72)
+    bi64, ba, bc, costs = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True, precision=mm.MM_PRECISION_F64,
+                                               return_costs=True)
+    assert bi64 == int(np.argmin(costs)) and ba == o_angle and bc == o_cost == costs[bi64], (bi64, ba, o_angle, bc, o_cost)
+    for prec in (mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+        bi, ba, bc = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True, precision=prec)
+        assert bi == bi64 and ba == o_angle and bc == o_cost, (prec, bi, bi64, ba, o_angle, bc, o_cost)
+
+
+@settings(max_examples=40 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), n_frames=st.integers(2, 9), n_points=st.sampled_from([6, 20, 64, 120, 200, 501]),
+       ss=st.sampled_from([5, 64, 200, 500, 501]), bruteforce=st.booleans(),
+       step=st.sampled_from([0.005, 0.05, 0.5, 1.0, 3.0]), rng_deg=st.sampled_from([6.0, 20.0, 45.0, 90.0, 180.0]),
+       prec=st.sampled_from([0, 1, 2, 3]), mode=st.sampled_from([0, 1]), sigma=st.sampled_from([0.5, 3.0, 25.0]),
+       circular=st.booleans())
+def test_chain_matches_the_oracle_chain(engine, oracle, mm, seed, n_frames, n_points, ss, bruteforce, step, rng_deg, prec, mode,
+                                        sigma, circular):
+    """align_frames_in_geometry lines 24-134: logs and every coordinate of the faithful chain (mode 0) and of the
+    decoupled plan (mode 1) equal the oracle's sequential chain, over random pullback sizes, sample sizes, grids,
+    ladders, precisions, torsion, and near-circular frames (flat cost curves: many near-ties)."""
+    from helpers import geoms_equal, to_oracle
+    if bruteforce and step < 0.5:
+        step = 0.5                                    # keep a brute-force grid of at most 721 candidates
+    g = mm.synthetic_pullback(n_frames, n_points, pullback_id=seed % 4, seed=seed % 1000, torsion_sigma_deg=sigma)
+    if circular:
+        c = g.centroids[np.repeat(np.arange(g.n_frames), np.diff(g.lumen_off)), :2]
+        d = g.lumen[:, :2] - c
+        r = np.hypot(d[:, 0], d[:, 1])[:, None]
+        g.lumen[:, :2] = c + d * (0.15 + 0.85 * (2.0 / r))
+    og = to_oracle(oracle, g)
+    logs, _ = mm.align_within(engine, [g], step, rng_deg, bruteforce, ss, precision=prec, mode=mode)
+    ol = oracle.align_within_chain(og, step, rng_deg, bruteforce, ss, n_threads=8)
+    assert logs[0] == ol
+    assert geoms_equal(g, og)
