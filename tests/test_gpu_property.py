@@ -91,3 +91,37 @@ def test_chain_matches_the_oracle_chain(engine, oracle, mm, seed, n_frames, n_po
     ol = oracle.align_within_chain(og, step, rng_deg, bruteforce, ss, n_threads=8)
     assert logs[0] == ol
     assert geoms_equal(g, og)
+
+
+@settings(max_examples=30 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), world=st.sampled_from([2, 3, 5, 8]), exchange=st.sampled_from(["gather", "device"]),
+       n_frames=st.integers(2, 7), n_points=st.sampled_from([20, 64, 200, 501]), ss=st.sampled_from([16, 200, 501]),
+       bruteforce=st.booleans(), step=st.sampled_from([0.05, 0.5, 1.0, 9.0, 45.0]),
+       rng_deg=st.sampled_from([20.0, 90.0, 180.0]), prec=st.sampled_from([2, 3]), circular=st.booleans(),
+       always_bound=st.booleans())
+def test_sharded_plan_equals_the_oracle_chain(engine, oracle, mm, seed, world, exchange, n_frames, n_points, ss, bruteforce,
+                                              step, rng_deg, prec, circular, always_bound):
+    """The candidate axis split over `world` plans (what `world` ranks run), either exchange: every rank ends with
+    the oracle chain's logs and coordinates -- random worlds (also more ranks than candidates), grids, ladders,
+    near-circular frames whose near-ties straddle shard borders."""
+    from helpers import geoms_equal, to_oracle
+    from test_gpu_sharded import drive_sharded
+    if bruteforce and step < 0.5:
+        step = 0.5
+    g = mm.synthetic_pullback(n_frames, n_points, pullback_id=seed % 4, seed=seed % 1000, torsion_sigma_deg=3.0)
+    if circular:
+        c = g.centroids[np.repeat(np.arange(g.n_frames), np.diff(g.lumen_off)), :2]
+        d = g.lumen[:, :2] - c
+        r = np.hypot(d[:, 0], d[:, 1])[:, None]
+        g.lumen[:, :2] = c + d * (0.15 + 0.85 * (2.0 / r))
+    og = to_oracle(oracle, g)
+    ol = oracle.align_within_chain(og, step, rng_deg, bruteforce, ss, n_threads=8)
+    if always_bound:
+        engine.set_bound_min_candidates(0)
+    try:
+        for geoms, logs, _evals, _unres in drive_sharded(mm, engine, [g], world, step, rng_deg, bruteforce, ss, prec, exchange):
+            assert logs[0] == ol
+            assert geoms_equal(geoms[0], og)
+    finally:
+        engine.set_bound_min_candidates(16384)
