@@ -77,14 +77,17 @@ def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     return logs, rot, evals + e2, unresolved
 
 
-def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None):
+def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None, stager=False):
     """Run steps `ks`: search(k) then finish(k), and -- if `stage` is given -- stage(k + lookahead) after
     finish(k) (the caller has staged the first `lookahead` steps of `ks` itself: priming), so a call over K steps
     does K stagings, K searches and K finishes.
     pipelined: steps are independent cases, so the search of step k+1 (the GPU-heavy half, and the only half with
-    collectives) overlaps the chain walk and between alignment of step k and the staging of step k+2 on a second
-    host thread; step k lives on engine k % 2, so step k+2 is staged only after step k is finished, and searched
-    only after it is staged.  Every step's work completes inside the call.
+    collectives) overlaps the chain walk and between alignment of step k and the staging of a later step on other
+    host threads.  Step k lives on engine k % lookahead: step k + lookahead is staged only after step k is finished
+    (it takes over that engine), and searched only after it is staged.  Every step's work completes inside the call.
+    stager (pipelined, lookahead >= 3): the stagings run on a third host thread, so stage(k + lookahead) overlaps
+    finish(k + 1) -- with three engines the step being searched, the one being finished and the one being staged
+    never share an engine.  Without it the finishing thread stages too (two engines suffice).
     begin (optional, pipelined only): the search split in two -- begin(k, prev) enqueues step k's launch behind step
     prev's long kernel and returns, search(k) then only collects -- so that step k+1 is already queued on the
     device when step k's launch ends: the device does not idle while the host fetches, commits and launches."""
@@ -99,40 +102,66 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
         return out
     import queue
     import threading
-    q, out, err = queue.Queue(), {}, []
-    done = {k: threading.Event() for k in ks}            # finished (and its successor on the same engine staged)
+    L = lookahead
+    q, sq, out, err = queue.Queue(), queue.Queue(), {}, []
+    # ready[j]: step j may be started -- the step it takes its engine over from (j - L) is finished and, if this
+    # call stages it, j is staged
+    ready = {k + L: threading.Event() for k in ks}
 
-    def worker():
+    def guarded(fn):
+        def run():
+            try:
+                fn()
+            except BaseException as ex:   # surfaced on the main thread
+                err.append(ex)
+                for e in ready.values():
+                    e.set()
+        return run
+
+    def finisher():
         while True:
             k = q.get()
             if k is None:
                 return
-            try:
-                out[k] = finish(k)
+            out[k] = finish(k)
+            if stage is not None and stager:
+                sq.put(k + L)
+            else:
                 if stage is not None:
-                    stage(k + lookahead)
-            except BaseException as ex:   # surfaced on the main thread
-                err.append(ex)
-                return
-            finally:
-                done[k].set()
+                    stage(k + L)
+                ready[k + L].set()
 
-    th = threading.Thread(target=worker, name="bench-finish")
-    th.start()
+    def stage_worker():
+        while True:
+            j = sq.get()
+            if j is None:
+                return
+            stage(j)
+            ready[j].set()
+
+    threads = [threading.Thread(target=guarded(finisher), name="bench-finish")]
+    if stage is not None and stager:
+        threads.append(threading.Thread(target=guarded(stage_worker), name="bench-stage"))
+    for th in threads:
+        th.start()
+
+    def wait_ready(j):
+        if j in ready and (j - L) in out_keys:
+            ready[j].wait()
+
+    out_keys = set(ks)
     try:
         if begin is not None and ks:
             begin(ks[0], None)
         for i, k in enumerate(ks):
             if begin is None:
-                if i >= 2:
-                    done[ks[i - 2]].wait()    # step k shares its engine with step k-2: that one must be finished
+                wait_ready(k)                     # step k takes its engine over from step k - L (finished, k staged)
                 if err:
                     break
                 search(k)
             else:
                 if i + 1 < len(ks):
-                    if i >= 1:
-                        done[ks[i - 1]].wait()    # step k+1 shares its engine with step k-1 (finished, and k+1 staged)
+                    wait_ready(ks[i + 1])
                     if err:
                         break
                     begin(ks[i + 1], k)           # queued on the device behind step k's long kernel
@@ -142,7 +171,10 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
             q.put(k)
     finally:
         q.put(None)
-        th.join()
+        threads[0].join()
+        sq.put(None)
+        for th in threads[1:]:
+            th.join()
     if err:
         raise err[0]
     return [out[k] for k in ks]
@@ -220,7 +252,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md, Peak FP64 (vector)
 class Runner:
     """The three pieces of a step for one precision: stage(k) (raw pullbacks -> HBM, search sets built on the
     device, level 0 staged), search(k) (all levels: local search -> exchange -> commit) and finish(k) (chain walk,
-    AB|CD and AC|BD between alignments).  Step k lives on engine k % 2 and works on its own copy of the case."""
+    AB|CD and AC|BD between alignments).  Step k lives on engine k % len(engs) and works on its own copy of the case."""
 
     def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases):
         self.mm, self.engs, self.cfg, self.prec, self.mode, self.rank, self.world, self.ext = mm, engs, cfg, prec, mode, rank, world, ext
@@ -241,7 +273,7 @@ class Runner:
             return
         mm, cfg = self.mm, self.cfg
         t0 = time.perf_counter()
-        self.plans[k] = mm.WithinPlan(self.engs[k % 2], self.cases[k], cfg["step_deg"], cfg["range_deg"], True,
+        self.plans[k] = mm.WithinPlan(self.engs[k % len(self.engs)], self.cases[k], cfg["step_deg"], cfg["range_deg"], True,
                                       cfg["sample_size"], precision=self.prec,
                                       shard=(self.rank, self.world) if self.world > 1 else None)
         self.stage_s += time.perf_counter() - t0
@@ -250,7 +282,7 @@ class Runner:
     def begin(self, k, prev):
         """world == 1: enqueue step k's search behind step prev's long kernel (Engine.wait_search) and return."""
         if self.plans[k] is not None and self.ext is None:
-            self.plans[k].search_begin(after=None if prev is None else self.engs[prev % 2])
+            self.plans[k].search_begin(after=None if prev is None else self.engs[prev % len(self.engs)])
 
     def search(self, k):
         if self.plans[k] is not None and self.ext is None:
@@ -268,7 +300,7 @@ class Runner:
             out = full_alignment(mm, self.engs[0], self.cases[k], cfg, None, self.prec)
         else:
             logs, ev, unres = self.plans[k].walk()
-            rot, e2 = between_stage(mm, self.engs[k % 2], self.cases[k], cfg, self.prec)
+            rot, e2 = between_stage(mm, self.engs[k % len(self.engs)], self.cases[k], cfg, self.prec)
             out = (logs, rot, ev + e2, unres)
         if self.plans[k] is not None:
             self.plans[k].close()                        # HBM of the step is released; at most three plans are alive
@@ -346,12 +378,16 @@ def main():
              "f64": mm.MM_PRECISION_F64}
     PREC = PRECS[args.precision]
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
-    # two engines (main stream, high-priority side stream, staging buffers each): step k lives on engine k % 2,
-    # so the search of step k+1 never shares one with the finish of step k or the staging of step k+2
-    engs = [mm.Engine(local_rank), mm.Engine(local_rank)]
+    # three engines (main stream, side stream, staging buffers each): step k lives on engine k % 3, so the search of
+    # step k+1, the finish of step k and the staging of step k+3 (which takes over step k's engine once that is
+    # finished) never share one, and each of the three has a host thread of its own
+    LOOK = int(os.environ.get("MM_BENCH_ENGINES", "3"))
+    if LOOK < 2:
+        raise SystemExit("MM_BENCH_ENGINES must be >= 2")
+    engs = [mm.Engine(local_rank) for _ in range(LOOK)]
     ext = cfg.get("shift")
     pipelined = mode == 1 and ext is None and not os.environ.get("MM_BENCH_SEQUENTIAL")
-    LOOK = 2
+    STAGER = LOOK >= 3
 
     # N > 1: the candidate axis is sharded -- rank r scores candidates [n*r/N, n*(r+1)/N) of every frame pair;
     # per-shard bests are all-reduced over RCCL on the device (multimoda_rs_amd.distributed) and every rank then
@@ -396,7 +432,7 @@ def main():
         for k in range(LOOK):
             r.stage(k)                                   # priming (setup, untimed)
         begin = r.begin if (pipe and world == 1 and mode == 1 and ext is None and not os.environ.get("MM_BENCH_NO_LOOKAHEAD")) else None
-        run_steps(range(warmup), r.search, r.finish, pipe, r.stage, LOOK, begin)
+        run_steps(range(warmup), r.search, r.finish, pipe, r.stage, LOOK, begin, STAGER)
         barrier()
         for e in engs:
             e.profile(True)
@@ -405,7 +441,7 @@ def main():
         gc.collect()
         gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
         t0 = time.perf_counter()
-        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, r.stage, LOOK, begin)
+        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, r.stage, LOOK, begin, STAGER)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -515,10 +551,13 @@ def main():
                        "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU",
                        "exchange": (os.environ.get("MM_EXCHANGE", "device") + (" (2 all-reduces per level on device records)"
                                     if os.environ.get("MM_EXCHANGE", "device") == "device" else "")) if world > 1 else None,
-                       "step_pipeline": ("3 pieces per step over consecutive (independent) cases: search of step k+1 || chain "
-                                         "walk + between alignment of step k, then staging of step k+2 (second host thread; "
-                                         "engine k % 2; staging and the small kernels on a high-priority stream); K stagings, K "
-                                         "searches, K finishes inside the timed region, the pipeline primed before it"
+                       "step_pipeline": ((f"3 pieces per step over consecutive (independent) cases, one host thread and one engine "
+                                          f"each: search of step k+1 || chain walk + between alignment of step k || staging of step "
+                                          f"k+3 (engine k % {LOOK})" if STAGER else
+                                          "3 pieces per step over consecutive (independent) cases: search of step k+1 || chain "
+                                          "walk + between alignment of step k, then staging of step k+2 (second host thread; "
+                                          "engine k % 2)") +
+                                         "; K stagings, K searches, K finishes inside the timed region, the pipeline primed before it"
                                          + ("; step k+1's launch is queued on the device behind step k's long kernel "
                                             "(mm_engine_wait_search), so the device does not idle across the hand-over" if world == 1 else "")
                                          ) if pipelined else "sequential"},

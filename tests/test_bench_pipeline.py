@@ -109,3 +109,58 @@ def test_split_search_queues_the_next_step_before_collecting_this_one(run_steps)
         if k + 2 < 10:
             assert pos[("f", k)] < pos[("b", k + 2)]                 # steps k and k+2 share an engine
             assert pos[("st", k + 2)] < pos[("b", k + 2)]            # and k+2 is staged before it is begun
+
+
+@pytest.mark.parametrize("with_begin", [False, True])
+def test_three_engines_with_a_staging_thread(run_steps, with_begin):
+    """lookahead 3 + stager: step k lives on engine k % 3, stage(k+3) runs on its own thread after finish(k) and may
+    overlap finish(k+1); a step is begun / searched only after it is staged; everything completes inside the call."""
+    log, lock = [], threading.Lock()
+    in_finish = threading.Event()
+    overlapped = []
+
+    def add(*e):
+        with lock:
+            log.append(e)
+
+    def begin(k, prev):
+        add("b", k)
+
+    def search(k):
+        time.sleep(0.002)
+        add("s", k)
+
+    def finish(k):
+        in_finish.set()
+        time.sleep(0.004)
+        add("f", k)
+        in_finish.clear()
+        return -k
+
+    def stage(k):
+        overlapped.append(in_finish.is_set())
+        time.sleep(0.003)
+        add("st", k)
+
+    ks = range(5, 14)
+    out = run_steps(ks, search, finish, True, stage, 3, begin if with_begin else None, stager=True)
+    assert out == [-k for k in ks]
+    pos = {e[:2]: i for i, e in enumerate(log)}
+    assert sorted(e[1] for e in log if e[0] == "st") == [k + 3 for k in ks]          # K stagings, all inside the call
+    for k in ks:
+        assert pos[("s", k)] < pos[("f", k)] < pos[("st", k + 3)]
+        if k + 3 in ks:
+            first = pos[("b", k + 3)] if with_begin else pos[("s", k + 3)]
+            assert pos[("st", k + 3)] < first                                        # staged before it is started
+        if k + 1 in ks:
+            assert pos[("f", k)] < pos[("f", k + 1)] and pos[("s", k)] < pos[("s", k + 1)]
+    assert any(overlapped)                                                           # staging beside a finish
+
+
+def test_an_error_in_the_staging_thread_reaches_the_caller(run_steps):
+    def stage(k):
+        if k == 6:
+            raise KeyError("stage")
+
+    with pytest.raises(KeyError):
+        run_steps(range(8), lambda k: time.sleep(0.001), lambda k: k, True, stage, 3, None, stager=True)
