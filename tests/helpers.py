@@ -32,16 +32,18 @@ def to_oracle(orc, g):
 
 
 def geoms_equal(g, og) -> bool:
-    """Bit-for-bit equality of everything the chain mutates."""
-    ok = np.array_equal(g.lumen, og.lumen) and np.array_equal(g.centroids, og.centroids)
+    """Bit-for-bit equality of everything the chain mutates.  NaN coordinates (a degenerate wall: 0/0 in the
+    reference's own arithmetic, wall.rs:151-168) must sit at the same positions on both sides."""
+    eq = lambda a, b: np.array_equal(a, b, equal_nan=True)
+    ok = eq(g.lumen, og.lumen) and eq(g.centroids, og.centroids)
     if g.cath is not None:
-        ok = ok and np.array_equal(g.cath, og.cath)
+        ok = ok and eq(g.cath, og.cath)
     if g.extra is not None:
-        ok = ok and np.array_equal(g.extra, og.extra)
+        ok = ok and eq(g.extra, og.extra)
     if g.ref is not None:
-        ok = ok and np.array_equal(g.ref, og.ref)
+        ok = ok and eq(g.ref, og.ref)
     if getattr(g, "lumen_centroids", None) is not None and og.lumen_centroids is not None:
-        ok = ok and np.array_equal(g.lumen_centroids, og.lumen_centroids)
+        ok = ok and eq(g.lumen_centroids, og.lumen_centroids)
     return bool(ok)
 
 

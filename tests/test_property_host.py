@@ -142,3 +142,54 @@ def test_finish_within_and_postprocess_pair_equal_the_python_checker(built, mm, 
         assert_same(out_n.geom_b, out_p.geom_b, "postprocess b")
     finally:
         mp.undo()
+
+
+@settings(max_examples=25 * SCALE, **SET)
+@given(seed=st.integers(0, 2**31 - 1), F=st.integers(2, 9), m=st.sampled_from([6, 12, 33, 64]), thick=st.booleans(),
+       eem=st.booleans(), angle=st.sampled_from([0.0, 17.0, -52.0, 180.0, 271.5]), walls=st.booleans(),
+       pair=st.booleans(), short_cl=st.booleans())
+def test_placement_with_walls_equals_the_oracle(built, mm, oracle, seed, F, m, thick, eem, angle, walls, pair, short_cl):
+    """align_manual (align.rs:126-166) = preprocess_centerline + rotate_geometry + apply_transformations
+    [+ align_walls] on generated pullbacks (measured thicknesses -> aortic flags on lumen and wall, EEM -> offset
+    walls), single geometries and pairs, centerlines shorter than the pullback (trailing frames keep their place):
+    coordinates, frame / contour centroids and the per-point flags equal oracle/mm_oracle_cl.c bit for bit."""
+    from oracle import oracle_cl as ocl
+    from helpers import geoms_equal, to_oracle, to_oracle_cl
+    from multimoda_rs_amd import native_frames as NF
+    ocl.lib()
+    rng = np.random.default_rng(seed)
+
+    def make():
+        g = _pullback(mm, rng, F, m, [], thick, eem)
+        g, _an = NF.finish_within(g, int(np.nonzero(g.has_ref)[0][0]) if g.has_ref.any() else 0, bool(rng.integers(0, 2)))
+        if not walls:                                         # drop the Wall contours again: align_walls has nothing to do
+            cnt = g.meta["extra_counts"]
+            keep = np.concatenate([np.r_[np.ones(int(e), bool), np.zeros(int(w), bool)]
+                                   for e, w in zip(cnt["eem"], cnt["wall"])]) if g.extra is not None else None
+            if keep is not None and keep.any():
+                g.extra = np.ascontiguousarray(g.extra[keep])
+                g.extra_off = np.concatenate([[0], np.cumsum(cnt["eem"])]).astype(np.int64)
+            else:
+                g.extra, g.extra_off = None, None
+            cnt["wall"] = np.zeros(g.n_frames, dtype=np.int64)
+            g.meta.pop("wall_aortic", None)
+        return g
+    ga = make()
+    target = mm.GeometryPair(ga, make(), "p") if pair else ga
+    n_cl = (ga.n_frames + 6) if not short_cl else max(ga.n_frames - 2, 3)
+    s = np.arange(0.0, 0.5 * n_cl, 0.25)
+    path = np.stack([12.0 + 6.0 * np.sin(s / 9.0), -200.0 + 5.0 * np.cos(s / 11.0), 1750.0 - 0.9 * s], axis=1)
+    cl = mm.Centerline.from_contour_points(path)
+    ref = path[int(rng.integers(0, 3))] + rng.normal(0, 0.05, 3)
+    out, sp, rot = mm.align_manual(cl, target, angle, ref, align_wall_anomalous=True)
+    gs = [target.geom_a, target.geom_b] if pair else [target]
+    ogs = [to_oracle(oracle, g) for g in gs]
+    osp, orot = ocl.align_manual(to_oracle_cl(ocl, cl), ogs, angle, ref, align_wall_anomalous=True)
+    assert sp == osp and rot == orot * (180.0 / math.pi)
+    outs = [out.geom_a, out.geom_b] if pair else [out]
+    for o, og in zip(outs, ogs):
+        assert geoms_equal(o, og)
+        for key in ("lumen_aortic", "wall_aortic"):
+            have = getattr(og, key)
+            if have is not None:
+                assert np.array_equal(np.asarray(o.meta[key], dtype=np.uint8), have), key
