@@ -432,14 +432,16 @@ def main():
         for k in range(LOOK):
             r.stage(k)                                   # priming (setup, untimed)
         begin = r.begin if (pipe and world == 1 and mode == 1 and ext is None and not os.environ.get("MM_BENCH_NO_LOOKAHEAD")) else None
+        import gc
+        gc.collect()
+        gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
+        # (collected BEFORE the warm-up: a collection between warm-up and timed region idles the device for ~40 ms,
+        # and the first big launch after such a pause runs 34.9 instead of 31.3 ms -- the clocks have dropped)
         run_steps(range(warmup), r.search, r.finish, pipe, r.stage, LOOK, begin, STAGER)
         barrier()
         for e in engs:
             e.profile(True)
         r.stage_s, r.staged = 0.0, 0
-        import gc
-        gc.collect()
-        gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
         t0 = time.perf_counter()
         results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, r.stage, LOOK, begin, STAGER)
         barrier()
