@@ -12,6 +12,8 @@
 #include "../../include/mm_build.h"
 #include "mm_engine.h"
 #include "mm_pool.h"
+#include "mm_sort.h"
+#include "mm_trace.h"
 
 namespace mm {
 namespace {
@@ -72,9 +74,7 @@ void sort_contour(BContour& c, std::vector<double>& key, std::vector<int32_t>& p
     const double cx = sx / (double)n, cy = sy / (double)n;
     key.resize((size_t)n); perm.resize((size_t)n); tmp.resize((size_t)n * 3);
     for (int64_t i = 0; i < n; ++i) key[(size_t)i] = std::atan2(c.xyz[3 * i + 1] - cy, c.xyz[3 * i] - cx);
-    std::iota(perm.begin(), perm.end(), 0);
-    const double* k = key.data();
-    std::stable_sort(perm.begin(), perm.end(), [k](int32_t a, int32_t b) { return k[a] < k[b]; });
+    stable_argsort(key.data(), n, perm.data());
     int64_t start = 0;
     for (int64_t i = 1; i < n; ++i)
         if (!(c.xyz[3 * perm[(size_t)i] + 1] < c.xyz[3 * perm[(size_t)start] + 1])) start = i;
@@ -106,9 +106,29 @@ void set_frame_z(BFrame& f, double z)   // every z of the frame: points, extras,
 // HashMap<u32, Vec<ContourPoint>> of build_contour_with_mapping (contour.rs:164-167): rows of one frame in input order
 void group_rows(const double* rows4, int64_t n, const uint8_t* flags, std::map<uint32_t, BContour>& out)
 {
+    // rows of a frame are usually adjacent: one map lookup per run of equal frame indices (map nodes do not move);
+    // a counting pass first, so that every contour is allocated once
+    BContour* cur = nullptr;
+    uint32_t last = 0;
+    {
+        std::map<uint32_t, int64_t> count;
+        int64_t* cc = nullptr;
+        for (int64_t i = 0; i < n; ++i) {
+            const uint32_t f = (uint32_t)rows4[4 * i];
+            if (!cc || f != last) { cc = &count[f]; last = f; }
+            ++*cc;
+        }
+        for (const auto& kv : count) {
+            BContour& c = out[kv.first];
+            c.xyz.reserve((size_t)kv.second * 3);
+            if (flags) c.aortic.reserve((size_t)kv.second);
+        }
+    }
     for (int64_t i = 0; i < n; ++i) {
-        BContour& c = out[(uint32_t)rows4[4 * i]];
-        c.xyz.push_back(rows4[4 * i + 1]); c.xyz.push_back(rows4[4 * i + 2]); c.xyz.push_back(rows4[4 * i + 3]);
+        const uint32_t f = (uint32_t)rows4[4 * i];
+        if (!cur || f != last) { cur = &out[f]; last = f; }
+        BContour& c = *cur;
+        c.xyz.insert(c.xyz.end(), rows4 + 4 * i + 1, rows4 + 4 * i + 4);
         if (flags) c.aortic.push_back(flags[i]);
     }
 }
@@ -194,6 +214,7 @@ int build_impl(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aorti
     const double* ext_rows[3] = {eem4, calc4, side4};
     const int64_t ext_n[3] = {eem4 ? n_eem : -1, calc4 ? n_calc : -1, side4 ? n_side : -1};   // -1: None
 
+    TraceTimer tt_map("build: id mapping");
     // build.rs:36-71: shared original-frame -> sequential-id mapping over ALL contour kinds and the reference point
     std::vector<uint32_t> originals;
     originals.reserve((size_t)n_lumen / 64 + 16);
@@ -217,6 +238,8 @@ int build_impl(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aorti
     std::map<uint32_t, const mm_record*> meas;
     if (records) for (int64_t i = 0; i < n_records; ++i) meas[records[i].frame] = &records[i];
 
+    tt_map.stop();
+    TraceTimer tt_group("build: group rows + frames");
     // build.rs:74-129: one frame per lumen contour, in ascending original frame (= ascending id)
     Built* B = new Built();
     std::map<uint32_t, BContour> groups;
@@ -246,6 +269,8 @@ int build_impl(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aorti
             f.has_ext[k] = true; f.ext[k] = std::move(kv.second);
         }
     }
+    tt_group.stop();
+    TraceTimer tt_cath("build: catheter + reorder");
     if (n_points > 0) {                                               // build.rs:152-174, frame.rs:163-204
         for (BFrame& f : B->frames) {
             const double z = f.lumen.xyz[2];                          // the first encountered z of the frame's points
@@ -287,6 +312,8 @@ int build_impl(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aorti
         }
     }
 
+    tt_cath.stop();
+    TraceTimer tt_sort("build: sort contours");
     {                                                                 // build.rs:188-190 sort_frame_points, frames in parallel
         const int nf = (int)B->frames.size();
         parallel_for((nf + 15) / 16, [&](int blk) {
@@ -300,6 +327,8 @@ int build_impl(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aorti
         });
     }
 
+    tt_sort.stop();
+    TraceTimer tt_tail("build: proximal end + integrity");
     const size_t n = B->frames.size();                                // build.rs:192 -> geometry.rs:325-381
     if (n) {
         size_t prox = n == 1 ? B->frames[0].id

@@ -18,6 +18,7 @@
 #include "../../include/mm_centerline.h"
 #include "mm_engine.h"
 #include "mm_pool.h"
+#include "mm_sort.h"
 #include "mm_trace.h"
 
 namespace mm {
@@ -146,9 +147,7 @@ void sort_contour(double* xyz, int64_t n, SortScratch& sc, uint8_t* flags = null
     const double cx = sx / (double)n, cy = sy / (double)n;
     sc.key.resize((size_t)n); sc.perm.resize((size_t)n); sc.tmp.resize((size_t)n * 3);
     for (int64_t i = 0; i < n; ++i) sc.key[i] = std::atan2(xyz[3 * i + 1] - cy, xyz[3 * i] - cx);
-    std::iota(sc.perm.begin(), sc.perm.end(), 0);
-    const double* key = sc.key.data();
-    std::stable_sort(sc.perm.begin(), sc.perm.end(), [key](int32_t a, int32_t b) { return key[a] < key[b]; });
+    stable_argsort(sc.key.data(), n, sc.perm.data());
     // highest y moves to the front; Iterator::max_by keeps the last of equal maxima
     int64_t start = 0;
     for (int64_t i = 1; i < n; ++i)

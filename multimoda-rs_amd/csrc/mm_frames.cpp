@@ -18,6 +18,7 @@
 #include "../../include/mm_build.h"
 #include "mm_engine.h"
 #include "mm_pool.h"
+#include "mm_sort.h"
 
 namespace mm {
 namespace {
@@ -291,9 +292,7 @@ void sort_contour(FContour& c, SortScratch& sc)
     const double cx = sx / (double)n, cy = sy / (double)n;
     sc.key.resize((size_t)n); sc.perm.resize((size_t)n); sc.tmp.resize((size_t)n * 3); sc.tf.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) sc.key[(size_t)i] = std::atan2(c.p[3 * i + 1] - cy, c.p[3 * i] - cx);
-    std::iota(sc.perm.begin(), sc.perm.end(), 0);
-    const double* k = sc.key.data();
-    std::stable_sort(sc.perm.begin(), sc.perm.end(), [k](int32_t a, int32_t b) { return k[a] < k[b]; });
+    stable_argsort(sc.key.data(), n, sc.perm.data());
     int64_t start = 0;
     for (int64_t i = 1; i < n; ++i)
         if (!(c.p[3 * sc.perm[(size_t)i] + 1] < c.p[3 * sc.perm[(size_t)start] + 1])) start = i;

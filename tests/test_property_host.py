@@ -193,3 +193,36 @@ def test_placement_with_walls_equals_the_oracle(built, mm, oracle, seed, F, m, t
             have = getattr(og, key)
             if have is not None:
                 assert np.array_equal(np.asarray(o.meta[key], dtype=np.uint8), have), key
+
+
+@settings(max_examples=150 * SCALE, **SET)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 70), kind=st.sampled_from(["sorted", "rotated", "random", "two_wraps"]),
+       dup_at_wrap=st.booleans(), dups=st.booleans())
+def test_sort_contour_points_fast_paths_equal_the_oracle(built, mm, oracle, seed, n, kind, dup_at_wrap, dups):
+    """Contour::sort_contour_points (contour.rs:368-405): contours that arrive in angular order -- ascending keys,
+    or ascending with one wrap -- skip the sort (csrc/mm_sort.h); ties that straddle the wrap, duplicate points and
+    sequences with two descents must still come out in the stable order of the oracle's full sort."""
+    from oracle import oracle_cl as ocl
+    ocl.lib()
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(-math.pi, math.pi, n))
+    if dups and n >= 4:
+        t[1] = t[2]                                   # equal keys inside a run
+    r = rng.uniform(0.5, 2.0, n) if rng.integers(0, 2) else np.full(n, 1.5)
+    p = np.stack([r * np.cos(t), r * np.sin(t), rng.normal(0, 1, n)], axis=1)
+    # shift so that the xy mean (the sort centre) is the origin the angles were drawn about -- approximately; the
+    # parity below does not depend on it, only how often the fast paths are taken does
+    if kind in ("rotated", "two_wraps") and n >= 2:
+        k = int(rng.integers(1, n))
+        p = np.concatenate([p[k:], p[:k]])
+        if dup_at_wrap:
+            p[-1, :2] = p[0, :2]                      # last and first point coincide: a tie across the wrap
+    if kind == "two_wraps" and n >= 6:
+        i, j = sorted(int(v) for v in rng.choice(n, 2, replace=False))
+        p[[i, j]] = p[[j, i]]
+    if kind == "random":
+        p = p[rng.permutation(n)]
+    p = np.ascontiguousarray(p)
+    q = p.copy()
+    assert mm._native.lib().mm_sort_contour_points(mm._native._ptr(q), n) == 0
+    assert np.array_equal(q, ocl.sort_contour_points(p))
