@@ -207,11 +207,18 @@ int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_
 // -------------------------------------------------------------------------------------
 // f32 screening error bound (DESIGN.md "screen-then-exact"): with u = 2^-24 and rho_r, rho_t
 // the largest distance of a reference / target point from the rotation centre,
-// |H_f32 - H_f64| <= u (3.9 rho_r + 10 rho_t); we use 24 u (rho_r + rho_t).
-static inline double screen_delta(double rho_r, double rho_t)
+// |H_f32 - H_true| <= u (3.9 rho_r + 10 rho_t); we use 24 u (rho_r + rho_t).
+// The screen works on coordinates relative to the rotation centre; the exact re-score is the REFERENCE's
+// arithmetic on the coordinates as given, whose rotation ends with "+ cx" (contour_point.rs:45-48): its result
+// is rounded at the magnitude of the coordinates, |H_f64 - H_true| <= 2^-53 (1.5 |c| + 10 rho_t + 3 rho_r).
+// That term only matters for point sets a billion times smaller than their coordinates (all points of a set
+// equal: every exact cost is 0.0, the screen sees 1e-17 -- found by the randomised search test), but the
+// shortlist has to hold every candidate whose EXACT cost can be minimal, so it is part of the bound:
+// 2^-49 (|cx| + |cy| + rho_r + rho_t), sixteen roundings at the coordinates' magnitude.
+static inline double screen_delta(double rho_r, double rho_t, double cx, double cy)
 {
     const double u = 5.9604644775390625e-08;  // 2^-24
-    return 24.0 * u * (rho_r + rho_t) + 1e-300;
+    return 24.0 * u * (rho_r + rho_t) + std::ldexp(std::fabs(cx) + std::fabs(cy) + rho_r + rho_t, -49) + 1e-300;
 }
 
 int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_t angle_begin, int32_t angle_end,
@@ -260,7 +267,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         d.cx = sp.cx; d.cy = sp.cy;
         d.tol2 = sp.tie_tol;
         d.delta = (precision != MM_PRECISION_F64)
-                      ? screen_delta(set_rho[sp.ref_set], set_rho[sp.tgt_set]) + sp.delta_extra : 0.0;
+                      ? screen_delta(set_rho[sp.ref_set], set_rho[sp.tgt_set], sp.cx, sp.cy) + sp.delta_extra : 0.0;
         {   // expanded-form screening: |d2_f32 - d2| <= 5 u (rho_a + rho_b)^2; we use 8 u (..)^2
             const double rs = set_rho[sp.ref_set] + set_rho[sp.tgt_set];
             d.e2 = expanded ? 8.0 * 5.9604644775390625e-08 * rs * rs : 0.0;

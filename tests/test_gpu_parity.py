@@ -115,6 +115,23 @@ def test_duplicate_candidates_first_index_wins(engine, oracle, mm):
         assert bi == int(np.argmin(ocosts)) == 0 and bc == ocosts[0]
 
 
+def test_point_sets_far_smaller_than_their_coordinates(engine, oracle, mm):
+    """All points of both sets equal (found by tests/test_gpu_property.py): every exact cost is 0.0 -- the reference's
+    rotation ends with `+ cx` and rounds at the coordinates' magnitude -- so the FIRST candidate wins
+    (process_utils.rs:72), while the screen, working relative to the rotation centre, sees 1e-17 for every angle but
+    0.  The screening bound carries the reference's own f64 rounding for exactly this case."""
+    p = np.array([[5.554607710218, 3.975742059671]] * 3)
+    c = p.mean(axis=0)                                        # one ulp off the point in y
+    angles, _, _ = mm.search_angles(0.5, 3.0)
+    ocosts = oracle.costs_over_angles(p, p, angles, float(c[0]), float(c[1]))
+    assert not ocosts.any()
+    for q in (p, p + np.array([[0.0, 0.0], [3e-16, 0.0], [0.0, 5e-16]])):      # and a cloud of a few ulps
+        oc = oracle.costs_over_angles(p, q, angles, float(c[0]), float(c[1]))
+        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+            bi, ba, bc = engine.best_rotation(p, q, angles, (float(c[0]), float(c[1])), skip_zero=True, precision=prec)
+            assert bi == int(np.argmin(oc)) and ba == angles[bi] and bc == oc[bi], prec
+
+
 def test_all_candidates_tie_circle(engine, oracle, mm):
     """A perfectly symmetric target: costs tie to within rounding; the f32 screen must hand
     every near-tie to the exact re-score and still return the reference's first minimum."""

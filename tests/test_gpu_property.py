@@ -2,7 +2,8 @@
 same examples every time): one brute-force rotation search through the C ABI at every precision against the oracle's
 threaded `bruteforce_rotation` (winner angle) and `cost_within` (its f64 cost), over shape families that stress the
 tie rules -- circles (every candidate ties), two-fold symmetric shapes (exact ties half a turn apart), duplicated and
-collinear points, single points -- and set sizes around the kernels' row-block / LDS-tile boundaries."""
+collinear points, single points, point sets far smaller than their coordinates (exact costs round to ties the
+screen does not see) -- and set sizes around the kernels' row-block / LDS-tile boundaries."""
 import math
 import os
 
@@ -32,13 +33,17 @@ def shape(rng, kind, n):
     if kind == "line":
         s = rng.uniform(-2, 2, n)
         return np.stack([4.5 + s, 4.5 + 0.5 * s], 1)
+    if kind == "point":                          # every point the same: all exact costs are 0.0, the first candidate wins
+        return np.tile(rng.normal(4.5, 1.0, size=(1, 2)), (n, 1))
+    if kind == "speck":                          # a cloud of a few ulps / of 1e-9 around a far point
+        return rng.normal(4.5, 1.0, size=(1, 2)) + rng.normal(0, float(rng.choice([4e-16, 1e-12, 1e-9])), size=(n, 2))
     raise AssertionError(kind)
 
 
 @settings(max_examples=150 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(seed=st.integers(0, 2**31 - 1), na=st.sampled_from(SIZES), nb=st.sampled_from(SIZES),
-       kind_a=st.sampled_from(["blob", "circle", "regular", "ellipse2", "dups", "line"]),
+       kind_a=st.sampled_from(["blob", "circle", "regular", "ellipse2", "dups", "line", "point", "speck"]),
        same=st.booleans(), step=st.sampled_from([0.5, 1.0, 2.5, 7.0]), rng_deg=st.sampled_from([3.0, 45.0, 90.0, 180.0]),
        twist=st.sampled_from([0.0, 7.3, 90.0, 180.0, -33.0]))
 def test_one_search_all_precisions_match_the_oracle(engine, oracle, mm, seed, na, nb, kind_a, same, step, rng_deg, twist):
@@ -50,7 +55,8 @@ def test_one_search_all_precisions_match_the_oracle(engine, oracle, mm, seed, na
         rot = np.array([[math.cos(th), math.sin(th)], [-math.sin(th), math.cos(th)]])
         tgt = ref.copy() if twist == 0.0 else (2 * c - ref if twist == 180.0 else (ref - c) @ rot + c)
     else:
-        tgt = shape(rng, str(rng.choice(["blob", "circle", "dups"])), nb)
+        tgt = shape(rng, str(rng.choice(["blob", "circle", "dups"])), nb) if kind_a not in ("point", "speck") else \
+            ref[rng.integers(0, na, nb)] + rng.normal(0, float(rng.choice([0.0, 4e-16, 1e-10])), size=(nb, 2))
     centre = (float(c[0]), float(c[1]))
     angles, degenerate, _ = mm.search_angles(step, rng_deg)
     assert not degenerate
