@@ -131,3 +131,29 @@ def test_sharded_plan_equals_the_oracle_chain(engine, oracle, mm, seed, world, e
             assert geoms_equal(geoms[0], og)
     finally:
         engine.set_bound_min_candidates(16384)
+
+
+@settings(max_examples=40 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), fa=st.integers(1, 24), fb=st.integers(1, 24), n_points=st.sampled_from([6, 40, 120, 501]),
+       ss=st.sampled_from([1, 50, 500, 640]), step=st.sampled_from([0.005, 0.05, 0.5, 1.0, 3.0]),
+       rng_deg=st.sampled_from([6.0, 30.0, 90.0, 180.0]), twist=st.sampled_from([0.0, 15.0, -70.0, 180.0]),
+       prec=st.sampled_from([0, 1, 2, 3]))
+def test_between_alignment_matches_the_oracle(engine, oracle, mm, seed, fa, fb, n_points, ss, step, rng_deg, twist, prec):
+    """align_between_geometries (align_between.rs:11-68): sampling of both pullbacks, the global centroid, the
+    hierarchical search without the angle-0 shortcut, rotation and translation of the target -- best angle and every
+    coordinate of both geometries equal the oracle's, for pullbacks of different lengths and point counts."""
+    from helpers import geoms_equal, to_oracle
+    a = mm.synthetic_pullback(fa, n_points, pullback_id=0, seed=seed % 1000)
+    b = mm.synthetic_pullback(fb, n_points, pullback_id=1, seed=(seed // 7) % 1000)
+    if twist:
+        th = math.radians(twist)
+        c = b.lumen[:, :2].mean(axis=0)
+        d = b.lumen[:, :2] - c
+        b.lumen[:, 0] = c[0] + d[:, 0] * math.cos(th) - d[:, 1] * math.sin(th)
+        b.lumen[:, 1] = c[1] + d[:, 0] * math.sin(th) + d[:, 1] * math.cos(th)
+    oa, ob = to_oracle(oracle, a), to_oracle(oracle, b)
+    best, _ = mm.align_between(engine, [(a, b)], rng_deg, step, ss, precision=prec)
+    obest = oracle.align_between(oa, ob, rng_deg, step, ss, n_threads=8)
+    assert best[0] == obest
+    assert geoms_equal(a, oa) and geoms_equal(b, ob)
