@@ -157,3 +157,65 @@ def test_between_alignment_matches_the_oracle(engine, oracle, mm, seed, fa, fb, 
     obest = oracle.align_between(oa, ob, rng_deg, step, ss, n_threads=8)
     assert best[0] == obest
     assert geoms_equal(a, oa) and geoms_equal(b, ob)
+
+
+@settings(max_examples=20 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10**6), n_frames=st.integers(3, 18), n_points=st.sampled_from([16, 64, 200]),
+       n_ccta=st.sampled_from([60, 900, 6000]), idx_range=st.integers(0, 3), rng_deg=st.sampled_from([0.0, 3.0, 8.0]),
+       step_deg=st.sampled_from([0.5, 1.0, 4.0]), clutter=st.sampled_from([0.0, 0.1]), true_index=st.integers(0, 12),
+       start_shift=st.integers(-3, 3))
+def test_refine_grid_matches_the_oracle(engine, oracle, mm, seed, n_frames, n_points, n_ccta, idx_range, rng_deg, step_deg,
+                                        clutter, true_index, start_shift):
+    """refine_alignment_hausdorff (align_algorithms.rs:339-451): every candidate's cost, the candidate order and the
+    strict-< first minimum equal the oracle's, for random grids (also the one-candidate grid), start indices near
+    the ends of the centerline (skipped candidates) and clouds of any size; the winner-only path agrees."""
+    from oracle import oracle_cl as ocl
+    from helpers import to_oracle, to_oracle_cl
+    ocl.lib()
+    case = mm.synth.synthetic_centerline_case(n_frames=n_frames, n_points=n_points, n_ccta=n_ccta, seed=seed % 997,
+                                              true_rotation_deg=float(seed % 360) - 180.0, true_index=true_index,
+                                              clutter_frac=clutter)
+    g = case["geometry"]
+    aligned, _, _ = mm.align_three_point(case["centerline"], g, case["main_ref_pt"], case["ccw_ref_pt"], case["cw_ref_pt"],
+                                         angle_step_deg=2.0)
+    rcl, _ = mm.preprocess_centerline(case["centerline"], g)
+    idx0 = max(0, rcl.find_reference_cl_point_idx(case["main_ref_pt"]) + start_shift)
+    og, orcl = to_oracle(oracle, aligned), to_oracle_cl(ocl, rcl)
+    a, s = math.radians(rng_deg), math.radians(step_deg)
+    r = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, idx0, 0.0, case["points"], a, s, idx_range)
+    o = ocl.refine_alignment_hausdorff([og], orcl, idx0, 0.0, case["points"], a, s, idx_range)
+    assert np.array_equal(r[3], o[3]) and r[:3] == o[:3]
+    w = mm.centerline.refine_alignment_hausdorff(engine, [aligned], rcl, idx0, 0.0, case["points"], a, s, idx_range,
+                                                 return_costs=False)
+    assert w[:3] == o[:3]
+
+
+@settings(max_examples=40 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 2**31 - 1), na=st.sampled_from([1, 2, 255, 256, 257, 511, 512, 513, 1500, 4096, 4097, 9000]),
+       nb=st.sampled_from([1, 2, 511, 512, 513, 1024, 1025, 4095, 4096, 7000]), shape=st.sampled_from(["cloud", "tube", "line", "dups"]),
+       offset=st.sampled_from([0.0, 0.3, 25.0]))
+def test_nearest_neighbour_minima_match_the_oracle(engine, mm, seed, na, nb, shape, offset):
+    """k_nn3_min (the CCTA diameter search's kernel): per-query squared nearest-neighbour distances in 3-D, bit for
+    bit, around the 512-point chunk / 4096-point slab-order boundaries, for thin tubes (what the pruning is built
+    for), lines, duplicates and clouds that do not overlap at all."""
+    from oracle import oracle_ccta as occ
+    occ.lib()
+    rng = np.random.default_rng(seed)
+
+    def cloud(n):
+        if shape == "cloud":
+            return rng.normal(0, 4, size=(n, 3))
+        if shape == "tube":
+            s = rng.uniform(0, 60, n); t = rng.uniform(0, 2 * math.pi, n)
+            return np.stack([2 * np.cos(t) + 5 * np.sin(s / 9), 2 * np.sin(t), s], 1) + rng.normal(0, 0.02, (n, 3))
+        if shape == "line":
+            s = rng.uniform(-30, 30, n)
+            return np.stack([s, 0.5 * s, -s], 1)
+        base = rng.normal(0, 3, size=(max(1, min(7, n)), 3))
+        return base[rng.integers(0, base.shape[0], n)]
+    origin = np.array([10.0, -190.0, 1700.0])
+    a, b = cloud(na) + origin, cloud(nb) + origin + offset
+    assert np.array_equal(mm.ccta.nn_min_sq(a, b, engine=engine), occ.nn_min_sq(a, b))
+    assert mm.ccta.symmetric_nn_distance(a, b, engine=engine) == occ.symmetric_nn_distance(a, b)
