@@ -936,7 +936,8 @@ int mm_align_combined(mm_engine* h, const mm_clpoint* cl, int64_t ncl, mm_cl_geo
     ag.lumen = a_lumen.data(); ag.centroid = a_centroid.data();
     ag.has_catheter = 0; ag.cath_off = nullptr; ag.cath = nullptr; ag.extra_off = nullptr; ag.extra = nullptr;
     ag.has_ref = nullptr; ag.ref = nullptr;
-    mm_cl_geometry acg{&ag, nullptr, nullptr, 0, nullptr};
+    mm_cl_geometry acg{};                        // no extras, no flags: only lumen and centroids are read
+    acg.g = &ag;
     if (geoms[0]->has_lumen_centroid && geoms[0]->lumen_centroid) {
         a_hlc.assign(geoms[0]->has_lumen_centroid, geoms[0]->has_lumen_centroid + F);
         a_lc.assign(geoms[0]->lumen_centroid, geoms[0]->lumen_centroid + 3 * F);

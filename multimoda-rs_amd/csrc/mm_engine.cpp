@@ -104,7 +104,7 @@ int Engine::sync_all()
     return MM_OK;
 }
 
-int Engine::profile_begin(hipStream_t stream)
+int Engine::profile_begin(hipStream_t st)
 {
     if (!profile) return MM_OK;
     while (events.size() < 2 * (launches + 1)) {
@@ -112,14 +112,14 @@ int Engine::profile_begin(hipStream_t stream)
         MM_HIP(hipEventCreate(&ev));
         events.push_back(ev);
     }
-    MM_HIP(hipEventRecord(events[2 * launches], stream));
+    MM_HIP(hipEventRecord(events[2 * launches], st));
     return MM_OK;
 }
 
-int Engine::profile_end(hipStream_t stream, double pair_evals, int64_t candidates)
+int Engine::profile_end(hipStream_t st, double pair_evals, int64_t candidates)
 {
     if (!profile) return MM_OK;
-    MM_HIP(hipEventRecord(events[2 * launches + 1], stream));
+    MM_HIP(hipEventRecord(events[2 * launches + 1], st));
     ++launches;
     prof_pair_evals += pair_evals;
     prof_candidates += candidates;
