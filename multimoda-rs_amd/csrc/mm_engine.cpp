@@ -579,12 +579,16 @@ static int make_specs(int n_pairs, const int64_t* ref_off, const double* ref_x, 
                       std::vector<SetRef>& sets, std::vector<PairSpec>& pairs)
 {
     if (n_pairs < 0) return set_error(MM_ERR_INVALID, "n_pairs < 0");
+    if (n_pairs > 0 && (!ref_off || !tgt_off || !ang_off || !cx || !cy))
+        return set_error(MM_ERR_INVALID, "batch offsets / rotation centres == NULL");
     sets.clear(); pairs.clear();
     sets.reserve(2 * (size_t)n_pairs); pairs.reserve((size_t)n_pairs);
     for (int p = 0; p < n_pairs; ++p) {
         const int64_t nr = ref_off[p + 1] - ref_off[p], nt = tgt_off[p + 1] - tgt_off[p], na = ang_off[p + 1] - ang_off[p];
         if (nr < 0 || nt < 0 || na < 0 || nr > INT32_MAX || nt > INT32_MAX || na > INT32_MAX)
             return set_error(MM_ERR_INVALID, "bad extent in batch offsets");
+        if ((nr > 0 && (!ref_x || !ref_y)) || (nt > 0 && (!tgt_x || !tgt_y)) || (na > 0 && !angles))
+            return set_error(MM_ERR_INVALID, "point / candidate arrays == NULL for a non-empty pair");
         sets.push_back(SetRef{ref_x + ref_off[p], ref_y + ref_off[p], (int32_t)nr, cx[p], cy[p]});
         sets.push_back(SetRef{tgt_x + tgt_off[p], tgt_y + tgt_off[p], (int32_t)nt, cx[p], cy[p]});
         pairs.push_back(PairSpec{2 * p, 2 * p + 1, cx[p], cy[p], flags ? flags[p] : 0, angles + ang_off[p], (int32_t)na, 0.0, 0.0});
@@ -1057,9 +1061,12 @@ int mm_hausdorff_batch(mm_engine* h, int n_pairs, const int64_t* a_off, const do
     std::vector<SetRef> sets;
     std::vector<std::array<int32_t, 2>> pr;
     sets.reserve(2 * (size_t)n_pairs); pr.reserve((size_t)n_pairs);
+    if (!a_off || !b_off) return set_error(MM_ERR_INVALID, "mm_hausdorff_batch: offsets == NULL");
     for (int p = 0; p < n_pairs; ++p) {
         const int64_t na = a_off[p + 1] - a_off[p], nb = b_off[p + 1] - b_off[p];
         if (na < 0 || nb < 0 || na > INT32_MAX || nb > INT32_MAX) return set_error(MM_ERR_INVALID, "bad set extent");
+        if ((na > 0 && (!ax || !ay)) || (nb > 0 && (!bx || !by)))
+            return set_error(MM_ERR_INVALID, "mm_hausdorff_batch: point arrays == NULL for a non-empty set");
         sets.push_back(SetRef{ax + a_off[p], ay + a_off[p], (int32_t)na, 0.0, 0.0});
         sets.push_back(SetRef{bx + b_off[p], by + b_off[p], (int32_t)nb, 0.0, 0.0});
         pr.push_back({2 * p, 2 * p + 1});
@@ -1114,11 +1121,16 @@ int mm_plan_create_indexed(mm_engine* h, int n_sets, const int64_t* set_off, con
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine/out == NULL");
     *out = nullptr;
     if (n_sets < 0 || n_pairs < 0) return set_error(MM_ERR_INVALID, "negative counts");
+    if ((n_sets > 0 && (!set_off || !set_cx || !set_cy)) || (n_pairs > 0 && (!ref_set || !tgt_set || !ang_off || !cx || !cy)))
+        return set_error(MM_ERR_INVALID, "mm_plan_create_indexed: offsets / centres / pair lists == NULL");
+    if (n_pairs > 0 && !angles && (shared_angles ? ang_off[1] > ang_off[0] : ang_off[n_pairs] > ang_off[0]))
+        return set_error(MM_ERR_INVALID, "mm_plan_create_indexed: candidate list == NULL");
     MM_HIP(hipSetDevice(e->device));
     std::vector<SetRef> sets((size_t)n_sets);
     for (int s = 0; s < n_sets; ++s) {
         const int64_t n = set_off[s + 1] - set_off[s];
         if (n < 0 || n > INT32_MAX) return set_error(MM_ERR_INVALID, "bad set extent");
+        if (n > 0 && (!x || !y)) return set_error(MM_ERR_INVALID, "mm_plan_create_indexed: point arrays == NULL");
         sets[s] = SetRef{x + set_off[s], y + set_off[s], (int32_t)n, set_cx[s], set_cy[s]};
     }
     std::vector<PairSpec> pairs((size_t)n_pairs);
@@ -1127,6 +1139,9 @@ int mm_plan_create_indexed(mm_engine* h, int n_sets, const int64_t* set_off, con
     for (int p = 0; p < n_pairs; ++p) {
         const int64_t a0 = shared_angles ? ang_off[0] : ang_off[p], a1 = shared_angles ? ang_off[1] : ang_off[p + 1];
         if (a1 < a0 || a1 - a0 > INT32_MAX) { delete ph; return set_error(MM_ERR_INVALID, "bad candidate extent"); }
+        if (ref_set[p] < 0 || ref_set[p] >= n_sets || tgt_set[p] < 0 || tgt_set[p] >= n_sets) {
+            delete ph; return set_error(MM_ERR_INVALID, "pair references a set that does not exist");
+        }
         pairs[p] = PairSpec{ref_set[p], tgt_set[p], cx[p], cy[p], flags ? flags[p] : 0, angles + a0, (int32_t)(a1 - a0), 0.0, 0.0};
         ph->ang_off[p] = shared_angles ? (int64_t)p * (a1 - a0) : a0;   // all_costs layout: pair-major
     }

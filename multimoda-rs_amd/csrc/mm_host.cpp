@@ -817,6 +817,7 @@ int64_t mm_refine_angles(double initial, double range, double step, double* out,
 int64_t mm_filter_points_in_region(const double* xyz, int64_t n, const double* s, const double* e,
                                    int64_t* out_idx, int64_t cap)
 {
+    if (n < 0 || (n > 0 && !xyz) || !s || !e) return set_error(MM_ERR_INVALID, "mm_filter_points_in_region: bad arguments");
     const double margin = 5.0;
     double lo[3], hi[3];
     for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(s[k], e[k]) - margin; hi[k] = std::fmax(s[k], e[k]) + margin; }
@@ -938,6 +939,7 @@ static void lumen_mean(mm_geometry* g, int32_t i)
 // frame.rs:17-38
 void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double dz)
 {
+    if (!g || i < 0 || i >= g->n_frames || !g->lumen_off || !g->lumen || !g->centroid) return;   // nothing to move
     span_translate(g->lumen, g->lumen_off[i], g->lumen_off[i + 1], dx, dy, dz);
     if (g->cath_off) span_translate(g->cath, g->cath_off[i], g->cath_off[i + 1], dx, dy, dz);
     if (g->extra_off) span_translate(g->extra, g->extra_off[i], g->extra_off[i + 1], dx, dy, dz);
@@ -950,6 +952,7 @@ void mm_frame_translate(mm_geometry* g, int32_t i, double dx, double dy, double 
 void mm_frame_rotate(mm_geometry* g, int32_t i, double angle, double cx, double cy)
 {
     if (angle == 0.0) return;
+    if (!g || i < 0 || i >= g->n_frames || !g->lumen_off || !g->lumen || !g->centroid) return;
     span_rotate(g->lumen, g->lumen_off[i], g->lumen_off[i + 1], angle, cx, cy);
     if (g->cath_off) span_rotate(g->cath, g->cath_off[i], g->cath_off[i + 1], angle, cx, cy);
     if (g->extra_off) span_rotate(g->extra, g->extra_off[i], g->extra_off[i + 1], angle, cx, cy);
@@ -1229,6 +1232,8 @@ int mm_merge_shards(int world, int n, const double* cost, const int32_t* uniform
                     double* out_cost)
 {
     if (world <= 0 || n < 0) return set_error(MM_ERR_INVALID, "mm_merge_shards: bad sizes");
+    if (n > 0 && (!cost || !uniform || !angle || !idx || !tol || !ok || !out_angle || !out_idx || !out_cost))
+        return set_error(MM_ERR_INVALID, "mm_merge_shards: NULL array");
     for (int j = 0; j < n; ++j) {
         double gbest = INFINITY;
         for (int r = 0; r < world; ++r) gbest = std::fmin(gbest, cost[(size_t)r * n + j]);

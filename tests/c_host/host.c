@@ -1,0 +1,123 @@
+/*
+ * A host written in plain C against the drop-in boundary (include/mm_hausdorff.h): no Python, no torch, nothing but
+ * the shared library -- what a Rust / C host of the reference would link.  It runs the three things the boundary is
+ * for -- the metric, one rotation search at every precision, a batch of searches -- on seeded data and checks every
+ * result against the CPU oracle (oracle/mm_oracle.h; test infrastructure, linked here as the checker only).
+ * Built and run by tests/test_gpu_c_host.py; exit code 0 = all checks passed.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "mm_hausdorff.h"
+#include "mm_oracle.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static double urand(void)            /* splitmix64 -> [0, 1) */
+{
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+static void blob(int n, double rot, double* x, double* y)     /* a noisy closed contour, IVUS-lumen sized */
+{
+    for (int i = 0; i < n; ++i) {
+        double t = 6.283185307179586 * (double)i / (double)n;
+        double r = 2.5 * (1.0 + 0.15 * cos(2.0 * t + 0.7) + 0.07 * sin(3.0 * t)) + 0.05 * (urand() - 0.5);
+        double px = r * cos(t), py = 0.8 * r * sin(t);
+        x[i] = 4.5 + px * cos(rot) - py * sin(rot);
+        y[i] = 4.5 + px * sin(rot) + py * cos(rot);
+    }
+}
+
+#define CHECK(cond, ...) do { if (!(cond)) { fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+    fprintf(stderr, __VA_ARGS__); fprintf(stderr, " [%s]\n", mm_last_error()); return 1; } } while (0)
+
+int main(void)
+{
+    setvbuf(stdout, NULL, _IONBF, 0);
+    CHECK(mm_device_count() >= 1, "no HIP device");
+    mm_engine* e = NULL;
+    CHECK(mm_engine_create(-1, NULL, &e) == MM_OK && e, "mm_engine_create");
+    printf("library %s, %d device(s)\n", mm_version(), mm_device_count());
+
+    /* 1. the metric: the reference's known answers (process_utils.rs:214-547) and a seeded pair vs the oracle */
+    {
+        const double ax[] = {0, 3}, ay[] = {0, 0}, bx[] = {1, 2, 4}, by[] = {0, 0, 0};
+        double h = -1.0;
+        CHECK(mm_hausdorff_2d(e, ax, ay, 2, bx, by, 3, &h) == MM_OK && h == 1.0, "hausdorff KAT: %g", h);
+        CHECK(mm_hausdorff_2d(e, ax, ay, 0, bx, by, 3, &h) == MM_OK && h == 0.0, "empty set: %g", h);
+    }
+    enum { N = 521 };
+    static double rx[N], ry[N], tx[N], ty[N];
+    static orc_point ro[N], to[N];
+    blob(N, 0.0, rx, ry);
+    blob(N, 0.31, tx, ty);
+    for (int i = 0; i < N; ++i) { ro[i].x = rx[i]; ro[i].y = ry[i]; ro[i].z = 0; to[i].x = tx[i]; to[i].y = ty[i]; to[i].z = 0; }
+    {
+        double h = -1.0;
+        CHECK(mm_hausdorff_2d(e, rx, ry, N, tx, ty, N, &h) == MM_OK, "mm_hausdorff_2d");
+        CHECK(h == orc_hausdorff(ro, N, to, N), "metric differs from the oracle: %.17g", h);
+    }
+
+    /* 2. one search: search_range(|a| hausdorff(ref, rotate(tgt, a))) at 0.5 deg x +-180 deg, every precision */
+    static double angles[2048], costs[2048];
+    int degenerate = 0; double early = 0.0;
+    int64_t na = mm_search_angles(0.5, 180.0, 0, 0.0, 180.0, angles, 2048, &degenerate, &early);
+    CHECK(na == 721 && !degenerate, "mm_search_angles: %lld", (long long)na);
+    double cx = 0.0, cy = 0.0;
+    for (int i = 0; i < N; ++i) { cx += tx[i]; cy += ty[i]; }
+    cx /= N; cy /= N;
+    const double o_angle = orc_bruteforce_rotation(ro, N, to, N, 0.5, 180.0, cx, cy, 8);
+    const double o_cost = orc_cost_within(ro, N, to, N, o_angle, cx, cy);
+    for (int prec = MM_PRECISION_F64; prec <= MM_PRECISION_F32_BOUNDED; ++prec) {
+        double ba = 0, bc = 0; int bi = -1;
+        CHECK(mm_best_rotation(e, rx, ry, N, tx, ty, N, cx, cy, angles, (int)na, MM_SEARCH_SKIP_ZERO, prec, &ba, &bc, &bi,
+                               prec == MM_PRECISION_F64 ? costs : NULL) == MM_OK, "mm_best_rotation(prec %d)", prec);
+        CHECK(ba == o_angle && bc == o_cost && angles[bi] == ba, "precision %d: angle %.17g cost %.17g, oracle %.17g %.17g",
+              prec, ba, bc, o_angle, o_cost);
+        if (prec == MM_PRECISION_F64)
+            for (int a = 0; a < (int)na; a += 97)
+                CHECK(costs[a] == orc_cost_within(ro, N, to, N, angles[a], cx, cy), "cost of candidate %d", a);
+    }
+    printf("search: best angle %.6f rad, cost %.6f mm -- identical to the oracle at all four precisions\n", o_angle, o_cost);
+
+    /* 3. a ragged batch: 6 pairs of different sizes (one with an empty target), one launch sequence */
+    enum { P = 6 };
+    const int sizes[P][2] = {{6, 6}, {120, 0}, {521, 521}, {100, 333}, {17, 1}, {300, 299}};
+    static double bxr[4096], byr[4096], bxt[4096], byt[4096], bang[P * 721], bcx[P], bcy[P];
+    int64_t roff[P + 1] = {0}, toff[P + 1] = {0}, aoff[P + 1] = {0};
+    int32_t flags[P], bidx[P];
+    double bbest[P], bcost[P];
+    for (int p = 0; p < P; ++p) {
+        roff[p + 1] = roff[p] + sizes[p][0]; toff[p + 1] = toff[p] + sizes[p][1]; aoff[p + 1] = aoff[p] + na;
+        blob(sizes[p][0], 0.05 * p, bxr + roff[p], byr + roff[p]);
+        blob(sizes[p][1], 0.4 - 0.1 * p, bxt + toff[p], byt + toff[p]);
+        for (int a = 0; a < (int)na; ++a) bang[aoff[p] + a] = angles[a];
+        bcx[p] = 4.5 + 0.01 * p; bcy[p] = 4.5 - 0.02 * p; flags[p] = MM_SEARCH_SKIP_ZERO;
+    }
+    CHECK(mm_best_rotation_batch(e, P, roff, bxr, byr, toff, bxt, byt, aoff, bang, bcx, bcy, flags, MM_PRECISION_F32_FAST,
+                                 bidx, bbest, bcost, NULL, NULL) == MM_OK, "mm_best_rotation_batch");
+    for (int p = 0; p < P; ++p) {
+        static orc_point a_[600], b_[600];
+        for (int i = 0; i < sizes[p][0]; ++i) { a_[i].x = bxr[roff[p] + i]; a_[i].y = byr[roff[p] + i]; a_[i].z = 0; }
+        for (int i = 0; i < sizes[p][1]; ++i) { b_[i].x = bxt[toff[p] + i]; b_[i].y = byt[toff[p] + i]; b_[i].z = 0; }
+        const double oa = orc_bruteforce_rotation(a_, (size_t)sizes[p][0], b_, (size_t)sizes[p][1], 0.5, 180.0, bcx[p], bcy[p], 8);
+        const double oc = orc_cost_within(a_, (size_t)sizes[p][0], b_, (size_t)sizes[p][1], oa, bcx[p], bcy[p]);
+        CHECK(bbest[p] == oa && bcost[p] == oc, "batch pair %d: %.17g %.17g vs %.17g %.17g", p, bbest[p], bcost[p], oa, oc);
+    }
+    printf("batch: %d ragged pairs identical to the oracle\n", P);
+
+    /* errors are codes + mm_last_error(), never a crash */
+    CHECK(mm_hausdorff_2d(e, NULL, NULL, 3, NULL, NULL, 3, &early) < 0, "NULL sets must be an error");
+    CHECK(mm_best_rotation(e, rx, ry, N, tx, ty, N, cx, cy, angles, (int)na, 0, 99, &early, &early, &degenerate, NULL) == MM_ERR_INVALID,
+          "unknown precision must be MM_ERR_INVALID");
+    CHECK(mm_engine_synchronize(e) == MM_OK, "mm_engine_synchronize");
+    mm_engine_destroy(e);
+    printf("C_HOST_OK\n");
+    return 0;
+}
