@@ -101,9 +101,15 @@ class _ExchangeBuffers:
 
 
 def _buffers(plan, n_jobs):
+    """One set of exchange buffers per engine and size (an engine runs one search at a time): consecutive cases on
+    an engine reuse them, so nothing is allocated between a step's hand-over and its first launch."""
     b = getattr(plan, "_xbuf", None)
     if b is None:
-        b = plan._xbuf = _ExchangeBuffers(plan, n_jobs)
+        cache = plan.engine.__dict__.setdefault("_xbuf_cache", {})
+        b = cache.get(n_jobs)
+        if b is None:
+            b = cache[n_jobs] = _ExchangeBuffers(plan, n_jobs)
+        plan._xbuf = b
     return b
 
 
@@ -124,9 +130,11 @@ def _all_reduce_min(t, group, stream):
 def search_device(plan, group=None):
     """The search half of WithinPlan.run_sharded with the exchange on the device (module docstring)."""
     n_jobs, n_levels, _tol = plan.dims()
-    b = _buffers(plan, n_jobs)
+    b = None
     for l in range(n_levels):
-        plan.level_launch(l)
+        plan.level_launch(l)                      # first thing: the device starts on the level while the host goes on
+        if b is None:
+            b = _buffers(plan, n_jobs)
         plan.level_export_cost(l, b.cost.data_ptr())
         _all_reduce_min(b.cost, group, b.stream)
         plan.level_export_keys(l, b.cost.data_ptr(), b.keys.data_ptr())
@@ -140,7 +148,7 @@ def search_inprocess(plans: Sequence):
     and the commit are the ones a multi-rank run uses; only the transport differs)."""
     import torch
     n_jobs, n_levels, _tol = plans[0].dims()
-    bufs = [_buffers(p, n_jobs) for p in plans]
+    bufs = [_ExchangeBuffers(p, n_jobs) for p in plans]      # the plans share one engine here: one record each
     for l in range(n_levels):
         for p, b in zip(plans, bufs):
             p.level_launch(l)
