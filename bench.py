@@ -254,8 +254,9 @@ class Runner:
     device, level 0 staged), search(k) (all levels: local search -> exchange -> commit) and finish(k) (chain walk,
     AB|CD and AC|BD between alignments).  Step k lives on engine k % len(engs) and works on its own copy of the case."""
 
-    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases):
+    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases, rehearse=0):
         self.mm, self.engs, self.cfg, self.prec, self.mode, self.rank, self.world, self.ext = mm, engs, cfg, prec, mode, rank, world, ext
+        self.rehearse = rehearse           # > 1: this process plays rank 0 of `rehearse` ranks without peers (timing only)
         # the caller's input data: one fresh copy of the case per step (made before the timed region -- this is
         # the data a caller hands over, not work of the step)
         self.cases = [base if ext is not None else [g.copy() for g in base] for _ in range(n_cases)]
@@ -275,7 +276,8 @@ class Runner:
         t0 = time.perf_counter()
         self.plans[k] = mm.WithinPlan(self.engs[k % len(self.engs)], self.cases[k], cfg["step_deg"], cfg["range_deg"], True,
                                       cfg["sample_size"], precision=self.prec,
-                                      shard=(self.rank, self.world) if self.world > 1 else None)
+                                      shard=(self.rank, self.world) if self.world > 1 else
+                                      ((0, self.rehearse) if self.rehearse > 1 else None))
         self.stage_s += time.perf_counter() - t0
         self.staged += 1
 
@@ -286,8 +288,11 @@ class Runner:
 
     def search(self, k):
         if self.plans[k] is not None and self.ext is None:
-            if getattr(self.plans[k], "_begun", False):
+            if getattr(self.plans[k], "_begun", False) and self.world == 1 and self.rehearse <= 1:
                 self.plans[k].search_end()               # collect level 0, remaining levels, commit
+            elif self.rehearse > 1:
+                from multimoda_rs_amd import distributed as D
+                D.search_device(self.plans[k])           # the N > 1 code path over a world = 1 RCCL group
             else:
                 self.plans[k].search()                   # levels: local search -> exchange -> commit
 
@@ -372,6 +377,18 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # MM_BENCH_REHEARSE_WORLD=N (single process): play rank 0 of N ranks WITHOUT peers -- this rank's share of the
+    # candidate axis, the N > 1 code path (no look-ahead, device exchange, both all-reduces over a world = 1 RCCL
+    # group).  The result is not an alignment (only 1/N of the candidates are seen); what it measures is the
+    # per-rank step time of an N-GPU run short of the xGMI latency of two small all-reduces.  Never a bench line.
+    rehearse = int(os.environ.get("MM_BENCH_REHEARSE_WORLD", "0"))
+    if rehearse > 1:
+        if world != 1:
+            raise SystemExit("MM_BENCH_REHEARSE_WORLD is a single-process rehearsal")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+
     cfg = WORKLOADS[args.workload]
     mode = 0 if args.mode == "chain" else 1
     PRECS = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED,
@@ -430,11 +447,16 @@ def main():
         resident: every case is staged before the timed region (inputs and search sets resident in HBM when it
         starts); the region then holds K searches and K finishes only."""
         n_total = warmup + steps
-        r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK)
+        r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK, rehearse)
         for k in range(n_total if resident else LOOK):
             r.stage(k)                                   # priming (setup, untimed)
         stage_fn = None if resident else r.stage
-        begin = r.begin if (pipe and world == 1 and mode == 1 and ext is None and not os.environ.get("MM_BENCH_NO_LOOKAHEAD")) else None
+        # N > 1 (opt-in, MM_BENCH_SHARD_LOOKAHEAD=1; never measured on a multi-GPU box): the same look-ahead -- step
+        # k+1's local launch is queued behind step k's long kernel and runs beside step k's re-score, exports and
+        # all-reduces.  The order of the collectives is unchanged on every rank.
+        sharded = world > 1 or rehearse > 1
+        begin = r.begin if (pipe and mode == 1 and ext is None and not os.environ.get("MM_BENCH_NO_LOOKAHEAD")
+                            and (not sharded or os.environ.get("MM_BENCH_SHARD_LOOKAHEAD") == "1")) else None
         import gc
         gc.collect()
         gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
@@ -463,6 +485,23 @@ def main():
             between_stage(mm, e, [g.copy() for g in base], cfg, PREC)
 
     main_leg = timed_leg(PREC, args.warmup, args.steps, pipelined)
+    if rehearse > 1:
+        full = cfg["frames"] and sum(g.n_frames - 1 for g in base) * len(mm.search_angles(cfg["step_deg"], cfg["range_deg"])[0])
+        ms = main_leg["dt"] / args.steps * 1e3
+        kms, kpe = main_leg["prof"][0], main_leg["prof"][1]
+        big = kpe >= 0.5 * kpe.max() if len(kpe) else np.zeros(0, bool)
+        print(json.dumps({"rehearsal": f"rank 0 of {rehearse} without peers (MM_BENCH_REHEARSE_WORLD): timing only, NOT an alignment",
+                          "per_rank_ms_per_step": ms, "steps": args.steps,
+                          "dominant_launch_ms": float(kms[big].mean()) if len(kms) else None,
+                          "stage_ms_per_case": main_leg["stage_ms"],
+                          "within_pose_evals_of_the_full_grid": int(full),
+                          "projected_pose_evals_per_s": full / (ms * 1e-3),
+                          "note": "projected = the full grid's within pose-evals / this rank's step time: what N such ranks "
+                                  "deliver if the two all-reduces cost what they cost at world = 1"}))
+        dist.destroy_process_group()
+        for e in engs:
+            e.close()
+        return
     dt, results, evals, unresolved = main_leg["dt"], main_leg["results"], main_leg["evals"], main_leg["unresolved"]
     launch_ms, launch_pe, prof, bound = main_leg["prof"]
     res = results[-1]

@@ -131,8 +131,11 @@ def search_device(plan, group=None):
     """The search half of WithinPlan.run_sharded with the exchange on the device (module docstring)."""
     n_jobs, n_levels, _tol = plan.dims()
     b = None
+    begun = bool(getattr(plan, "_begun", False))  # WithinPlan.search_begin has enqueued level 0 already
+    plan._begun = False
     for l in range(n_levels):
-        plan.level_launch(l)                      # first thing: the device starts on the level while the host goes on
+        if not (begun and l == 0):
+            plan.level_launch(l)                  # first thing: the device starts on the level while the host goes on
         if b is None:
             b = _buffers(plan, n_jobs)
         plan.level_export_cost(l, b.cost.data_ptr())

@@ -362,8 +362,9 @@ class WithinPlan:
         if D.world_size(group) > 1 and D.exchange_mode() == "device":
             return D.search_device(self, group)
         n_jobs, n_levels, tol = self.dims()
+        begun, self._begun = bool(getattr(self, "_begun", False)), False      # search_begin enqueued level 0 already
         for l in range(n_levels):
-            local = self.level_local(l, n_jobs)
+            local = self.level_collect(l, n_jobs) if (begun and l == 0) else self.level_local(l, n_jobs)
             ok, angle, _idx, _cost = D.merge_level(local, tol, group)
             self.level_commit(l, ok, angle)
 
