@@ -323,7 +323,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)   # the first two big launches of a process run at ramping clocks
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
     ap.add_argument("--precision", default="fast", choices=["f32", "fast", "bounded", "f64"],
