@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "mm_hausdorff.h"
 #include "mm_oracle.h"
@@ -111,6 +112,77 @@ int main(void)
         CHECK(bbest[p] == oa && bcost[p] == oc, "batch pair %d: %.17g %.17g vs %.17g %.17g", p, bbest[p], bcost[p], oa, oc);
     }
     printf("batch: %d ragged pairs identical to the oracle\n", P);
+
+    /* 4. the path itself: two pullbacks through the decoupled plan (all frame pairs in one launch sequence, then the
+     *    exact chain walk) and the between alignment of the second onto the first -- logs, best rotation and every
+     *    coordinate against the oracle's sequential chain (align_within.rs:24-134, align_between.rs:11-68) */
+    {
+        enum { F = 9, M = 120, NC = 20, G = 2 };
+        static uint32_t ids[G][F], origs[G][F];
+        static double cen[G][F * 3], lum[G][F * M * 3], cath[G][F * NC * 3], refp[G][F * 3], lcen[G][F * 3];
+        static double o_cen[G][F * 3], o_lum[G][F * M * 3], o_cath[G][F * NC * 3], o_ref[G][F * 3], o_lcen[G][F * 3];
+        static int64_t loff[F + 1], coff[F + 1];
+        static uint8_t href[G][F];
+        mm_geometry g[G]; orc_geometry og[G];
+        mm_geometry* gp[G]; mm_alignlog logs[G][F - 1]; mm_alignlog* lp[G]; orc_alignlog ologs[G][F - 1];
+        for (int k = 0; k <= F; ++k) { loff[k] = (int64_t)k * M; coff[k] = (int64_t)k * NC; }
+        for (int q = 0; q < G; ++q) {
+            double twist = 0.0;
+            for (int k = 0; k < F; ++k) {
+                static double x[M], y[M];
+                twist += 0.12 * (urand() - 0.3);                     /* a random-walk torsion along the pullback */
+                blob(M, twist + 0.4 * q, x, y);
+                double sx = 0, sy = 0;
+                for (int i = 0; i < M; ++i) {
+                    double* p3 = &lum[q][(k * M + i) * 3];
+                    p3[0] = x[i] + 0.03 * k; p3[1] = y[i] - 0.02 * k; p3[2] = 0.5 * k;
+                    sx += p3[0]; sy += p3[1];
+                }
+                cen[q][3 * k] = sx / M; cen[q][3 * k + 1] = sy / M; cen[q][3 * k + 2] = 0.5 * k;
+                lcen[q][3 * k] = cen[q][3 * k]; lcen[q][3 * k + 1] = cen[q][3 * k + 1]; lcen[q][3 * k + 2] = cen[q][3 * k + 2];
+                for (int i = 0; i < NC; ++i) {
+                    double a = 6.283185307179586 * i / NC;
+                    double* c3 = &cath[q][(k * NC + i) * 3];
+                    c3[0] = 4.5 + 0.5 * cos(a); c3[1] = 4.5 + 0.5 * sin(a); c3[2] = 0.5 * k;
+                }
+                ids[q][k] = (uint32_t)k; origs[q][k] = (uint32_t)(F - 1 - k); href[q][k] = k == 0;
+                refp[q][3 * k] = k == 0 ? 6.9 : 0.0; refp[q][3 * k + 1] = k == 0 ? 4.5 : 0.0; refp[q][3 * k + 2] = 0.0;
+            }
+            memcpy(o_cen[q], cen[q], sizeof cen[q]); memcpy(o_lum[q], lum[q], sizeof lum[q]);
+            memcpy(o_cath[q], cath[q], sizeof cath[q]); memcpy(o_ref[q], refp[q], sizeof refp[q]);
+            memcpy(o_lcen[q], lcen[q], sizeof lcen[q]);
+            memset(&g[q], 0, sizeof g[q]); memset(&og[q], 0, sizeof og[q]);
+            g[q].n_frames = F; g[q].id = ids[q]; g[q].lumen_id = ids[q]; g[q].orig_frame = origs[q]; g[q].centroid = cen[q];
+            g[q].lumen_off = loff; g[q].lumen = lum[q]; g[q].has_catheter = 1; g[q].cath_off = coff; g[q].cath = cath[q];
+            g[q].has_ref = href[q]; g[q].ref = refp[q]; g[q].lumen_centroid = lcen[q];
+            og[q].n_frames = F; og[q].id = ids[q]; og[q].lumen_id = ids[q]; og[q].orig_frame = origs[q]; og[q].centroid = o_cen[q];
+            og[q].lumen_off = loff; og[q].lumen = (orc_point*)o_lum[q]; og[q].has_catheter = 1; og[q].cath_off = coff;
+            og[q].cath = (orc_point*)o_cath[q]; og[q].has_ref = href[q]; og[q].ref = (orc_point*)o_ref[q];
+            og[q].lumen_centroid = o_lcen[q];
+            gp[q] = &g[q]; lp[q] = logs[q];
+        }
+        mm_within_plan* plan = NULL;
+        int64_t evals = 0, unresolved = -1;
+        CHECK(mm_within_plan_create(e, G, gp, 1.0, 60.0, 1, 200, MM_PRECISION_F32_FAST, &plan) == MM_OK && plan, "mm_within_plan_create");
+        CHECK(mm_within_plan_run(plan, lp, &evals, &unresolved) == MM_OK, "mm_within_plan_run");
+        mm_within_plan_destroy(plan);
+        for (int q = 0; q < G; ++q) {
+            CHECK(orc_align_within_chain(&og[q], 1.0, 60.0, 1, 200, ologs[q], 8) == 0, "oracle chain");
+            CHECK(sizeof(mm_alignlog) == sizeof(orc_alignlog) && memcmp(logs[q], ologs[q], sizeof ologs[q]) == 0, "chain logs of pullback %d", q);
+            CHECK(memcmp(lum[q], o_lum[q], sizeof lum[q]) == 0 && memcmp(cath[q], o_cath[q], sizeof cath[q]) == 0 &&
+                  memcmp(cen[q], o_cen[q], sizeof cen[q]) == 0 && memcmp(lcen[q], o_lcen[q], sizeof lcen[q]) == 0,
+                  "chain coordinates of pullback %d", q);
+        }
+        double best = 0.0, obest = 1.0; int64_t bevals = 0;
+        mm_geometry* ga[1] = {&g[0]}; mm_geometry* gb[1] = {&g[1]};
+        CHECK(mm_align_between(e, 1, ga, gb, 60.0, 0.5, 200, MM_PRECISION_F32_BOUNDED, &best, &bevals) == MM_OK, "mm_align_between");
+        CHECK(orc_align_between(&og[0], &og[1], 60.0, 0.5, 200, &obest, 8) == 0, "oracle between");
+        CHECK(best == obest, "between rotation %.17g vs %.17g", best, obest);
+        CHECK(memcmp(lum[1], o_lum[1], sizeof lum[1]) == 0 && memcmp(cen[1], o_cen[1], sizeof cen[1]) == 0 &&
+              memcmp(refp[1], o_ref[1], sizeof refp[1]) == 0, "between coordinates");
+        printf("alignment: %d pullbacks x %d frames, %lld within pose-evals (%lld steps re-searched), between rotation %.6f rad -- "
+               "logs and coordinates identical to the oracle\n", G, F, (long long)evals, (long long)unresolved, best);
+    }
 
     /* errors are codes + mm_last_error(), never a crash */
     CHECK(mm_hausdorff_2d(e, NULL, NULL, 3, NULL, NULL, 3, &early) < 0, "NULL sets must be an error");
