@@ -219,3 +219,54 @@ def test_nearest_neighbour_minima_match_the_oracle(engine, mm, seed, na, nb, sha
     a, b = cloud(na) + origin, cloud(nb) + origin + offset
     assert np.array_equal(mm.ccta.nn_min_sq(a, b, engine=engine), occ.nn_min_sq(a, b))
     assert mm.ccta.symmetric_nn_distance(a, b, engine=engine) == occ.symmetric_nn_distance(a, b)
+
+
+@settings(max_examples=15 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(seed=st.integers(0, 10**6), n_frames=st.integers(4, 14), n_points=st.sampled_from([24, 60, 120]),
+       hole=st.booleans(), with_eem=st.booleans(), thick=st.sampled_from([None, 0.7, 1.1]), smooth=st.booleans(),
+       post=st.booleans(), bruteforce=st.booleans(), step=st.sampled_from([0.5, 1.0, 3.0]),
+       mode=st.sampled_from(["single", "singlepair", "full"]))
+def test_entry_points_native_bookkeeping_equals_the_python_checkers(engine, mm, seed, n_frames, n_points, hole, with_eem, thick,
+                                                                    smooth, post, bruteforce, step, mode):
+    """from_array_single / _singlepair / _full end to end with the searches on the device: the native builder, post-steps
+    and pair post-processing (the product path) against the same calls with every host piece switched to its Python
+    checker (MM_PY_BUILDER, MM_PY_POSTPROC) -- logs, frame counts and every array of every returned geometry, over
+    pullbacks with missing frames, EEM contours, measured thicknesses (anomalous coronaries), with and without
+    smoothing and post-processing."""
+    from test_golden_and_api import _array_input
+    from test_native_frames import assert_same
+
+    def inputs():
+        out = []
+        for q in range({"single": 1, "singlepair": 2, "full": 4}[mode]):
+            drop = (2 + (seed + q) % max(n_frames - 3, 1),) if hole else ()
+            d = _array_input(mm, n_frames=n_frames, n_points=n_points, drop=drop, with_eem=with_eem, thickness=thick,
+                             seed=(seed + 17 * q) % 1000)
+            d.diastole = q % 2 == 0
+            out.append(d)
+        return out
+
+    kw = dict(step_rotation_deg=step, range_rotation_deg=30.0, bruteforce=bruteforce, smooth=smooth, write_obj=False,
+              engine=engine)
+    fn = {"single": mm.from_array_single, "singlepair": mm.from_array_singlepair, "full": mm.from_array_full}[mode]
+    if mode != "single":
+        kw["postprocessing"] = post
+    mp = pytest.MonkeyPatch()
+    try:
+        got = fn(*inputs(), **kw)
+        mp.setenv("MM_PY_BUILDER", "1"); mp.setenv("MM_PY_POSTPROC", "1")
+        want = fn(*inputs(), **kw)
+    finally:
+        mp.undo()
+
+    def geoms(r):
+        if mode == "single":
+            return [r[0]], r[1]
+        pairs = r[:-1] if mode == "full" else [r[0]]
+        return [g for p in pairs for g in (p.geom_a, p.geom_b)], r[-1]
+    ga, la = geoms(got)
+    gb, lb = geoms(want)
+    assert la == lb and len(ga) == len(gb)
+    for x, y in zip(ga, gb):
+        assert_same(x, y, mode)
