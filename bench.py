@@ -505,6 +505,11 @@ def main():
     dt, results, evals, unresolved = main_leg["dt"], main_leg["results"], main_leg["evals"], main_leg["unresolved"]
     launch_ms, launch_pe, prof, bound = main_leg["prof"]
     res = results[-1]
+    # every step aligns a copy of the same case: all K results (logs, between rotations, pose-eval and re-search counts)
+    # must be the same -- a race in the pipeline (three threads, three engines) would show here first
+    steps_identical = all(list(r[0]) == list(res[0]) and np.array_equal(r[1], res[1]) and r[2:] == res[2:] for r in results)
+    if not steps_identical:
+        raise SystemExit("the timed steps disagree with each other: identical inputs gave different alignments")
     if args.precision != "bounded":
         bound = None
 
@@ -604,6 +609,7 @@ def main():
                                          ("search only, point sets staged in HBM before the timed region" if ext is not None else
                                           "the whole step (faithful chain: sets built and uploaded per chain step)"),
                        "staged_cases_in_timed_region": main_leg["staged"], "stage_ms_per_case": main_leg["stage_ms"],
+                       "all_timed_steps_identical": steps_identical,
                        "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU",
                        "exchange": (os.environ.get("MM_EXCHANGE", "device") + (" (2 all-reduces per level on device records)"
                                     if os.environ.get("MM_EXCHANGE", "device") == "device" else "")) if world > 1 else None,
