@@ -351,7 +351,7 @@ def _build_geometry_native(d: InputData, label: str, image_center, radius: float
         F, nl, nc, ne = F.value, nl.value, nc.value, ne.value
         g = FlatGeometry(ids=np.zeros(F, np.uint32), lumen_ids=np.zeros(F, np.uint32), orig_frames=np.zeros(F, np.uint32),
                          centroids=np.zeros((F, 3)), lumen_off=np.zeros(F + 1, np.int64), lumen=np.zeros((nl, 3)),
-                         has_ref=np.zeros(F, np.uint8), ref=np.zeros((F, 3)), label=d.label or label)
+                         has_ref=np.zeros(F, np.uint8), ref=np.zeros((F, 3)), label=label or d.label)
         if nc:
             g.cath_off, g.cath = np.zeros(F + 1, np.int64), np.zeros((nc, 3))
         if ne:
@@ -510,7 +510,7 @@ def build_geometry_python(d: InputData, label: str = "", image_center=(4.5, 4.5)
         why = _integrity_error(flist)
         if why:
             raise RuntimeError(f"build_geometry_from_inputdata: {why}")
-    return _to_flat(flist, d.label or label)
+    return _to_flat(flist, label or d.label)
 
 
 def _to_flat(flist: Sequence[_Frame], label: str) -> FlatGeometry:

@@ -132,15 +132,20 @@ def build_geometry(path, diastole, image_center=(4.5, 4.5), radius=0.5, n_points
     phase = "diastolic" if diastole else "systolic"
     lumen = read_contour_data(os.path.join(path, f"{phase}_contours.csv"))
     ref = read_reference_point(os.path.join(path, f"{phase}_reference_points.csv"))
-    for extra in ("branch", "calcium", "eem"):
-        if os.path.exists(os.path.join(path, f"{extra}_{phase}_contours.csv")):
-            raise NotImplementedError("refbuild covers the lumen-only fixtures")
+    extras_in = {}                                                                 # input.rs:100-118: optional contour files
+    for kind, stem in (("eem", "eem"), ("calcification", "calcium"), ("sidebranch", "branch")):
+        f = os.path.join(path, f"{stem}_{phase}_contours.csv")
+        if os.path.exists(f):
+            extras_in[kind] = read_contour_data(f)
     rec_path = os.path.join(path, "combined_sorted_manual.csv")
     if not os.path.exists(rec_path):
         rec_path = os.path.join(path, "diastolic_systolic_records.csv")
     records = read_records(rec_path) if os.path.exists(rec_path) else None
 
-    originals = sorted({p["frame"] for p in lumen} | {ref["frame"]})              # build.rs:36-68
+    originals = {p["frame"] for p in lumen} | {ref["frame"]}                       # build.rs:36-68: ALL contour kinds
+    for pts in extras_in.values():
+        originals |= {p["frame"] for p in pts}
+    originals = sorted(originals)
     mapping = {o: i for i, o in enumerate(originals)}
 
     groups = {}
@@ -150,10 +155,20 @@ def build_geometry(path, diastole, image_center=(4.5, 4.5), radius=0.5, n_points
     for orig in sorted(groups):
         pts = groups[orig]
         fid = mapping[orig]
-        fr = {"id": fid, "orig": orig, "lumen": pts, "centroid": _centroid(pts), "ref": None, "cath": None}
+        fr = {"id": fid, "orig": orig, "lumen": pts, "centroid": _centroid(pts), "ref": None, "cath": None, "extras": {}}
         if mapping.get(ref["frame"]) == fid:                                       # build.rs:121-125
             fr["ref"] = dict(ref)
         frames.append(fr)
+
+    by_id = {fr["id"]: fr for fr in frames}                                        # build.rs:131-150: extras join the frame of
+    for kind, pts in extras_in.items():                                            # their (mapped) id; frames without a lumen
+        g2 = {}                                                                    # do not exist, their extras are dropped
+        for p in pts:
+            g2.setdefault(p["frame"], []).append(p)
+        for orig, cp in g2.items():
+            fr = by_id.get(mapping[orig])
+            if fr is not None:
+                fr["extras"][kind] = cp
 
     if n_points > 0:                                                               # build.rs:152-174, frame.rs:163-204
         for fr in frames:
@@ -185,6 +200,9 @@ def build_geometry(path, diastole, image_center=(4.5, 4.5), radius=0.5, n_points
             if fr["cath"] is not None:
                 for p in fr["cath"]:
                     p["z"] = z
+            for cp in fr["extras"].values():
+                for p in cp:
+                    p["z"] = z
             if fr["ref"] is not None:
                 fr["ref"]["z"] = z
             fr["centroid"][2] = z
@@ -194,6 +212,7 @@ def build_geometry(path, diastole, image_center=(4.5, 4.5), radius=0.5, n_points
         fr["lumen"] = _sort_contour_points(fr["lumen"])
         if fr["cath"] is not None:
             fr["cath"] = _sort_contour_points(fr["cath"])
+        fr["extras"] = {k: _sort_contour_points(v) for k, v in fr["extras"].items()}
 
     n = len(frames)                                                                # geometry.rs:325-381
     if n:
@@ -214,6 +233,9 @@ def build_geometry(path, diastole, image_center=(4.5, 4.5), radius=0.5, n_points
             if fr["cath"] is not None:
                 for p in fr["cath"]:
                     p["z"] = z
+            for cp in fr["extras"].values():
+                for p in cp:
+                    p["z"] = z
             if fr["ref"] is not None:
                 fr["ref"]["z"] = z
 
@@ -225,6 +247,7 @@ def build_geometry(path, diastole, image_center=(4.5, 4.5), radius=0.5, n_points
         "catheters": [xyz(fr["cath"]) for fr in frames] if n_points > 0 else None,
         "centroids": [list(fr["centroid"]) for fr in frames],
         "ref_points": {i: [fr["ref"]["x"], fr["ref"]["y"], fr["ref"]["z"]] for i, fr in enumerate(frames) if fr["ref"] is not None},
+        "extras": [{k: xyz(v) for k, v in fr["extras"].items()} for fr in frames],
     }
 
 

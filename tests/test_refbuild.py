@@ -39,6 +39,65 @@ def test_product_builder_equals_independent_builder(mm, folder, diastole, builde
         assert list(g.ref[i]) == p
 
 
+@pytest.mark.parametrize("builder", ["native", "python"])
+def test_fixture_with_eem_calcium_and_branch_files(mm, builder, monkeypatch):
+    """data/fixtures/ivus_full of the reference (build.rs: test_full_directory_all_frames_explicit_types): EEM contours
+    on the lumen frames, calcium and side-branch contours on frames that have NO lumen (they take part in the id
+    mapping and are dropped).  Every frame carries lumen, EEM and catheter with one id and one original frame; the
+    systolic phase of this fixture has its reference point on a frame without contours -- the builder's integrity
+    check refuses it (the reference's test only builds the diastolic phase)."""
+    import __graft_entry__ as ge
+    ge.build()
+    if builder == "python":
+        monkeypatch.setenv("MM_PY_BUILDER", "1")
+    path = os.path.join(GOLD, "ivus_full")
+    g = mm.build_geometry_from_inputdata(None, path, "full", True)
+    b = refbuild.build_geometry(path, True)
+    F = g.n_frames
+    assert F == len(b["ids"]) == 3 and list(g.ids) == b["ids"] == [0, 1, 2] and list(g.orig_frames) == b["orig_frames"]
+    cnt = g.meta["extra_counts"]
+    assert cnt["eem"].tolist() == [501] * 3 and not cnt["calcification"].any() and not cnt["sidebranch"].any()
+    assert np.array_equal(g.centroids, np.array(b["centroids"]))
+    for i in range(F):
+        assert set(b["extras"][i]) == {"eem"}
+        assert np.array_equal(g.frame_lumen(i), b["lumens"][i]) and np.array_equal(g.frame_cath(i), b["catheters"][i])
+        assert np.array_equal(g.extra[g.extra_off[i]:g.extra_off[i + 1]], b["extras"][i]["eem"])
+        assert g.frame_cath(i).shape[0] == 20 and (g.frame_cath(i)[:, 2] == g.centroids[i, 2]).all()
+    with pytest.raises(RuntimeError, match="Expected exactly one reference point, found 0"):
+        mm.build_geometry_from_inputdata(None, path, "full", False)
+
+
+def test_rest_directory_area_elliptic(mm):
+    """build.rs: test_rest_directory_area_elliptic on data/fixtures/ivus_rest -- the reference's expected values."""
+    import __graft_entry__ as ge
+    from multimoda_rs_amd import api
+    ge.build()
+    g = mm.build_geometry_from_inputdata(None, os.path.join(GOLD, "ivus_rest"), "full", True)
+    lum = g.frame_lumen(0)
+    assert int(g.orig_frames[0]) == 385
+    x, y = lum[:, 0], lum[:, 1]
+    area = 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))     # Contour::area is the shoelace formula
+    assert area == pytest.approx(5.42, abs=0.1)
+    assert api._find_farthest_points(lum)[1] == pytest.approx(5.2, abs=0.1)
+    assert api._elliptic_ratio(lum) == pytest.approx(4.52, abs=0.1)
+    assert g.meta["aortic_thickness"][0] == 0.96 and g.meta["pulmonary_thickness"][0] == 1.68
+    assert g.has_ref[0] == 1                                    # the reference point sits on frame 0 (= original frame 385)
+    assert (g.frame_cath(0)[:, 2] == g.centroids[0, 2]).all()   # test_catheter_contour_properties
+
+
+def test_label_argument_names_the_geometry(mm):
+    """build.rs:181 / test_build_geometry_with_input_data: Geometry.label is the `label` argument, not InputData.label."""
+    import __graft_entry__ as ge
+    ge.build()
+    d = mm.InputData(lumen=np.array([[0, 1.0, 2.0, 3.0]]), eem=np.array([[0, 1.0, 2.0, 3.0]]),
+                     ref_point=np.array([0, 1.0, 2.0, 3.0]), diastole=True, label="test")
+    g = mm.build_geometry_from_inputdata(d, None, "test_label", True, (0.0, 0.0), 1.0, 10)
+    assert g.n_frames == 1 and g.label == "test_label"
+    assert mm.build_geometry_from_inputdata(None, os.path.join(GOLD, "ivus_rest"), "path_test", True).label == "path_test"
+    with pytest.raises(RuntimeError, match="Either input_data or path must be provided"):
+        mm.build_geometry_from_inputdata(None, None, "x", True)                        # test_error_on_no_input
+
+
 def test_rows_the_reference_reader_skips(tmp_path):
     """read_contour_data (input.rs:172-194): rows that do not deserialize into ContourPoint are skipped."""
     p = tmp_path / "c.csv"
