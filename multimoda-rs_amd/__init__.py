@@ -19,7 +19,7 @@ from .io import InputData, Record, build_geometry_from_inputdata, numpy_to_input
 from .api import (GeometryPair, align_frames_in_geometries, from_array_doublepair, from_array_full,
                   from_array_single, from_array_singlepair, from_file_doublepair, from_file_full,
                   from_file_single, from_file_singlepair)
-from .centerline import (Centerline, align_combined, align_manual, align_three_point, numpy_to_centerline,
+from .centerline import (Centerline, align_combined, align_manual, align_three_point, numpy_to_centerline, read_centerline_vtp,
                          preprocess_centerline)
 from . import centerline
 from . import ccta
@@ -43,7 +43,7 @@ __all__ = [
     "InputData", "Record", "numpy_to_inputdata", "build_geometry_from_inputdata", "process_directory",
     "GeometryPair", "align_frames_in_geometries",
     "ShiftRotationSearch", "to_array", "numpy_to_geometry", "to_obj", "export",
-    "Centerline", "numpy_to_centerline", "preprocess_centerline", "align_three_point", "align_manual",
+    "Centerline", "numpy_to_centerline", "read_centerline_vtp", "preprocess_centerline", "align_three_point", "align_manual",
     "align_combined", "centerline",
     "ccta", "adjust_diameter_centerline_morphing_simple", "find_proximal_distal_scaling", "find_aortic_scaling",
     "find_aortic_wall_scaling", "find_distal_and_proximal_scaling", "find_aorta_scaling",

@@ -66,6 +66,11 @@ class Centerline:
     def xyz(self) -> np.ndarray:
         return np.stack([self.points["x"], self.points["y"], self.points["z"]], axis=1)
 
+    @property
+    def branch_start_indices(self):
+        """Centerline.branch_start_indices (centerline.rs): first point of every branch."""
+        return [s for s, _e in self._branch_runs()]
+
     # -- branches (centerline.rs: points of one branch are contiguous, branch 0 = main vessel) -------
     def _branch_runs(self):
         b = self.points["branch_id"]
@@ -175,6 +180,116 @@ def numpy_to_centerline(arr) -> Centerline:
     if arr.shape[0] < 2:
         raise ValueError("Centerline must contain at least two points after cleaning/interpolation.")
     return Centerline.from_contour_points(arr)
+
+
+def read_centerline_vtp(file_path: str) -> Centerline:
+    """``read_centerline_vtp`` (multimodars/_processing.py:1355-1385, src/intravascular/io/input.rs:259-461): an
+    ASCII VTK PolyData (``.vtp``) centerline, e.g. a VMTK export.  Every VTK line is a branch; branches are numbered
+    by descending ARC LENGTH (branch 0 = the geometrically longest line, not the one with most points); tangents are
+    normalised forward differences inside a branch, the last point of a branch repeats its predecessor's (zero for a
+    single-point branch or coincident points); radii from ``MaximumInscribedSphereRadius`` if its length matches,
+    else 0.  Binary or appended-data files are refused with the reference's messages."""
+    from .io import _RE_F64, _RE_U32
+    try:
+        with open(file_path, "rb") as fh:
+            raw = fh.read()
+    except OSError as e:
+        raise RuntimeError(f"cannot open {file_path!r}: {e}") from e
+    if any(b < 0x09 or 0x0D < b < 0x20 for b in raw[:512]):
+        raise RuntimeError(f"{file_path!r} appears to be a binary VTP file; only ASCII-format VTP is supported. "
+                           "Re-export from your software with 'ASCII' data mode.")
+    try:
+        xml = raw.decode("utf-8")
+    except UnicodeDecodeError as e:
+        raise RuntimeError(f"{file_path!r}: not valid UTF-8") from e
+    for fmt in ('format="binary"', 'format="appended"'):
+        if fmt in xml:
+            raise RuntimeError(f"{file_path!r}: binary-encoded DataArrays detected ({fmt}); only ASCII format is "
+                               "supported. Re-export with 'ASCII' data mode.")
+
+    def section(tag):                                         # extract_section (:295-306)
+        start = xml.find("<" + tag)
+        if start < 0:
+            raise RuntimeError(f"VTP: <{tag}> section not found")
+        end = xml.find(f"</{tag}>", start)
+        if end < 0:
+            raise RuntimeError(f"VTP: </{tag}> not found")
+        return xml[start:end + len(tag) + 3]
+
+    def dataarray_text(sec, name):                            # :308-329
+        pos = sec.find(f'Name="{name}"')
+        if pos < 0:
+            raise RuntimeError(f'VTP: DataArray Name="{name}" not found')
+        da = sec.rfind("<DataArray", 0, pos)
+        if da < 0:
+            raise RuntimeError(f'VTP: no <DataArray before Name="{name}"')
+        gt = sec.find(">", da)
+        if gt < 0:
+            raise RuntimeError(f'VTP: unclosed <DataArray Name="{name}">')
+        close = sec.find("</DataArray>", gt + 1)
+        if close < 0:
+            raise RuntimeError(f'VTP: no </DataArray> for Name="{name}"')
+        text = sec[gt + 1:close].strip()
+        lt = text.find("<")                                   # <InformationKey> nodes inside the Points array
+        return (text if lt < 0 else text[:lt]).strip()
+
+    def nums(text, rx, conv):                                 # parse_nums (:331-343), Rust's number grammars
+        out = []
+        for tok in text.split():
+            if not rx.match(tok):
+                raise RuntimeError(f"VTP: bad number '{tok}'")
+            out.append(conv(tok))
+        return out
+
+    pts_raw = nums(dataarray_text(section("Points"), "Points"), _RE_F64, float)
+    if len(pts_raw) % 3:
+        raise RuntimeError(f"VTP: Points array length {len(pts_raw)} not divisible by 3")
+    coords = np.asarray(pts_raw, dtype=np.float64).reshape(-1, 3)
+    n_pts = coords.shape[0]
+    try:
+        radii = nums(dataarray_text(section("PointData"), "MaximumInscribedSphereRadius"), _RE_F64, float)
+    except RuntimeError:
+        radii = []
+    if len(radii) != n_pts:
+        radii = [0.0] * n_pts
+    lines = section("Lines")
+    connectivity = nums(dataarray_text(lines, "connectivity"), _RE_U32, int)
+    offsets = nums(dataarray_text(lines, "offsets"), _RE_U32, int)
+    if not offsets:
+        raise RuntimeError("VTP: Lines section is empty (no branches)")
+    if offsets[-1] != len(connectivity):
+        raise RuntimeError(f"VTP: last offset ({offsets[-1]}) != connectivity length ({len(connectivity)})")
+    branches = [connectivity[a:b] for a, b in zip([0] + offsets[:-1], offsets)]
+    for br in branches:
+        for i in br:
+            if i >= n_pts:
+                raise RuntimeError(f"VTP: connectivity index {i} out of range ({n_pts} points)")
+
+    def arc_length(br):                                       # :383-393, sequential f64 sum
+        total = 0.0
+        for a, b in zip(br[:-1], br[1:]):
+            d = coords[b] - coords[a]
+            total += math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+        return total
+    lengths = [arc_length(br) for br in branches]
+    order = sorted(range(len(branches)), key=lambda k: -lengths[k])      # longest first (ties: file order)
+    out = np.zeros(len(connectivity), dtype=CL_DTYPE)
+    k = 0
+    for branch_id, vi in enumerate(order):
+        br = branches[vi]
+        for li, pi in enumerate(br):
+            x, y, z = coords[pi]
+            if li + 1 < len(br):
+                d = coords[br[li + 1]] - coords[pi]
+                nrm = math.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+                t = d / nrm if nrm > 1e-12 else np.zeros(3)
+            elif li > 0:
+                t = np.array([out["tx"][k - 1], out["ty"][k - 1], out["tz"][k - 1]])
+            else:
+                t = np.zeros(3)
+            out[k] = (x, y, z, t[0], t[1], t[2], radii[pi], branch_id, 0)
+            k += 1
+    return Centerline(out)
 
 
 def preprocess_centerline(centerline: Centerline, ref_mesh: G.FlatGeometry) -> Tuple[Centerline, float]:

@@ -245,3 +245,74 @@ def test_align_walls_native_equals_oracle_and_python(built, mm, ocl, oracle, cas
     again = mm.centerline.align_walls(plain, True)
     assert np.array_equal(again.extra, out.extra)
     assert np.array_equal(mm.centerline.align_walls(plain, False).extra, plain.extra)
+
+
+def test_read_centerline_vtp_rca(built, mm):                       # io/input.rs: test_read_centerline_vtp_rca
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "examples_centerlines", "rca_cl.vtp")
+    cl = mm.read_centerline_vtp(path)
+    starts = cl.branch_start_indices
+    assert len(starts) == 4 and len(cl) == 2652
+    assert starts[1] - starts[0] == 763                            # branch 0 = the longest VTK line by arc length
+    for i, s in enumerate(starts):
+        e = starts[i + 1] if i + 1 < len(starts) else len(cl)
+        assert (cl.points["branch_id"][s:e] == i).all()
+    assert (cl.points["radius"] > 0.0).any()
+    b0 = cl.points[starts[0]:starts[1]]
+    assert (np.sqrt(b0["tx"] ** 2 + b0["ty"] ** 2 + b0["tz"] ** 2) > 0.5).any()
+    # it feeds the placement like any other centerline: branch 0, descending z, resampled
+    g = mm.synthetic_pullback(12, 64, pullback_id=0)
+    mm.centerline.with_lumen_centroids(g)
+    rcl, spacing = mm.preprocess_centerline(cl, g)
+    assert len(rcl) > 20 and spacing > 0 and (rcl.points["branch_id"] == 0).all()
+    assert rcl.points["z"][0] >= rcl.points["z"][-1]
+
+
+def test_read_centerline_vtp_picks_longest_by_arc_length_not_point_count(built, mm, tmp_path):     # io/input.rs
+    a = [(i * 10.0, 0.0, 0.0) for i in range(5)]                   # 40 mm, 5 points
+    b = [(0.0, i * 0.1, 0.0) for i in range(20)]                   # 1.9 mm, 20 points
+    pts = a + b
+    n = len(pts)
+    xml = f"""<?xml version="1.0"?>
+<VTKFile type="PolyData" version="0.1" byte_order="LittleEndian" header_type="UInt32">
+  <PolyData>
+    <Piece NumberOfPoints="{n}" NumberOfVerts="0" NumberOfLines="2" NumberOfStrips="0" NumberOfPolys="0">
+      <PointData>
+        <DataArray type="Float64" Name="MaximumInscribedSphereRadius" format="ascii">
+          {" ".join(["1.0"] * n)}
+        </DataArray>
+      </PointData>
+      <Points>
+        <DataArray type="Float64" Name="Points" NumberOfComponents="3" format="ascii">
+          {" ".join(f"{x} {y} {z}" for x, y, z in pts)}
+        </DataArray>
+      </Points>
+      <Lines>
+        <DataArray type="Int64" Name="connectivity" format="ascii">
+          {" ".join(str(i) for i in range(n))}
+        </DataArray>
+        <DataArray type="Int64" Name="offsets" format="ascii">
+          {len(a)} {n}
+        </DataArray>
+      </Lines>
+    </Piece>
+  </PolyData>
+</VTKFile>
+"""
+    p = tmp_path / "arc.vtp"
+    p.write_text(xml)
+    cl = mm.read_centerline_vtp(str(p))
+    starts = cl.branch_start_indices
+    assert len(starts) == 2 and starts[1] - starts[0] == len(a)    # the longer (but sparser) line A is branch 0
+    assert cl.points["tx"][0] == 1.0 and cl.points["tx"][len(a) - 1] == 1.0        # last point repeats its predecessor's
+    # refusals (input.rs:269-294)
+    (tmp_path / "bin.vtp").write_bytes(b"<VTKFile>\x00\x01\x02")
+    with pytest.raises(RuntimeError, match="appears to be a binary VTP file"):
+        mm.read_centerline_vtp(str(tmp_path / "bin.vtp"))
+    (tmp_path / "app.vtp").write_text(xml.replace('Name="Points" NumberOfComponents="3" format="ascii"',
+                                                  'Name="Points" NumberOfComponents="3" format="appended"'))
+    with pytest.raises(RuntimeError, match="binary-encoded DataArrays detected"):
+        mm.read_centerline_vtp(str(tmp_path / "app.vtp"))
+    (tmp_path / "odd.vtp").write_text(xml.replace(f"{len(a)} {n}\n", f"{len(a)} {n - 1}\n"))
+    with pytest.raises(RuntimeError, match="last offset"):
+        mm.read_centerline_vtp(str(tmp_path / "odd.vtp"))
