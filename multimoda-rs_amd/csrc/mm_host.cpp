@@ -836,7 +836,9 @@ int64_t mm_filter_points_in_region(const double* xyz, int64_t n, const double* s
 int64_t mm_refine_downsample_count(int64_t n_filtered, int64_t n_points_per_frame, int64_t n_frames)
 {
     const double ratio = (double)n_filtered / ((double)n_points_per_frame * (double)n_frames);
-    int64_t n = (int64_t)std::ceil(ratio * (double)n_points_per_frame);
+    const double nd = std::ceil(ratio * (double)n_points_per_frame);
+    // Rust's `as usize` saturates: NaN (0/0 with no frames or no points) -> 0, +inf -> usize::MAX; then clamp(1, M)
+    int64_t n = !(nd > 0.0) ? 0 : (nd >= 9.2e18 ? INT64_MAX : (int64_t)nd);
     if (n < 1) n = 1;
     if (n > n_points_per_frame) n = n_points_per_frame;
     return n;

@@ -554,7 +554,7 @@ size_t orc_refine_downsample_count(size_t n_filtered, size_t n_points_per_frame,
 {
     double ratio = (double)n_filtered / ((double)n_points_per_frame * (double)n_frames); /* :415-416 */
     double nd = ceil(ratio * (double)n_points_per_frame);                                /* :417 */
-    size_t n = nd <= 0.0 ? 0 : (size_t)nd;
+    size_t n = !(nd > 0.0) ? 0 : (nd >= 1.8e19 ? (size_t)-1 : (size_t)nd);                /* `as usize` saturates (NaN -> 0) */
     if (n < 1) n = 1;                                                                    /* :418 clamp */
     if (n > n_points_per_frame) n = n_points_per_frame;
     return n;
