@@ -149,7 +149,10 @@ int64_t mm_refine_downsample_count(int64_t n_filtered, int64_t n_points_per_fram
 /* ---- candidate enumeration of search_range (process_utils.rs:43-67) ---------------- */
 /* Host-side, exact: writes up to `cap` wrapped angles, returns their count. When the
  * reference returns early (step <= 0, or stop <= start) *degenerate = 1 and
- * *early_value is the value it returns. has_center = 0 <=> center_angle = None. */
+ * *early_value is the value it returns. has_center = 0 <=> center_angle = None.  A list of more than 2^24
+ * candidates (a step far below the range; below the spacing of the doubles the reference would not terminate) is
+ * refused: MM_ERR_TOO_LARGE, here and in every search that enumerates its candidates from (step, range).
+ * mm_refine_angles likewise stops with MM_ERR_TOO_LARGE after 2^22 angles. */
 int64_t mm_search_angles(double step_deg, double range_deg, int has_center, double center,
                          double limes_deg, double* out, int64_t cap,
                          int* degenerate, double* early_value);

@@ -400,6 +400,8 @@ def search_angles(step_deg: float, range_deg: float, center: Optional[float] = N
     deg, early = C.c_int(0), C.c_double(0.0)
     hc, c = (0, 0.0) if center is None else (1, float(center))
     n = lib().mm_search_angles(step_deg, range_deg, hc, c, limes_deg, None, 0, C.byref(deg), C.byref(early))
+    if n < 0:
+        check(int(n), "search_angles")
     out = np.empty(int(n), dtype=np.float64)
     if n:
         lib().mm_search_angles(step_deg, range_deg, hc, c, limes_deg, _ptr(out), n, C.byref(deg), C.byref(early))
@@ -409,6 +411,8 @@ def search_angles(step_deg: float, range_deg: float, center: Optional[float] = N
 def refine_angles(initial: float, search_range: float, step: float) -> np.ndarray:
     """Accumulated angle enumeration of refine_alignment_hausdorff (align_algorithms.rs:386-439)."""
     n = lib().mm_refine_angles(initial, search_range, step, None, 0)
+    if n < 0:
+        check(int(n), "refine_angles")
     out = np.empty(int(n), dtype=np.float64)
     if n:
         lib().mm_refine_angles(initial, search_range, step, _ptr(out), n)

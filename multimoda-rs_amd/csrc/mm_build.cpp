@@ -211,6 +211,15 @@ int build_impl(const double* lumen4, int64_t n_lumen, const uint8_t* lumen_aorti
     if (!lumen4 || n_lumen <= 0 || !ref4) return set_error(MM_ERR_INVALID, "mm_build_geometry: lumen and reference point are required");
     if ((n_eem > 0 && !eem4) || (n_calc > 0 && !calc4) || (n_side > 0 && !side4) || n_eem < 0 || n_calc < 0 || n_side < 0)
         return set_error(MM_ERR_INVALID, "mm_build_geometry: bad extras arrays");
+    {   // ContourPoint.frame_index is a u32: anything else in column 0 is a caller error (and a UB cast below)
+        auto frames_ok = [](const double* rows, int64_t n) {
+            for (int64_t i = 0; i < n; ++i) { const double f = rows[4 * i]; if (!(f >= 0.0 && f <= 4294967295.0)) return false; }
+            return true;
+        };
+        if (!frames_ok(lumen4, n_lumen) || !frames_ok(ref4, 1) || (eem4 && !frames_ok(eem4, n_eem)) ||
+            (calc4 && !frames_ok(calc4, n_calc)) || (side4 && !frames_ok(side4, n_side)))
+            return set_error(MM_ERR_INVALID, "mm_build_geometry: frame index outside u32");
+    }
     const double* ext_rows[3] = {eem4, calc4, side4};
     const int64_t ext_n[3] = {eem4 ? n_eem : -1, calc4 ? n_calc : -1, side4 ? n_side : -1};   // -1: None
 

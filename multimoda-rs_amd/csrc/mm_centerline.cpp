@@ -583,7 +583,7 @@ int refine(Engine* e, mm_cl_geometry** geoms, const mm_clpoint* cl, int64_t ncl,
         if (grp.fx.empty()) continue;                                                          // :406-409 (every angle skipped)
         const double ratio = (double)grp.fx.size() / ((double)m * (double)F);                  // :415-418
         const double nd = std::ceil(ratio * (double)m);
-        int64_t n_down = nd <= 0.0 ? 0 : (int64_t)nd;
+        int64_t n_down = !(nd > 0.0) ? 0 : (nd >= 9.2e18 ? INT64_MAX : (int64_t)nd);          // `as usize` saturates
         n_down = std::max<int64_t>(1, std::min<int64_t>(n_down, m));
         grp.n_down = n_down;
         int64_t per_cand = 0;

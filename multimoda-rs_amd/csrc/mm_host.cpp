@@ -39,6 +39,15 @@ static inline double wrap_pi(double a)  // ((a + PI).rem_euclid(2 PI)) - PI, pro
     return r - kPi;
 }
 
+// set by enumerate_angles when a candidate list would exceed 2^24 entries; the entry points turn it into an error
+static thread_local bool tl_enum_overflow = false;
+static int enum_overflow_error()
+{
+    if (!tl_enum_overflow) return MM_OK;
+    tl_enum_overflow = false;
+    return set_error(MM_ERR_TOO_LARGE, "more than 2^24 candidates for one search (step far below the range)");
+}
+
 // process_utils.rs:43-67.  Returns false when the reference returns early (`early`).
 static bool enumerate_angles(double step_deg, double range_deg, bool has_center, double center_in,
                              double limes_deg, std::vector<double>& out, double& early)
@@ -53,7 +62,10 @@ static bool enumerate_angles(double step_deg, double range_deg, bool has_center,
     const double stop = std::fmin(center + range_rad, limes);
     if (stop <= start) { early = center; return false; }
     const double sf = std::ceil((stop - start) / step_rad);
-    size_t steps = sf <= 0.0 ? 0 : (size_t)sf;
+    // `as usize` saturates (NaN -> 0).  More than 2^24 candidates for ONE search (a step of 2e-5 degrees over +-180) is
+    // refused: the reference would allocate the list or, below the spacing of the doubles, never terminate
+    if (sf >= 16777216.0) { tl_enum_overflow = true; early = center; return false; }
+    size_t steps = !(sf > 0.0) ? 0 : (size_t)sf;
     steps = std::max<size_t>(steps, 1);
     out.reserve(steps + 1);
     for (size_t i = 0; i <= steps; ++i) {
@@ -149,7 +161,8 @@ static SampleSpec sample_spec(const mm_geometry* g, int64_t sample_size)
     if (g->has_catheter && g->cath_off) {
         const int64_t c0 = g->cath_off[1] - g->cath_off[0];
         s.has_cath = true;
-        s.cath = (int64_t)std::ceil((double)c0 * ratio);
+        const double cs = std::ceil((double)c0 * ratio);                 // finite: len0 > 0 is checked by every caller
+        s.cath = !(cs > 0.0) ? 0 : (cs >= 9.2e18 ? INT64_MAX : (int64_t)cs);
     }
     return s;
 }
@@ -199,6 +212,7 @@ static int run_searches(Engine* e, std::vector<SearchJob>& jobs, double step_deg
             double early = 0.0;
             const bool ok = enumerate_angles(levels[l].step, levels[l].range, l > 0, centre[j], range_deg,
                                              lists[j], early);
+            if (int erc = enum_overflow_error()) return erc;
             if (!ok) { centre[j] = early; continue; }  // search_range returned early
             active.push_back(j);
         }
@@ -437,6 +451,7 @@ int WithinPlan::prepare()
     }
     levels = search_levels(step_deg, range_deg, bruteforce);
     level0_ok = enumerate_angles(levels[0].step, levels[0].range, false, 0.0, range_deg, level0, level0_early);
+    if (int erc = enum_overflow_error()) return erc;
 
     // centred search sets of the ORIGINAL frames + per-geometry rounding scale
     set_base.assign(n_geoms + 1, 0); job_base.assign(n_geoms + 1, 0);
@@ -481,7 +496,8 @@ void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centres,
             lp = level0.data(); ln = (int32_t)level0.size();
         } else {
             double early = 0.0;
-            if (!enumerate_angles(levels[l].step, levels[l].range, true, centres[j], range_deg, lists[j], early)) {
+            const bool ok = enumerate_angles(levels[l].step, levels[l].range, true, centres[j], range_deg, lists[j], early);
+            if (!ok) {                              // (an overflow leaves tl_enum_overflow set: the callers check it)
                 if (centre_out) (*centre_out)[j] = early;
                 continue;
             }
@@ -510,6 +526,7 @@ int WithinPlan::level_launch(size_t l)
     if (!(l == 0 && level0_staged)) {
         TraceTimer t("within: stage level");
         build_level_pairs(l, centre, resolved, lvl_pairs, lvl_active, &centre);
+        if ((rc = enum_overflow_error())) return rc;
         if (lvl_active.empty()) return MM_OK;
         if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
     }
@@ -793,6 +810,7 @@ int64_t mm_search_angles(double step_deg, double range_deg, int has_center, doub
     std::vector<double> v;
     double early = 0.0;
     const bool ok = enumerate_angles(step_deg, range_deg, has_center != 0, center, limes_deg, v, early);
+    if (int erc = enum_overflow_error()) return erc;
     if (degenerate) *degenerate = ok ? 0 : 1;
     if (early_value) *early_value = ok ? 0.0 : early;
     if (out) for (int64_t i = 0; i < (int64_t)v.size() && i < cap; ++i) out[i] = v[(size_t)i];
@@ -809,6 +827,9 @@ int64_t mm_refine_angles(double initial, double range, double step, double* out,
         if (out && n < cap) out[n] = angle;
         ++n;
         angle += step;
+        // a step below the spacing of the doubles at `angle` never advances (the reference would not terminate), and a
+        // grid of more than 2^22 angles is refused by the refinement anyway
+        if (n > ((int64_t)1 << 22)) return set_error(MM_ERR_TOO_LARGE, "mm_refine_angles: more than 2^22 angles");
     }
     return n;
 }
@@ -984,7 +1005,8 @@ static void between_points(const mm_geometry* g, int64_t sample_size, std::vecto
     const double ratio = (double)sample_size / (double)total;
     for (int32_t i = 0; i < g->n_frames; ++i) {
         const int64_t len = g->lumen_off[i + 1] - g->lumen_off[i];
-        int64_t fs = (int64_t)std::ceil((double)len * ratio);
+        const double fd = std::ceil((double)len * ratio);
+        int64_t fs = !(fd > 0.0) ? 0 : (fd >= 9.2e18 ? INT64_MAX : (int64_t)fd);
         fs = std::max<int64_t>(fs, 1);
         downsample_append(g->lumen + 3 * g->lumen_off[i], len, fs, x, y);
     }

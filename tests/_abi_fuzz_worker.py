@@ -1,5 +1,5 @@
 """Worker of tests/test_abi_null_args.py: calls every function the headers declare with NULL pointers and small / zero
-scalars, one after the other from index `start`, printing the name BEFORE each call -- so that the parent sees which
+scalars (ones, zeros, NaN, huge / negative values), one after the other from index `start`, printing the name BEFORE each call -- so that the parent sees which
 call took the process down, if one does.  mode "engine": a live engine handle goes into every `mm_engine*` first
 argument, so the validation BEHIND the engine check is what runs.  A bad argument must come back as a negative status
 (or a harmless value), never as a fault."""
@@ -36,18 +36,23 @@ def main():
     eng = mm.Engine() if mode == "engine" else None
     names = functions()
     with_engine = engine_first() if eng is not None else set()
-    for k in range(start, 2 * len(names)):
-        name, variant = names[k % len(names)], k // len(names)          # variant 0: scalars = 1, variant 1: scalars = 0
+    VARIANTS = [(1, 1.0), (0, 0.0), (1, float("nan")), (-1, 1e300), (1, -1e-300), (3, 1e-300), (2, float("inf"))]     # (integers, floats)
+    for k in range(start, len(VARIANTS) * len(names)):
+        name, variant = names[k % len(names)], k // len(names)
         f = getattr(L, name)
         args = []
         for j, t in enumerate(f.argtypes):
             is_ptr = t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents")
             if is_ptr:
                 args.append(eng.handle if (j == 0 and name in with_engine) else None)
+            elif t is C.c_char:
+                args.append(b",")
             elif t in (C.c_double, C.c_float):
-                args.append(1.0 if variant == 0 else 0.0)
+                args.append(VARIANTS[variant][1])
+            elif t in (C.c_uint32, C.c_uint64, C.c_uint8, C.c_size_t):
+                args.append(abs(VARIANTS[variant][0]))
             else:
-                args.append(1 if variant == 0 else 0)
+                args.append(VARIANTS[variant][0])
         print(f"CALL {k} {name}", flush=True)
         f(*args)
     print("DONE", flush=True)

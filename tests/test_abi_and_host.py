@@ -146,3 +146,20 @@ def test_rotation_uses_one_sincos_call(built, mm, oracle):
         p = base.frame_lumen(i + 1)
         ex = (p[:, 0] - cx) * co - (p[:, 1] - cy) * si + cx
         assert np.array_equal(g.frame_lumen(i + 1)[:, 0], ex)
+
+
+def test_enumerations_terminate_on_steps_that_never_advance(built, mm):
+    """A step below the spacing of the doubles it is added to never advances; the reference's loops would not
+    terminate (`while angle <= ..{ angle += step }`, align_algorithms.rs:386-439; search_range's take_while). Here the
+    refine enumeration fails after 2^22 angles and a candidate list of more than 2^24 entries is refused before it
+    is allocated."""
+    with pytest.raises(RuntimeError, match="more than 2\\^22 angles"):
+        mm.refine_angles(0.0, 1.0, 1e-300)
+    L = mm._native.lib()
+    deg, early = C.c_int(0), C.c_double(0.0)
+    n = L.mm_search_angles(1e-300, 1.0, 1, 1.0, 180.0, None, 0, C.byref(deg), C.byref(early))   # centre 1: start + i*step == start
+    assert n == -3 and b"2^24 candidates" in L.mm_last_error()               # MM_ERR_TOO_LARGE
+    with pytest.raises(RuntimeError, match="2\\^24 candidates"):
+        mm.search_angles(1e-300, 1.0, center=1.0, limes_deg=180.0)
+    assert len(mm.search_angles(0.0001, 180.0)[0]) == 3600001                # a fine but finite grid still enumerates
+    assert mm.refine_downsample_count(10, 0, 0) == 0 and mm.refine_downsample_count(0, 5, 0) == 1   # NaN / inf saturate like `as usize`
