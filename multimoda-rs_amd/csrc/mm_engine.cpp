@@ -189,13 +189,15 @@ int Plan::stage_sets(Engine* e, const std::vector<SetRef>& sets, bool transient_
         const SetRef& r = sets[s];
         const int32_t o = set_off[s];
         double rho2 = 0.0;
+        bool bad = false;   // NaN / inf / overflowing coordinates: no f32 screen can bound them (rho = inf -> stage_level)
         for (int32_t i = 0; i < r.n; ++i) {
             const double dx = r.x[i] - r.cx, dy = r.y[i] - r.cy;
             x64[o + i] = r.x[i]; y64[o + i] = r.y[i];
             x32[o + i] = (float)dx; y32[o + i] = (float)dy;
-            rho2 = std::max(rho2, dx * dx + dy * dy);
+            const double r2 = dx * dx + dy * dy;
+            if (r2 <= 1.0e300) rho2 = std::max(rho2, r2); else bad = true;
         }
-        set_rho[s] = std::sqrt(rho2) * (1.0 + 1e-12);
+        set_rho[s] = bad ? INFINITY : std::sqrt(rho2) * (1.0 + 1e-12);
     }
     if (pts_bytes) MM_HIP(upload(pts_blob, h, pts_bytes, transient, st));
     if (!transient) MM_HIP(hipStreamSynchronize(st));
@@ -234,6 +236,16 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         precision != MM_PRECISION_F32_BOUNDED)
         return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64, MM_PRECISION_F32, MM_PRECISION_F32_FAST or "
                                          "MM_PRECISION_F32_BOUNDED");
+    // Non-finite (or overflowing) coordinates: the reference's metric skips the points whose distances are not finite
+    // (process_utils.rs:112-114) and carries on.  The exact kernels do the same; a screen cannot bound such values, so
+    // every candidate of this level is scored exactly.  (rho = inf marks such a set, see stage_sets / k_build_sets.)
+    if (precision != MM_PRECISION_F64)
+        for (const PairSpec& sp : pairs)
+            if (sp.ref_set >= 0 && sp.tgt_set >= 0 && (size_t)sp.ref_set < set_rho.size() && (size_t)sp.tgt_set < set_rho.size() &&
+                (!(set_rho[sp.ref_set] < 1.0e150) || !(set_rho[sp.tgt_set] < 1.0e150) || !std::isfinite(sp.cx) || !std::isfinite(sp.cy))) {
+                precision = MM_PRECISION_F64;
+                break;
+            }
     const bool expanded = precision == MM_PRECISION_F32_FAST || precision == MM_PRECISION_F32_BOUNDED;
     if (angle_begin < 0) angle_begin = 0;
 

@@ -324,16 +324,18 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const T v = lane_min16(rmin[r]);
-                    rowmax = v > rowmax ? v : rowmax;
+                    // process_utils.rs:112-114: `if min_sq.is_finite() && min_sq > local_max_sq` -- a point whose
+                    // distances are all inf / NaN (non-finite coordinates) does not take part in the maximum
+                    rowmax = (v > rowmax && v < TT::inf()) ? v : rowmax;
                 }
             }
             __syncthreads();  // S2: all column minima are in LDS
 
-            // directed(B,A): max over valid columns of the column minima
+            // directed(B,A): max over valid columns of the (finite) column minima
             T m = rowmax;
             for (int j = tid; j < nb; j += NT) {
                 const T v = TT::from(s_colmin[j]);
-                m = (v > m) ? v : m;
+                m = (v > m && v < TT::inf()) ? v : m;
             }
             m = wave_max(m);
             if ((tid & 63) == 0) atomicMax(&s_red[0], TT::bits(m));
@@ -1060,7 +1062,7 @@ k_hausdorff_large(const LargePair* __restrict__ pairs, const LargeWork* __restri
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const double v = lane_min16(rmin[r]);
-        rowmax = v > rowmax ? v : rowmax;
+        rowmax = (v > rowmax && v < __longlong_as_double(0x7ff0000000000000ll)) ? v : rowmax;   // finite minima only (:112-114)
     }
     rowmax = wave_max(rowmax);
     if ((tid & 63) == 0) atomicMax(&s_red, (unsigned long long)__double_as_longlong(rowmax));
@@ -1085,7 +1087,10 @@ k_large_finish(const LargePair* __restrict__ pairs, const unsigned long long* __
     if (tid == 0) s_red = g_rowmax[p];
     __syncthreads();
     unsigned long long m = 0ull;
-    for (int j = tid; j < pd.nb; j += 256) { const unsigned long long v = g_colmin[pd.col_off + j]; m = v > m ? v : m; }
+    for (int j = tid; j < pd.nb; j += 256) {
+        const unsigned long long v = g_colmin[pd.col_off + j];
+        m = (v > m && v < 0x7ff0000000000000ull) ? v : m;                   // finite minima only (:112-114)
+    }
     atomicMax(&s_red, m);
     __syncthreads();
     if (tid == 0) out[p] = sqrt(__longlong_as_double((long long)s_red));   // process_utils.rs:120, :81
@@ -1426,8 +1431,9 @@ k_build_sets(const SetSrc* __restrict__ src, const double* __restrict__ raw, flo
         scale = fmax(scale, fmax(fabs(x), fabs(y)));
         p64x[s.dst_off + k] = x; p64y[s.dst_off + k] = y;
         p32x[s.dst_off + k] = (float)x; p32y[s.dst_off + k] = (float)y;
-        rho2 = fmax(rho2, x * x + y * y);
-    }
+        const double r2 = x * x + y * y;
+        rho2 = (r2 <= 1.0e300) ? fmax(rho2, r2) : __longlong_as_double(0x7ff0000000000000ll);   // NaN / inf / overflow:
+    }                                                                                             // rho = inf tells the host
     rho2 = wave_max(rho2); scale = wave_max(scale);
     if ((tid & 63) == 0) { s_rho[tid >> 6] = rho2; s_scale[tid >> 6] = scale; }
     __syncthreads();

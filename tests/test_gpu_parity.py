@@ -132,6 +132,33 @@ def test_point_sets_far_smaller_than_their_coordinates(engine, oracle, mm):
             assert bi == int(np.argmin(oc)) and ba == angles[bi] and bc == oc[bi], prec
 
 
+@pytest.mark.parametrize("n", [200, 521, 1200])
+def test_non_finite_coordinates_follow_the_reference(engine, oracle, mm, n):
+    """process_utils.rs:103-114: `if d2 < min_sq` never selects a NaN, and `if min_sq.is_finite() && min_sq > local_max`
+    leaves a point out whose distances are all inf / NaN -- so with NaN, inf or overflowing coordinates the reference
+    still returns a finite distance (0.0 if nothing is left) and a winner (the first candidate if all costs tie at 0).
+    The exact kernels apply the same filter; a set with such coordinates makes its level skip the f32 screens (they
+    cannot bound non-finite values) and score every candidate exactly.  Metric and search at all four precisions
+    against the oracle."""
+    rng = np.random.default_rng(n)
+    ref, tgt = blob(rng, n), blob(rng, n)
+    angles, _, _ = mm.search_angles(1.0, 30.0)
+    c = tgt.mean(axis=0)
+    centre = (float(c[0]), float(c[1]))
+    idx = np.arange(n)[:, None]
+    cases = [(ref, np.where(idx == 7, np.nan, tgt)), (np.where(idx == 3, np.inf, ref), tgt),
+             (np.where(idx % 50 == 3, np.inf, ref), np.where(idx % 40 == 7, np.nan, tgt)),
+             (ref * np.nan, tgt * np.nan), (ref * 1e200, tgt * 1e200), (ref, np.where(idx == 0, -np.inf, tgt))]
+    for r, t in cases:
+        assert engine.hausdorff(r, t) == oracle.hausdorff(r, t)
+        o_angle = oracle.bruteforce_rotation(r, t, 1.0, 30.0, centre[0], centre[1], n_threads=8)
+        o_cost = oracle.cost_within(r, t, o_angle, centre[0], centre[1])
+        assert math.isfinite(o_cost)
+        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+            bi, ba, bc = engine.best_rotation(r, t, angles, centre, skip_zero=True, precision=prec)
+            assert bi >= 0 and ba == o_angle and bc == o_cost, prec
+
+
 def test_all_candidates_tie_circle(engine, oracle, mm):
     """A perfectly symmetric target: costs tie to within rounding; the f32 screen must hand
     every near-tie to the exact re-score and still return the reference's first minimum."""
