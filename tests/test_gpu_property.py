@@ -35,6 +35,11 @@ def shape(rng, kind, n):
         return np.stack([4.5 + s, 4.5 + 0.5 * s], 1)
     if kind == "point":                          # every point the same: all exact costs are 0.0, the first candidate wins
         return np.tile(rng.normal(4.5, 1.0, size=(1, 2)), (n, 1))
+    if kind == "holes":                          # a contour with a few NaN / inf coordinates: the metric skips those points
+        p = shape(rng, "blob", n)
+        bad = rng.integers(0, n, size=max(1, n // 50))
+        p[bad, rng.integers(0, 2, size=bad.size)] = rng.choice([np.nan, np.inf, -np.inf], size=bad.size)
+        return p
     if kind == "speck":                          # a cloud of a few ulps / of 1e-9 around a far point
         return rng.normal(4.5, 1.0, size=(1, 2)) + rng.normal(0, float(rng.choice([4e-16, 1e-12, 1e-9])), size=(n, 2))
     raise AssertionError(kind)
@@ -43,17 +48,24 @@ def shape(rng, kind, n):
 @settings(max_examples=150 * int(os.environ.get("MM_HYP_SCALE", "1")), deadline=None, derandomize=True, database=None,
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(seed=st.integers(0, 2**31 - 1), na=st.sampled_from(SIZES), nb=st.sampled_from(SIZES),
-       kind_a=st.sampled_from(["blob", "circle", "regular", "ellipse2", "dups", "line", "point", "speck"]),
+       kind_a=st.sampled_from(["blob", "circle", "regular", "ellipse2", "dups", "line", "point", "speck", "holes"]),
        same=st.booleans(), step=st.sampled_from([0.5, 1.0, 2.5, 7.0]), rng_deg=st.sampled_from([3.0, 45.0, 90.0, 180.0]),
        twist=st.sampled_from([0.0, 7.3, 90.0, 180.0, -33.0]))
 def test_one_search_all_precisions_match_the_oracle(engine, oracle, mm, seed, na, nb, kind_a, same, step, rng_deg, twist):
     rng = np.random.default_rng(seed)
     ref = shape(rng, kind_a, na)
-    c = ref.mean(axis=0)
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = np.nanmean(np.where(np.isfinite(ref), ref, np.nan), axis=0) if kind_a == "holes" else ref.mean(axis=0)
+    if not np.all(np.isfinite(c)):
+        c = np.array([4.5, 4.5])
     if same and na == nb:                         # the target is the reference turned by `twist` (exactly at 0 / 180)
         th = math.radians(twist)
         rot = np.array([[math.cos(th), math.sin(th)], [-math.sin(th), math.cos(th)]])
-        tgt = ref.copy() if twist == 0.0 else (2 * c - ref if twist == 180.0 else (ref - c) @ rot + c)
+        with np.errstate(all="ignore"):
+            tgt = ref.copy() if twist == 0.0 else (2 * c - ref if twist == 180.0 else (ref - c) @ rot + c)
     else:
         tgt = shape(rng, str(rng.choice(["blob", "circle", "dups"])), nb) if kind_a not in ("point", "speck") else \
             ref[rng.integers(0, na, nb)] + rng.normal(0, float(rng.choice([0.0, 4e-16, 1e-10])), size=(nb, 2))
