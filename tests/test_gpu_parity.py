@@ -159,6 +159,21 @@ def test_non_finite_coordinates_follow_the_reference(engine, oracle, mm, n):
             assert bi >= 0 and ba == o_angle and bc == o_cost, prec
 
 
+@pytest.mark.parametrize("what", [np.nan, np.inf])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_chain_with_non_finite_points_equals_the_oracle_chain(engine, oracle, mm, mode, what):
+    """A pullback with a few NaN / inf lumen coordinates: the chain (faithful and decoupled, every precision) gives the
+    oracle chain's logs and coordinates -- NaNs at the same places."""
+    for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+        g = mm.synthetic_pullback(8, 120, pullback_id=1, seed=5)
+        g.lumen[g.lumen_off[3] + 18, 0] = what
+        g.lumen[g.lumen_off[5] + 2, 1] = -what
+        og = to_oracle(oracle, g)
+        logs, _ = mm.align_within(engine, [g], 1.0, 30.0, True, 100, precision=prec, mode=mode)
+        assert logs[0] == oracle.align_within_chain(og, 1.0, 30.0, True, 100, n_threads=8)
+        assert geoms_equal(g, og)
+
+
 def test_all_candidates_tie_circle(engine, oracle, mm):
     """A perfectly symmetric target: costs tie to within rounding; the f32 screen must hand
     every near-tie to the exact re-score and still return the reference's first minimum."""
