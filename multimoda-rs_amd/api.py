@@ -447,8 +447,13 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
     a, b, c, d = geoms
     G.align_between(eng, [(a, b), (c, d)], rng, step, sample_size)                 # entry.rs:206-240
     b.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True         # moved last by a translation
-    pair_ab = _make_pair(a.copy(), b.copy())
-    pair_cd = _make_pair(c.copy(), d.copy())
+    # The reference clones the geometries into every pair.  With the native post-processing each pair's geometries are
+    # rebuilt from (and never written through) the ones handed in, so a, b -- final after the first batch -- and the
+    # final c, d can be handed in as they are; only the state of c and d BEFORE the second batch needs a snapshot.
+    share = postprocessing and not os.environ.get("MM_PY_POSTPROC")
+    keep = (lambda g: g) if share else (lambda g: g.copy())
+    pair_ab = _make_pair(keep(a), keep(b))
+    pair_cd = _make_pair(keep(c), keep(d)) if not both_batches else _make_pair(c.copy(), d.copy())
     def post_all(pairs):
         # the pairs are independent (maybe_postprocess x4, entry.rs:282-290); the native post-processing releases
         # the interpreter lock
@@ -462,8 +467,8 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
         return (*post_all([pair_ab, pair_cd]), tuple(logs))
     G.align_between(eng, [(a, c), (b, d)], rng, step, sample_size)                 # entry.rs:243-277
     c.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True
-    pair_ac = _make_pair(a.copy(), c.copy())
-    pair_bd = _make_pair(b.copy(), d.copy())
+    pair_ac = _make_pair(keep(a), keep(c))
+    pair_bd = _make_pair(keep(b), keep(d))
     return (*post_all([pair_ab, pair_cd, pair_ac, pair_bd]), tuple(logs))
 
 
