@@ -356,6 +356,15 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # stdout carries ONE line, the JSON: whatever libraries write to file descriptor 1 meanwhile (RCCL prints a version
+    # banner there when a communicator is created) goes to stderr; the JSON is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
 
@@ -490,7 +499,7 @@ def main():
         ms = main_leg["dt"] / args.steps * 1e3
         kms, kpe = main_leg["prof"][0], main_leg["prof"][1]
         big = kpe >= 0.5 * kpe.max() if len(kpe) else np.zeros(0, bool)
-        print(json.dumps({"rehearsal": f"rank 0 of {rehearse} without peers (MM_BENCH_REHEARSE_WORLD): timing only, NOT an alignment",
+        emit(({"rehearsal": f"rank 0 of {rehearse} without peers (MM_BENCH_REHEARSE_WORLD): timing only, NOT an alignment",
                           "per_rank_ms_per_step": ms, "steps": args.steps,
                           "dominant_launch_ms": float(kms[big].mean()) if len(kms) else None,
                           "stage_ms_per_case": main_leg["stage_ms"],
@@ -678,7 +687,7 @@ def main():
                                                       for g, o in zip(last, og))),
                 "oracle_seconds": time.perf_counter() - t0c, "oracle_threads": threads,
             }
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         # every rank must have produced the same alignment (reduced winners -> identical host walk)
         import hashlib
