@@ -254,9 +254,11 @@ class Runner:
     device, level 0 staged), search(k) (all levels: local search -> exchange -> commit) and finish(k) (chain walk,
     AB|CD and AC|BD between alignments).  Step k lives on engine k % len(engs) and works on its own copy of the case."""
 
-    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases, rehearse=0):
+    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases, rehearse=0, grid=None, comm=None):
         self.mm, self.engs, self.cfg, self.prec, self.mode, self.rank, self.world, self.ext = mm, engs, cfg, prec, mode, rank, world, ext
         self.rehearse = rehearse           # > 1: this process plays rank 0 of `rehearse` ranks without peers (timing only)
+        self.grid = grid                   # (pair_blocks, cand_slices) of the shard grid (N > 1 / rehearsal)
+        self.comm = comm                   # rehearsal: the library's world = 1 RCCL communicator (None: torch's)
         # the caller's input data: one fresh copy of the case per step (made before the timed region -- this is
         # the data a caller hands over, not work of the step)
         self.cases = [base if ext is not None else [g.copy() for g in base] for _ in range(n_cases)]
@@ -276,13 +278,13 @@ class Runner:
         t0 = time.perf_counter()
         self.plans[k] = mm.WithinPlan(self.engs[k % len(self.engs)], self.cases[k], cfg["step_deg"], cfg["range_deg"], True,
                                       cfg["sample_size"], precision=self.prec,
-                                      shard=(self.rank, self.world) if self.world > 1 else
-                                      ((0, self.rehearse) if self.rehearse > 1 else None))
+                                      shard=(self.rank, *self.grid) if self.world > 1 else
+                                      ((0, *self.grid) if self.rehearse > 1 else None))
         self.stage_s += time.perf_counter() - t0
         self.staged += 1
 
     def begin(self, k, prev):
-        """world == 1: enqueue step k's search behind step prev's long kernel (Engine.wait_search) and return."""
+        """Enqueue step k's level-0 launch behind step prev's long kernel (Engine.wait_search) and return."""
         if self.plans[k] is not None and self.ext is None:
             self.plans[k].search_begin(after=None if prev is None else self.engs[prev % len(self.engs)])
 
@@ -291,8 +293,11 @@ class Runner:
             if getattr(self.plans[k], "_begun", False) and self.world == 1 and self.rehearse <= 1:
                 self.plans[k].search_end()               # collect level 0, remaining levels, commit
             elif self.rehearse > 1:
-                from multimoda_rs_amd import distributed as D
-                D.search_device(self.plans[k])           # the N > 1 code path over a world = 1 RCCL group
+                if self.comm is not None:
+                    self.plans[k].search_sharded(self.comm)  # the N > 1 code path over the library's world = 1 communicator
+                else:
+                    from multimoda_rs_amd import distributed as D
+                    D.search_device(self.plans[k])       # the same through torch's world = 1 RCCL group (the checker)
             else:
                 self.plans[k].search()                   # levels: local search -> exchange -> commit
 
@@ -391,12 +396,17 @@ def main():
     # group).  The result is not an alignment (only 1/N of the candidates are seen); what it measures is the
     # per-rank step time of an N-GPU run short of the xGMI latency of two small all-reduces.  Never a bench line.
     rehearse = int(os.environ.get("MM_BENCH_REHEARSE_WORLD", "0"))
+    rehearse_comm = None
     if rehearse > 1:
         if world != 1:
             raise SystemExit("MM_BENCH_REHEARSE_WORLD is a single-process rehearsal")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("MM_EXCHANGE", "rccl") == "rccl":
+            os.environ["MM_SHARD_REHEARSAL"] = "1"      # the library lets a world = 1 communicator serve a rank of a larger job
+            rehearse_comm = mm.Comm(mm.Comm.unique_id(), 0, 1, local_rank)   # the library's own communicator
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     cfg = WORKLOADS[args.workload]
     mode = 0 if args.mode == "chain" else 1
@@ -404,6 +414,12 @@ def main():
              "f64": mm.MM_PRECISION_F64}
     PREC = PRECS[args.precision]
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
+    # N > 1: the (frame pair x candidate) grid is cut into pair_blocks x cand_slices tiles, one per rank
+    # (multimoda_rs_amd.distributed.shard_grid: frame pairs first, the candidate axis when the pairs are few;
+    # MM_SHARD_GRID=PxC overrides, 1xN = the pure candidate-axis split)
+    from multimoda_rs_amd import distributed as D
+    n_jobs = sum(g.n_frames - 1 for g in base)
+    grid = D.shard_grid(max(world, rehearse, 1), n_jobs)
     # three engines (main stream, side stream, staging buffers each): step k lives on engine k % 3, so the search of
     # step k+1, the finish of step k and the staging of step k+3 (which takes over step k's engine once that is
     # finished) never share one, and each of the three has a host thread of its own
@@ -456,7 +472,7 @@ def main():
         resident: every case is staged before the timed region (inputs and search sets resident in HBM when it
         starts); the region then holds K searches and K finishes only."""
         n_total = warmup + steps
-        r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK, rehearse)
+        r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK, rehearse, grid, rehearse_comm)
         for k in range(n_total if resident else LOOK):
             r.stage(k)                                   # priming (setup, untimed)
         stage_fn = None if resident else r.stage
@@ -493,6 +509,45 @@ def main():
         for e in engs:
             between_stage(mm, e, [g.copy() for g in base], cfg, PREC)
 
+    # N > 1, first thing: one case through every exchange -- the library's own RCCL communicator (the default on an
+    # nccl group), torch's all-reduces on the same device records, and the host gather + mm_merge_shards -- all three
+    # must give the same alignment on this rank (the digest below compares the ranks).  If the library's communicator
+    # cannot be set up the run goes on over torch's (said in the JSON line), it does not stop.
+    exchange_note = None
+    if world > 1:
+        def one_case(mode_):
+            os.environ["MM_EXCHANGE"] = mode_
+            case = [g.copy() for g in base]
+            pl = mm.WithinPlan(engs[0], case, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"], precision=PREC,
+                               shard=(rank, *grid))
+            pl.search()
+            logs_, ev_, un_ = pl.walk()
+            pl.close()
+            return [list(l) for l in logs_], ev_, un_
+        chosen = os.environ.get("MM_EXCHANGE", "") or D.exchange_mode()
+        modes = ["gather", "device"] + (["rccl"] if chosen == "rccl" else [])
+        got = {}
+        for m in modes:
+            try:
+                got[m] = one_case(m)
+            except Exception as ex:
+                if m != "rccl":
+                    raise
+                # every rank must take the same decision: any rank's failure sends all ranks to torch's exchange
+                got[m] = None
+                exchange_note = f"library RCCL communicator unavailable ({type(ex).__name__}: {ex}); torch.distributed all-reduces used"
+        flag = torch.tensor([0 if got.get("rccl", 1) is not None else 1], dtype=torch.int32,
+                            device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and chosen == "rccl":
+            chosen = "device"
+            exchange_note = exchange_note or "library RCCL communicator unavailable on another rank; torch.distributed all-reduces used"
+        ref_ = got["gather"]
+        for m, v in got.items():
+            if v is not None and v != ref_:
+                raise SystemExit(f"exchange '{m}' and exchange 'gather' disagree on rank {rank}")
+        os.environ["MM_EXCHANGE"] = chosen
+
     main_leg = timed_leg(PREC, args.warmup, args.steps, pipelined)
     if rehearse > 1:
         full = cfg["frames"] and sum(g.n_frames - 1 for g in base) * len(mm.search_angles(cfg["step_deg"], cfg["range_deg"])[0])
@@ -500,6 +555,8 @@ def main():
         kms, kpe = main_leg["prof"][0], main_leg["prof"][1]
         big = kpe >= 0.5 * kpe.max() if len(kpe) else np.zeros(0, bool)
         emit(({"rehearsal": f"rank 0 of {rehearse} without peers (MM_BENCH_REHEARSE_WORLD): timing only, NOT an alignment",
+                          "shard_grid": {"pair_blocks": grid[0], "cand_slices": grid[1]},
+                          "exchange": "library RCCL communicator (world = 1)" if rehearse_comm is not None else "torch.distributed (world = 1)",
                           "per_rank_ms_per_step": ms, "steps": args.steps,
                           "dominant_launch_ms": float(kms[big].mean()) if len(kms) else None,
                           "stage_ms_per_case": main_leg["stage_ms"],
@@ -507,7 +564,10 @@ def main():
                           "projected_pose_evals_per_s": full / (ms * 1e-3),
                           "note": "projected = the full grid's within pose-evals / this rank's step time: what N such ranks "
                                   "deliver if the two all-reduces cost what they cost at world = 1"}))
-        dist.destroy_process_group()
+        if rehearse_comm is not None:
+            rehearse_comm.close()
+        else:
+            dist.destroy_process_group()
         for e in engs:
             e.close()
         return
@@ -620,9 +680,15 @@ def main():
                                           "the whole step (faithful chain: sets built and uploaded per chain step)"),
                        "staged_cases_in_timed_region": main_leg["staged"], "stage_ms_per_case": main_leg["stage_ms"],
                        "all_timed_steps_identical": steps_identical,
-                       "parallelism": f"candidate-axis x{world}" if world > 1 else "single GPU",
-                       "exchange": (os.environ.get("MM_EXCHANGE", "device") + (" (2 all-reduces per level on device records)"
-                                    if os.environ.get("MM_EXCHANGE", "device") == "device" else "")) if world > 1 else None,
+                       "parallelism": (f"(frame pair x candidate) grid in {grid[0]} x {grid[1]} tiles, one per GPU" if world > 1
+                                       else "single GPU"),
+                       "shard_grid": {"pair_blocks": grid[0], "cand_slices": grid[1]} if world > 1 else None,
+                       "exchange": ({"rccl": "ncclAllReduce(MIN) x 2 per level on device records, issued by the library on its own "
+                                             "RCCL communicator (mm_within_plan_search_sharded)",
+                                     "device": "2 all-reduces(MIN) per level on device records through torch.distributed",
+                                     "gather": "host all_gather + mm_merge_shards"}[os.environ.get("MM_EXCHANGE", "device")]
+                                    + (f"; NOTE: {exchange_note}" if exchange_note else "")
+                                    + "; checked at start-up: rccl / device / gather exchanges give the same alignment") if world > 1 else None,
                        "step_pipeline": ((f"3 pieces per step over consecutive (independent) cases, one host thread and one engine "
                                           f"each: search of step k+1 || chain walk + between alignment of step k || staging of step "
                                           f"k+3 (engine k % {LOOK})" if STAGER else
@@ -699,6 +765,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
             raise SystemExit("ranks disagree on the alignment result")
+        D.close_native_comms()
         dist.destroy_process_group()
     for e in engs:
         e.close()

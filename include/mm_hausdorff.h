@@ -42,8 +42,9 @@ typedef enum {
     MM_ERR_SAMPLE_SIZE  = -6,  /* "sample_size must be > 0"          (align_within.rs:38-40) */
     MM_ERR_HIP          = -7,
     MM_ERR_REF_INDEX    = -8,  /* reference-frame index out of range (Rust would panic)      */
-    MM_ERR_INTEGRITY    = -9   /* a check of check_geometry_integrity failed (integrity_check.rs:8-33);
+    MM_ERR_INTEGRITY    = -9,  /* a check of check_geometry_integrity failed (integrity_check.rs:8-33);
                                   mm_last_error() holds the reference's message                */
+    MM_ERR_COMM         = -10  /* RCCL could not be loaded, or a collective / communicator call failed */
 } mm_status;
 
 /* precision of the candidate scoring */
@@ -344,6 +345,53 @@ int  mm_within_plan_level_launch(mm_within_plan* p, int level);
 int  mm_within_plan_level_export_cost(mm_within_plan* p, int level, double* cost_dev);
 int  mm_within_plan_level_export_keys(mm_within_plan* p, int level, const double* gcost_dev, int64_t* keys_dev);
 int  mm_within_plan_level_commit_dev(mm_within_plan* p, int level, const double* gcost_dev, const int64_t* keys_dev);
+/* ---- multi-GPU: the shard grid and the collective behind the C ABI ------------------------------------------
+ * north_star: "the candidate-pose x frame-pair grid shards naturally across the 8 GPUs of one node with an RCCL
+ * allreduce over xGMI of the per-shard best score".  A shard is a tile of that grid: `pair_blocks` x `cand_slices`
+ * ranks, rank r = pair block r / cand_slices, candidate slice r % cand_slices.  Rank r scores, for the jobs
+ * (frame pairs, all pullbacks) [J*pb/pair_blocks, J*(pb+1)/pair_blocks), the candidates
+ * [n*cs/cand_slices, n*(cs+1)/cand_slices) of each list; every other (job, candidate) is some other rank's.  The
+ * exchange is the same for every grid: a rank exports +inf / INT64_MAX for what it does not own, and the two
+ * all-reduces(MIN) give every rank the first index of minimal cost over the whole axis (process_utils.rs:69-74).
+ * pair_blocks = 1 is the pure candidate-axis split (mm_within_plan_create_sharded); cand_slices = 1 shards the frame
+ * pairs only (each pair's exact re-score then runs on one rank instead of on every rank).
+ *   mm_shard_grid   the default tile shape for `world` ranks and n_jobs frame pairs: as many pair blocks as leave
+ *                   every rank at least 64 frame pairs, the rest of the factor on the candidate axis */
+int  mm_shard_grid(int world, int64_t n_jobs, int* pair_blocks, int* cand_slices);
+int  mm_within_plan_create_grid(mm_engine* e, int n_geoms, mm_geometry** geoms,
+                                double step_deg, double range_deg, int bruteforce, int64_t sample_size,
+                                int precision, int rank, int pair_blocks, int cand_slices, mm_within_plan** out);
+int  mm_within_plan_set_shard_grid(mm_within_plan* p, int rank, int pair_blocks, int cand_slices);
+
+/* The communicator: RCCL (librccl.so.1, loaded at run time; MM_RCCL_LIB overrides the path; a process that already
+ * holds a copy -- torch ships one -- shares it).  One process per GPU:
+ *   rank 0:      mm_comm_unique_id(id)                      -> MM_COMM_ID_BYTES bytes, handed to every rank by the host
+ *   every rank:  mm_comm_init_rank(id, rank, world, device, &comm)       (collective, like ncclCommInitRank)
+ * A communicator serves one thread at a time; collectives are enqueued on the stream given (the plan's engine
+ * stream inside mm_within_plan_search_sharded), in the same order on every rank. */
+typedef struct mm_comm mm_comm;
+#define MM_COMM_ID_BYTES 128
+int  mm_comm_unique_id(void* id);
+int  mm_comm_init_rank(const void* id, int rank, int world, int device, mm_comm** out);
+void mm_comm_destroy(mm_comm* c);
+int  mm_comm_rank(const mm_comm* c);
+int  mm_comm_world(const mm_comm* c);
+int  mm_comm_version(void);   /* RCCL's version code, -1 if RCCL cannot be loaded */
+/* all-reduce(MIN) in place on device memory, enqueued on `stream` (a hipStream_t) */
+int  mm_comm_all_reduce_min_f64(mm_comm* c, double* dev, int64_t n, void* stream);
+int  mm_comm_all_reduce_min_i64(mm_comm* c, int64_t* dev, int64_t n, void* stream);
+
+/* The sharded search with the exchange inside the library: for every level
+ *   level_launch -> export_cost -> ncclAllReduce(MIN, f64 x jobs) -> export_keys -> ncclAllReduce(MIN, i64 x 3 jobs)
+ *   -> commit_dev
+ * on the engine's stream, one host synchronisation per level.  The plan must have been created for
+ * (mm_comm_rank, mm_comm_world) = (rank, pair_blocks * cand_slices).  A level already enqueued by
+ * mm_within_plan_level_launch (a driver that queues the next case's launch early) is not launched again.
+ * run_sharded = search_sharded + walk: every rank ends with the same logs and geometry (the walk is host f64). */
+int  mm_within_plan_search_sharded(mm_within_plan* p, mm_comm* c);
+int  mm_within_plan_run_sharded(mm_within_plan* p, mm_comm* c, mm_alignlog** logs, int64_t* pose_evals,
+                                int64_t* n_unresolved);
+
 /* arrays cost/uniform/angle/idx are [world][n] rank-major; tol [n] (nullable); outputs [n] */
 int  mm_merge_shards(int world, int n, const double* cost, const int32_t* uniform,
                      const double* angle, const int32_t* idx, const double* tol,

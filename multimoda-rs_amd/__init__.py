@@ -10,7 +10,7 @@ package directory name contains a hyphen.
 from __future__ import annotations
 
 from . import _native
-from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_BOUNDED, MM_PRECISION_F32_FAST, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Engine,
+from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_BOUNDED, MM_PRECISION_F32_FAST, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Comm, Engine,
                       IndexedBatch, Plan,
                       device_count, filter_points_in_region, refine_angles, refine_downsample_count, search_angles)
 from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
@@ -35,7 +35,7 @@ from .synth import synthetic_case, synthetic_pullback
 __version__ = "0.1.0"
 
 __all__ = [
-    "Engine", "Batch", "Plan", "FlatGeometry", "device_count", "search_angles", "refine_angles",
+    "Engine", "Comm", "Batch", "Plan", "FlatGeometry", "device_count", "search_angles", "refine_angles",
     "filter_points_in_region", "refine_downsample_count",
     "align_within", "align_between", "WithinPlan", "search_set", "between_points",
     "from_file_full", "from_file_doublepair", "from_file_singlepair", "from_file_single",

@@ -38,6 +38,9 @@ EXPORTS = [
     "mm_within_plan_walk", "mm_within_plan_level_collect", "mm_within_plan_level_launch", "mm_within_plan_level_export_cost",
     "mm_within_plan_level_export_keys", "mm_within_plan_level_commit_dev", "mm_merge_shards", "mm_catheter_lumen_vec", "mm_extract_between_points",
     "mm_frame_translate", "mm_frame_rotate", "mm_parse_contour_table",
+    "mm_shard_grid", "mm_within_plan_create_grid", "mm_within_plan_set_shard_grid", "mm_comm_unique_id", "mm_comm_init_rank",
+    "mm_comm_destroy", "mm_comm_rank", "mm_comm_world", "mm_comm_version", "mm_comm_all_reduce_min_f64",
+    "mm_comm_all_reduce_min_i64", "mm_within_plan_search_sharded", "mm_within_plan_run_sharded",
 ]
 # include/mm_centerline.h
 EXPORTS_CENTERLINE = [
@@ -252,6 +255,32 @@ def lib():
     L.mm_within_plan_set_shard.argtypes = [P, I, I]
     L.mm_within_plan_dims.restype = I
     L.mm_within_plan_dims.argtypes = [P, C.POINTER(I32), C.POINTER(I32), P]
+    L.mm_shard_grid.restype = I
+    L.mm_shard_grid.argtypes = [I, I64, C.POINTER(I), C.POINTER(I)]
+    L.mm_within_plan_create_grid.restype = I
+    L.mm_within_plan_create_grid.argtypes = [P, I, P, D, D, I, I64, I, I, I, I, C.POINTER(P)]
+    L.mm_within_plan_set_shard_grid.restype = I
+    L.mm_within_plan_set_shard_grid.argtypes = [P, I, I, I]
+    L.mm_comm_unique_id.restype = I
+    L.mm_comm_unique_id.argtypes = [P]
+    L.mm_comm_init_rank.restype = I
+    L.mm_comm_init_rank.argtypes = [P, I, I, I, C.POINTER(P)]
+    L.mm_comm_destroy.restype = None
+    L.mm_comm_destroy.argtypes = [P]
+    L.mm_comm_rank.restype = I
+    L.mm_comm_rank.argtypes = [P]
+    L.mm_comm_world.restype = I
+    L.mm_comm_world.argtypes = [P]
+    L.mm_comm_version.restype = I
+    L.mm_comm_version.argtypes = []
+    L.mm_comm_all_reduce_min_f64.restype = I
+    L.mm_comm_all_reduce_min_f64.argtypes = [P, P, I64, P]
+    L.mm_comm_all_reduce_min_i64.restype = I
+    L.mm_comm_all_reduce_min_i64.argtypes = [P, P, I64, P]
+    L.mm_within_plan_search_sharded.restype = I
+    L.mm_within_plan_search_sharded.argtypes = [P, P]
+    L.mm_within_plan_run_sharded.restype = I
+    L.mm_within_plan_run_sharded.argtypes = [P, P, P, C.POINTER(I64), C.POINTER(I64)]
     L.mm_within_plan_level_local.restype = I
     L.mm_within_plan_level_local.argtypes = [P, I, P, P, P, P, P]
     L.mm_within_plan_level_collect.restype = I
@@ -480,6 +509,54 @@ class Batch:
         return [self.n_pairs, _ptr(self.ref_off), _ptr(self.ref_x), _ptr(self.ref_y),
                 _ptr(self.tgt_off), _ptr(self.tgt_x), _ptr(self.tgt_y),
                 _ptr(self.ang_off), _ptr(self.angles), _ptr(self.cx), _ptr(self.cy), _ptr(self.flags)]
+
+
+class Comm:
+    """``mm_comm``: the RCCL communicator owned by the library (include/mm_hausdorff.h, "multi-GPU").  Rank 0 makes
+    the 128-byte id (``Comm.unique_id()``), the host hands it to every rank, every rank constructs ``Comm(id, rank,
+    world, device)`` -- a collective call, like ncclCommInitRank."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(lib().mm_comm_unique_id(buf), "mm_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int = -1):
+        if len(uid) != Comm.ID_BYTES:
+            raise ValueError("the communicator id is 128 bytes")
+        self.handle = C.c_void_p()
+        check(lib().mm_comm_init_rank(C.create_string_buffer(uid, Comm.ID_BYTES), int(rank), int(world), int(device),
+                                      C.byref(self.handle)), "mm_comm_init_rank")
+        self.rank, self.world = int(rank), int(world)
+
+    def all_reduce_min_f64(self, dev_ptr: int, n: int, stream: int):
+        check(lib().mm_comm_all_reduce_min_f64(self.handle, C.c_void_p(dev_ptr), int(n), C.c_void_p(stream)),
+              "mm_comm_all_reduce_min_f64")
+
+    def all_reduce_min_i64(self, dev_ptr: int, n: int, stream: int):
+        check(lib().mm_comm_all_reduce_min_i64(self.handle, C.c_void_p(dev_ptr), int(n), C.c_void_p(stream)),
+              "mm_comm_all_reduce_min_i64")
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            lib().mm_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_grid(world: int, n_jobs: int):
+    """``mm_shard_grid``: the default (pair_blocks, cand_slices) for `world` ranks and n_jobs frame pairs."""
+    pb, cs = C.c_int(0), C.c_int(0)
+    check(lib().mm_shard_grid(int(world), int(n_jobs), C.byref(pb), C.byref(cs)), "mm_shard_grid")
+    return int(pb.value), int(cs.value)
 
 
 class Engine:

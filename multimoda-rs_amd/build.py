@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmm_hausdorff.so")
 SOURCES = ["mm_kernels.hip", "mm_nn_kernels.hip", "mm_engine.cpp", "mm_host.cpp", "mm_centerline.cpp", "mm_ccta.cpp",
-           "mm_build.cpp", "mm_frames.cpp"]
+           "mm_build.cpp", "mm_frames.cpp", "mm_comm.cpp"]
 HEADERS = ["mm_device.h", "mm_engine.h", "mm_pool.h", "mm_sort.h", "mm_trace.h", os.path.join("..", "..", "include", "mm_hausdorff.h"),
            os.path.join("..", "..", "include", "mm_centerline.h"), os.path.join("..", "..", "include", "mm_ccta.h"),
            os.path.join("..", "..", "include", "mm_build.h")]
@@ -62,7 +62,7 @@ def _build_locked(verbose: bool) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -882,11 +882,12 @@ void mm_engine_destroy(mm_engine* h)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)e->sync_all();
-    for (Engine::Buf* b : {&e->host_pts, &e->host_lvl}) if (b->p) (void)hipHostFree(b->p);
+    for (Engine::Buf* b : {&e->host_pts, &e->host_lvl, &e->host_pof}) if (b->p) (void)hipHostFree(b->p);
     for (Engine::Buf* b : {&e->dev_pts, &e->dev_lvl, &e->dev_raw}) if (b->p) (void)hipFree(b->p);
     for (Engine::Buf& b : e->blob_cache) (void)hipFree(b.p);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->search_done) (void)hipEventDestroy(e->search_done);
+    if (e->pof_done) (void)hipEventDestroy(e->pof_done);
     if (e->dev_stats) (void)hipFree(e->dev_stats);
     if (e->own_aux) (void)hipStreamDestroy(e->aux);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);

@@ -37,6 +37,8 @@ struct Engine {
     hipEvent_t search_done = nullptr;
     bool search_done_recorded = false;
     Buf host_pts, host_lvl;   // pinned staging: point pool / level (+ results)
+    Buf host_pof;             // pinned: job -> pair map of a sharded level (WithinPlan::upload_pair_of_job)
+    hipEvent_t pof_done = nullptr; bool pof_busy = false;   // its upload in flight
     Buf dev_pts, dev_lvl;     // device buffers of transient plans
     Buf dev_raw;              // raw pullbacks of a within-plan while its search sets are built on the device
     int ensure(Buf& b, size_t bytes, bool host);
@@ -82,6 +84,8 @@ struct PairSpec {          // one search
     double delta_extra;            // added to the f32 screening bound
     int32_t slice_begin = 0, slice_end = INT32_MAX;   // this pair's share of the candidate axis
 };
+struct Comm;               // mm_comm.cpp: the RCCL communicator behind mm_comm_*
+
 struct BatchResult {
     std::vector<int32_t> best_idx, n_rescored, near_cnt, near_idx;  // near_idx: kMaxNear per pair
     std::vector<double> best_cost;

@@ -286,15 +286,25 @@ struct WithinPlan {
     std::vector<double> centre;
     std::vector<uint8_t> resolved;
     std::vector<int64_t> evals;
-    int rank = 0, world = 1;          // this plan's share of the candidate axis
+    // this plan's tile of the (frame pair x candidate) grid: world = grid_p * grid_c ranks, rank = pair block
+    // rank / grid_c, candidate slice rank % grid_c (grid_p = 1: the pure candidate-axis split)
+    int rank = 0, world = 1, grid_p = 1, grid_c = 1;
     bool searched = false;
+    int launched_level = -1;          // level most recently enqueued by level_launch
+    // exchange records of search_sharded (device; from the engine's blob cache)
+    unsigned char* d_xrec = nullptr; size_t xrec_cap = 0;
     // device-side exchange (level_launch / export_* / commit_dev): job -> pair of the current level
-    std::vector<int32_t> pair_of_job;
     int32_t* d_pair_of_job = nullptr;
     int pof_level = -1;               // level whose map d_pair_of_job holds
 
     size_t pof_cap = 0;
-    ~WithinPlan() { if (d_pair_of_job) e->blob_release(d_pair_of_job, pof_cap); }   // not hipFree: it waits for the whole device
+    ~WithinPlan()
+    {   // not hipFree: it waits for the whole device
+        if (d_pair_of_job) e->blob_release(d_pair_of_job, pof_cap);
+        if (d_xrec) e->blob_release(d_xrec, xrec_cap);
+    }
+    int upload_pair_of_job(size_t l);
+    int search_sharded(Comm* c);
     int prepare();
     int build_sets_host(int32_t n_sets);
     int build_sets_device(int32_t n_sets);
@@ -506,8 +516,12 @@ void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centres,
         const int g = job_geom[j], i = job_frame[j];
         const int32_t sid = set_base[g] + i;
         PairSpec sp{sid - 1, sid, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, lp, ln, 2.0 * eps[g], eps[g]};
-        sp.slice_begin = (int32_t)((int64_t)ln * rank / world);          // this rank's share of the
-        sp.slice_end = (int32_t)((int64_t)ln * (rank + 1) / world);      // candidate axis
+        // this rank's tile: the jobs of its pair block, and of their lists its slice of the candidate axis; a job of
+        // another block keeps its place in the level (every rank commits every job) with an empty slice
+        const int pb = rank / grid_c, cs = rank % grid_c;
+        const bool mine = (int64_t)j >= (int64_t)J * pb / grid_p && (int64_t)j < (int64_t)J * (pb + 1) / grid_p;
+        sp.slice_begin = mine ? (int32_t)((int64_t)ln * cs / grid_c) : 0;
+        sp.slice_end = mine ? (int32_t)((int64_t)ln * (cs + 1) / grid_c) : 0;
         pairs.push_back(sp);
         active.push_back(j);
     }
@@ -531,17 +545,34 @@ int WithinPlan::level_launch(size_t l)
         if ((rc = plan.stage_level(lvl_pairs, precision, 0, INT32_MAX, false))) return rc;
     }
     if (lvl_active.empty()) return MM_OK;
-    if (world > 1) {   // job -> pair map of the level for the device-side exchange, uploaded ahead of the search
-        pair_of_job.assign((size_t)J, -1);
-        for (size_t k = 0; k < lvl_active.size(); ++k) pair_of_job[(size_t)lvl_active[k]] = (int32_t)k;
-        if (!d_pair_of_job) {
-            if (int arc = e->blob_alloc((void**)&d_pair_of_job, (size_t)std::max(J, 1) * 4, &pof_cap)) return arc;
-        }
-        const hipError_t hc = hipMemcpyAsync(d_pair_of_job, pair_of_job.data(), (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
-        if (hc != hipSuccess) return hip_error(hc, "hipMemcpyAsync(pair_of_job)");
-        pof_level = (int)l;
-    }
+    if (world > 1)     // job -> pair map of the level for the device-side exchange, uploaded ahead of the search
+        if ((rc = upload_pair_of_job(l))) return rc;
+    launched_level = (int)l;
     return plan.run(false);
+}
+
+// The job -> pair map goes up from PINNED memory (the engine's, grow-only): a copy from a pageable vector is staged
+// synchronously by the runtime, and on a stream that waits for another engine's launch (the look-ahead of a pipelined
+// driver) that would hold the host for the whole launch.  The buffer is free again at the level's synchronisation.
+int WithinPlan::upload_pair_of_job(size_t l)
+{
+    const int J = (int)job_geom.size();
+    // (several plans may share an engine -- shard plans driven in lockstep by a test: wait for the previous upload)
+    if (e->pof_busy) { (void)hipEventSynchronize(e->pof_done); e->pof_busy = false; }
+    if (int rc = e->ensure(e->host_pof, (size_t)std::max(J, 1) * 4, true)) return rc;
+    int32_t* h = (int32_t*)e->host_pof.p;
+    for (int j = 0; j < J; ++j) h[j] = -1;
+    for (size_t k = 0; k < lvl_active.size(); ++k) h[(size_t)lvl_active[k]] = (int32_t)k;
+    if (!d_pair_of_job) {
+        if (int arc = e->blob_alloc((void**)&d_pair_of_job, (size_t)std::max(J, 1) * 4, &pof_cap)) return arc;
+    }
+    const hipError_t hc = hipMemcpyAsync(d_pair_of_job, h, (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
+    if (hc != hipSuccess) return hip_error(hc, "hipMemcpyAsync(pair_of_job)");
+    if (!e->pof_done && hipEventCreateWithFlags(&e->pof_done, hipEventDisableTiming) != hipSuccess) e->pof_done = nullptr;
+    if (e->pof_done && hipEventRecord(e->pof_done, plan.stream) == hipSuccess) e->pof_busy = true;
+    else (void)hipStreamSynchronize(plan.stream);
+    pof_level = (int)l;
+    return MM_OK;
 }
 
 int WithinPlan::level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active)
@@ -597,16 +628,8 @@ int WithinPlan::level_export_cost(size_t l, double* cost_dev)
     if (!searched) return set_error(MM_ERR_INVALID, "level_export_cost before level_launch");
     const int J = (int)job_geom.size();
     if (J == 0) return MM_OK;
-    if (pof_level != (int)l || lvl_active.empty()) {   // world == 1 (tests), or a level without active jobs
-        pair_of_job.assign((size_t)J, -1);
-        for (size_t k = 0; k < lvl_active.size(); ++k) pair_of_job[(size_t)lvl_active[k]] = (int32_t)k;
-        if (!d_pair_of_job) {
-            if (int arc = e->blob_alloc((void**)&d_pair_of_job, (size_t)J * 4, &pof_cap)) return arc;
-        }
-        const hipError_t hc = hipMemcpyAsync(d_pair_of_job, pair_of_job.data(), (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
-        if (hc != hipSuccess) return hip_error(hc, "hipMemcpyAsync(pair_of_job)");
-        pof_level = (int)l;
-    }
+    if (pof_level != (int)l || lvl_active.empty())     // world == 1 (tests), or a level without active jobs
+        if (int rc = upload_pair_of_job(l)) return rc;
     const hipError_t he = launch_export_cost(plan.dev, d_pair_of_job, J, cost_dev, plan.stream);
     return he == hipSuccess ? MM_OK : hip_error(he, "export_cost kernel launch");
 }
@@ -680,6 +703,38 @@ int WithinPlan::search()
                                   out_angle.data(), out_idx.data(), out_cost.data())))
             return rc;
         if ((rc = level_commit(l, ok.data(), out_angle.data()))) return rc;
+    }
+    return MM_OK;
+}
+
+// The search over this rank's tile with the exchange inside the library (include/mm_hausdorff.h, "multi-GPU"):
+// per level the tile's results stay in HBM, two small kernels write the job-indexed records, RCCL reduces them in
+// place on the engine's stream, one copy + one synchronisation bring the reduced records to the host.
+int comm_all_reduce_min(Comm* c, void* dev, int64_t n, bool is_f64, hipStream_t st);
+int comm_rank(const Comm* c);
+int comm_world(const Comm* c);
+
+int WithinPlan::search_sharded(Comm* c)
+{
+    // MM_SHARD_REHEARSAL=1 (timing only, bench.py's MM_BENCH_REHEARSE_WORLD): one process plays a rank of a larger job on
+    // a world = 1 communicator -- the reduced records then hold this rank's tile alone, the result is not an alignment
+    static const bool rehearsal = std::getenv("MM_SHARD_REHEARSAL") != nullptr;
+    if ((comm_world(c) != world || comm_rank(c) != rank) && !(rehearsal && comm_world(c) == 1))
+        return set_error(MM_ERR_INVALID, "search_sharded: the plan's (rank, world) is not the communicator's");
+    const int J = (int)job_geom.size();
+    const size_t o_keys = ((size_t)std::max(J, 1) * 8 + 255) / 256 * 256;
+    if (!d_xrec)
+        if (int rc = e->blob_alloc((void**)&d_xrec, o_keys + (size_t)std::max(J, 1) * 24, &xrec_cap)) return rc;
+    double* xc = (double*)d_xrec;
+    long long* xk = (long long*)(d_xrec + o_keys);
+    for (size_t l = 0; l < levels.size(); ++l) {
+        int rc;
+        if (launched_level != (int)l && (rc = level_launch(l))) return rc;   // (level 0 may have been queued early)
+        if ((rc = level_export_cost(l, xc))) return rc;
+        if (J > 0 && (rc = comm_all_reduce_min(c, xc, J, true, plan.stream))) return rc;
+        if (J > 0 && (rc = level_export_keys(l, xc, xk))) return rc;
+        if (J > 0 && (rc = comm_all_reduce_min(c, xk, 3 * (int64_t)J, false, plan.stream))) return rc;
+        if ((rc = level_commit_dev(l, xc, xk))) return rc;
     }
     return MM_OK;
 }
@@ -1101,14 +1156,37 @@ int mm_within_plan_create_sharded(mm_engine* eh, int n_geoms, mm_geometry** geom
                                   int bruteforce, int64_t sample_size, int precision, int rank, int world,
                                   mm_within_plan** out)
 {
+    return mm_within_plan_create_grid(eh, n_geoms, geoms, step_deg, range_deg, bruteforce, sample_size, precision, rank, 1,
+                                      world, out);
+}
+
+// Default tile shape: frame pairs first (a pair's exact re-score then runs on one rank, and the screen keeps its
+// full-size workgroups), the candidate axis when the pairs are few.
+int mm_shard_grid(int world, int64_t n_jobs, int* pair_blocks, int* cand_slices)
+{
+    if (world <= 0 || n_jobs < 0 || !pair_blocks || !cand_slices) return set_error(MM_ERR_INVALID, "mm_shard_grid: bad argument");
+    int p = 1;
+    for (int d = 1; d <= world; ++d)
+        if (world % d == 0 && n_jobs / d >= 64) p = d;
+    *pair_blocks = p; *cand_slices = world / p;
+    return MM_OK;
+}
+
+int mm_within_plan_create_grid(mm_engine* eh, int n_geoms, mm_geometry** geoms, double step_deg, double range_deg,
+                               int bruteforce, int64_t sample_size, int precision, int rank, int pair_blocks,
+                               int cand_slices, mm_within_plan** out)
+{
     Engine* e = reinterpret_cast<Engine*>(eh);
     if (!e || !out) return set_error(MM_ERR_INVALID, "engine/out == NULL");
     *out = nullptr;
     if (n_geoms <= 0 || !geoms) return set_error(MM_ERR_INVALID, "no geometries");
-    if (world <= 0 || rank < 0 || rank >= world) return set_error(MM_ERR_INVALID, "bad shard");
+    if (pair_blocks <= 0 || cand_slices <= 0 || pair_blocks > (1 << 15) || cand_slices > (1 << 15))
+        return set_error(MM_ERR_INVALID, "bad shard");
+    const int world = pair_blocks * cand_slices;
+    if (rank < 0 || rank >= world) return set_error(MM_ERR_INVALID, "bad shard");
     if (int drc = select_device(e)) return drc;
     WithinPlan* wp = new WithinPlan();
-    wp->rank = rank; wp->world = world;
+    wp->rank = rank; wp->world = world; wp->grid_p = pair_blocks; wp->grid_c = cand_slices;
     wp->e = e; wp->n_geoms = n_geoms; wp->geoms.assign(geoms, geoms + n_geoms);
     wp->step_deg = step_deg; wp->range_deg = range_deg; wp->bruteforce = bruteforce != 0;
     wp->sample_size = sample_size; wp->precision = precision;
@@ -1132,12 +1210,20 @@ int mm_within_plan_run(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_eval
 
 int mm_within_plan_set_shard(mm_within_plan* h, int rank, int world)
 {
+    return mm_within_plan_set_shard_grid(h, rank, 1, world);
+}
+
+int mm_within_plan_set_shard_grid(mm_within_plan* h, int rank, int pair_blocks, int cand_slices)
+{
     WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
-    if (!wp || world <= 0 || rank < 0 || rank >= world) return set_error(MM_ERR_INVALID, "bad shard");
+    if (!wp || pair_blocks <= 0 || cand_slices <= 0 || pair_blocks > (1 << 15) || cand_slices > (1 << 15))
+        return set_error(MM_ERR_INVALID, "bad shard");
+    const int world = pair_blocks * cand_slices;
+    if (rank < 0 || rank >= world) return set_error(MM_ERR_INVALID, "bad shard");
     if (wp->searched) return set_error(MM_ERR_INVALID, "shard must be set before the first level");
     if (int drc = select_device(wp->e)) return drc;
-    if (rank != wp->rank || world != wp->world) {
-        wp->rank = rank; wp->world = world; wp->level0_staged = false;
+    if (rank != wp->rank || pair_blocks != wp->grid_p || cand_slices != wp->grid_c) {
+        wp->rank = rank; wp->world = world; wp->grid_p = pair_blocks; wp->grid_c = cand_slices; wp->level0_staged = false;
         if (wp->level0_ok) {  // re-stage level 0 for the new slice now, not inside the search
             wp->build_level_pairs(0, std::vector<double>(), std::vector<uint8_t>(wp->job_geom.size(), 1), wp->lvl_pairs,
                                   wp->lvl_active, nullptr);
@@ -1235,6 +1321,25 @@ int mm_within_plan_level_commit(mm_within_plan* h, int level, const uint8_t* ok,
     WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
     if (!wp || level < 0 || (size_t)level >= wp->levels.size()) return set_error(MM_ERR_INVALID, "bad level");
     return wp->level_commit((size_t)level, ok, angle);
+}
+
+int mm_within_plan_search_sharded(mm_within_plan* h, mm_comm* ch)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || !ch) return set_error(MM_ERR_INVALID, "within plan / communicator == NULL");
+    if (int drc = select_device(wp->e)) return drc;
+    return wp->search_sharded(reinterpret_cast<Comm*>(ch));
+}
+
+int mm_within_plan_run_sharded(mm_within_plan* h, mm_comm* ch, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || !ch) return set_error(MM_ERR_INVALID, "within plan / communicator == NULL");
+    if (pose_evals) *pose_evals = 0;
+    if (n_unresolved) *n_unresolved = 0;
+    if (int drc = select_device(wp->e)) return drc;
+    if (int rc = wp->search_sharded(reinterpret_cast<Comm*>(ch))) return rc;
+    return wp->walk(logs, pose_evals, n_unresolved);
 }
 
 int mm_within_plan_walk(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)

@@ -5,9 +5,17 @@ Every rank scores its slice [n*rank/world, n*(rank+1)/world) of every pair's can
 and holds, per pair, the exact first minimum inside the slice.  The reference's winner is the
 first index of minimal cost over the whole axis (process_utils.rs:72).
 
-Two exchanges, same result (identical on every rank):
+A shard is a tile of the (frame pair x candidate) grid: ``shard_grid(world, n_jobs)`` gives the default
+(pair_blocks, cand_slices); pair_blocks = 1 is the pure candidate-axis split.  The exchange is the same for every grid
+(a rank exports +inf / INT64_MAX for what it does not own).
 
-``device`` (default)
+Three exchanges, same result (identical on every rank):
+
+``rccl`` (default when the process group's backend is nccl)
+    the ``device`` exchange below issued by the LIBRARY on its own RCCL communicator
+    (``mm_within_plan_search_sharded``: ncclAllReduce(MIN) on the engine's stream between the export kernels; the
+    path a non-Python host uses).  The communicator's id travels over the torch process group once.
+``device`` (the checker of ``rccl``; default with a CPU backend such as gloo)
     per level two RCCL all-reduces on DEVICE buffers, stream-ordered behind the search kernels on
     the engine's stream -- no host round trip between the search and the collectives:
       1. all_reduce(MIN) of the per-shard best cost (f64 x pairs)
@@ -34,11 +42,58 @@ def shard_bounds(n: int, rank: int, world: int):
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
-def exchange_mode() -> str:
-    m = os.environ.get("MM_EXCHANGE", "device")
-    if m not in ("device", "gather"):
-        raise ValueError("MM_EXCHANGE must be 'device' or 'gather'")
+def exchange_mode(group=None) -> str:
+    """MM_EXCHANGE = rccl | device | gather; default: rccl on an nccl process group, device otherwise (the library's
+    communicator needs one GPU per rank, which a gloo rehearsal of several ranks on one GPU does not have)."""
+    m = os.environ.get("MM_EXCHANGE", "")
+    if m == "":
+        import torch.distributed as dist
+        nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        m = "rccl" if nccl else "device"
+    if m not in ("rccl", "device", "gather"):
+        raise ValueError("MM_EXCHANGE must be 'rccl', 'device' or 'gather'")
     return m
+
+
+def shard_grid(world: int, n_jobs: int):
+    """Default tile shape (pair_blocks, cand_slices) of `world` ranks (``mm_shard_grid``); MM_SHARD_GRID=PxC overrides."""
+    g = os.environ.get("MM_SHARD_GRID", "")
+    if g:
+        pb, cs = (int(v) for v in g.lower().split("x"))
+        if pb * cs != world:
+            raise ValueError(f"MM_SHARD_GRID={g} does not multiply to the world size {world}")
+        return pb, cs
+    return N.shard_grid(world, n_jobs)
+
+
+_native_comms: Dict[object, "N.Comm"] = {}
+
+
+def native_comm(group=None) -> "N.Comm":
+    """The library's RCCL communicator over the ranks of a torch process group: rank 0 makes the id, it is
+    broadcast over the group once, every rank joins (collective).  Cached per group."""
+    import torch
+    import torch.distributed as dist
+    key = group if group is not None else "default"
+    c = _native_comms.get(key)
+    if c is not None:
+        return c
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    on_dev = dist.get_backend(group) == "nccl"
+    uid = N.Comm.unique_id() if rank == 0 else bytes(N.Comm.ID_BYTES)
+    t = torch.frombuffer(bytearray(uid), dtype=torch.uint8)
+    t = t.to(dev) if on_dev else t.clone()
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    c = N.Comm(bytes(t.cpu().numpy().tobytes()), rank, world, dev.index)
+    _native_comms[key] = c
+    return c
+
+
+def close_native_comms():
+    for c in _native_comms.values():
+        c.close()
+    _native_comms.clear()
 
 
 def world_size(group=None) -> int:

@@ -235,7 +235,9 @@ class WithinPlan:
     def __init__(self, engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: float, range_deg: float,
                  bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32, shard=None):
         """shard = (rank, world): this plan owns the share [n*rank/world, n*(rank+1)/world) of every candidate
-        list from the start (same as set_shard afterwards, without staging level 0 twice)."""
+        list from the start (same as set_shard afterwards, without staging level 0 twice).
+        shard = (rank, pair_blocks, cand_slices): a tile of the (frame pair x candidate) grid
+        (``mm_within_plan_create_grid``; distributed.shard_grid gives the default shape)."""
         self.engine = engine
         self.geoms = list(geoms)
         G = len(self.geoms)
@@ -243,10 +245,16 @@ class WithinPlan:
         self._gptrs = (C.POINTER(N.MMGeometry) * G)(*[C.pointer(s) for s in self._structs])
         self._h = C.c_void_p()
         engine._children.add(self)
-        rank, world = (0, 1) if shard is None else (int(shard[0]), int(shard[1]))
-        N.check(N.lib().mm_within_plan_create_sharded(engine.handle, G, C.cast(self._gptrs, C.c_void_p), float(step_deg),
-                                                      float(range_deg), int(bool(bruteforce)), int(sample_size),
-                                                      int(precision), rank, world, C.byref(self._h)),
+        if shard is None:
+            rank, pb, cs = 0, 1, 1
+        elif len(shard) == 2:
+            rank, pb, cs = int(shard[0]), 1, int(shard[1])
+        else:
+            rank, pb, cs = int(shard[0]), int(shard[1]), int(shard[2])
+        self.shard = (rank, pb, cs)
+        N.check(N.lib().mm_within_plan_create_grid(engine.handle, G, C.cast(self._gptrs, C.c_void_p), float(step_deg),
+                                                   float(range_deg), int(bool(bruteforce)), int(sample_size),
+                                                   int(precision), rank, pb, cs, C.byref(self._h)),
                 "mm_within_plan_create")
 
     def run(self):
@@ -275,6 +283,18 @@ class WithinPlan:
     # -- candidate axis sharded over ranks (one process per GPU) ---------------------------
     def set_shard(self, rank: int, world: int):
         N.check(N.lib().mm_within_plan_set_shard(self._h, int(rank), int(world)), "mm_within_plan_set_shard")
+        self.shard = (int(rank), 1, int(world))
+
+    def set_shard_grid(self, rank: int, pair_blocks: int, cand_slices: int):
+        N.check(N.lib().mm_within_plan_set_shard_grid(self._h, int(rank), int(pair_blocks), int(cand_slices)),
+                "mm_within_plan_set_shard_grid")
+        self.shard = (int(rank), int(pair_blocks), int(cand_slices))
+
+    def search_sharded(self, comm: "N.Comm"):
+        """The sharded search with the exchange inside the library: per level launch -> export -> ncclAllReduce(MIN)
+        x 2 on the engine's stream -> commit (``mm_within_plan_search_sharded``)."""
+        N.check(N.lib().mm_within_plan_search_sharded(self._h, comm.handle), "mm_within_plan_search_sharded")
+        self._begun = False
 
     def dims(self):
         """(n_jobs, n_levels, per-job tie tolerance)."""
@@ -359,8 +379,12 @@ class WithinPlan:
         process group this is the single-rank search.  walk() is the other half; a driver may overlap it
         with the search of the next, independent case (bench.py)."""
         from . import distributed as D
-        if D.world_size(group) > 1 and D.exchange_mode() == "device":
-            return D.search_device(self, group)
+        if D.world_size(group) > 1:
+            mode = D.exchange_mode(group)
+            if mode == "rccl":
+                return self.search_sharded(D.native_comm(group))
+            if mode == "device":
+                return D.search_device(self, group)
         n_jobs, n_levels, tol = self.dims()
         begun, self._begun = bool(getattr(self, "_begun", False)), False      # search_begin enqueued level 0 already
         for l in range(n_levels):

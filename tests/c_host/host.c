@@ -121,6 +121,7 @@ int main(void)
         static uint32_t ids[G][F], origs[G][F];
         static double cen[G][F * 3], lum[G][F * M * 3], cath[G][F * NC * 3], refp[G][F * 3], lcen[G][F * 3];
         static double o_cen[G][F * 3], o_lum[G][F * M * 3], o_cath[G][F * NC * 3], o_ref[G][F * 3], o_lcen[G][F * 3];
+        static double p_cen[G][F * 3], p_lum[G][F * M * 3], p_cath[G][F * NC * 3], p_lcen[G][F * 3];   /* pristine inputs */
         static int64_t loff[F + 1], coff[F + 1];
         static uint8_t href[G][F];
         mm_geometry g[G]; orc_geometry og[G];
@@ -151,6 +152,8 @@ int main(void)
             memcpy(o_cen[q], cen[q], sizeof cen[q]); memcpy(o_lum[q], lum[q], sizeof lum[q]);
             memcpy(o_cath[q], cath[q], sizeof cath[q]); memcpy(o_ref[q], refp[q], sizeof refp[q]);
             memcpy(o_lcen[q], lcen[q], sizeof lcen[q]);
+            memcpy(p_cen[q], cen[q], sizeof cen[q]); memcpy(p_lum[q], lum[q], sizeof lum[q]);
+            memcpy(p_cath[q], cath[q], sizeof cath[q]); memcpy(p_lcen[q], lcen[q], sizeof lcen[q]);
             memset(&g[q], 0, sizeof g[q]); memset(&og[q], 0, sizeof og[q]);
             g[q].n_frames = F; g[q].id = ids[q]; g[q].lumen_id = ids[q]; g[q].orig_frame = origs[q]; g[q].centroid = cen[q];
             g[q].lumen_off = loff; g[q].lumen = lum[q]; g[q].has_catheter = 1; g[q].cath_off = coff; g[q].cath = cath[q];
@@ -172,6 +175,44 @@ int main(void)
             CHECK(memcmp(lum[q], o_lum[q], sizeof lum[q]) == 0 && memcmp(cath[q], o_cath[q], sizeof cath[q]) == 0 &&
                   memcmp(cen[q], o_cen[q], sizeof cen[q]) == 0 && memcmp(lcen[q], o_lcen[q], sizeof lcen[q]) == 0,
                   "chain coordinates of pullback %d", q);
+        }
+        /* 4b. the same alignment as rank 0 of a one-rank job through the multi-GPU entry points: the library's own RCCL
+         *     communicator (mm_comm_*), a 1 x 1 shard grid, export kernels + ncclAllReduce(MIN) x 2 per level on the
+         *     engine's stream (mm_within_plan_run_sharded) -- what every rank of an N-GPU host calls */
+        {
+            unsigned char uid[MM_COMM_ID_BYTES];
+            mm_comm* comm = NULL;
+            mm_alignlog logs2[G][F - 1]; mm_alignlog* lp2[G];
+            int pb = 0, cs = 0;
+            CHECK(mm_shard_grid(8, 2044, &pb, &cs) == MM_OK && pb == 8 && cs == 1, "mm_shard_grid");
+            CHECK(mm_comm_version() > 0, "RCCL not loadable: %s", mm_last_error());
+            CHECK(mm_comm_unique_id(uid) == MM_OK, "mm_comm_unique_id: %s", mm_last_error());
+            CHECK(mm_comm_init_rank(uid, 0, 1, -1, &comm) == MM_OK && comm, "mm_comm_init_rank: %s", mm_last_error());
+            CHECK(mm_comm_rank(comm) == 0 && mm_comm_world(comm) == 1, "communicator rank / world");
+            for (int q = 0; q < G; ++q) {
+                memcpy(cen[q], p_cen[q], sizeof cen[q]); memcpy(lum[q], p_lum[q], sizeof lum[q]);
+                memcpy(cath[q], p_cath[q], sizeof cath[q]); memcpy(lcen[q], p_lcen[q], sizeof lcen[q]);
+                lp2[q] = logs2[q];
+            }
+            int64_t evals2 = 0, unres2 = -1;
+            plan = NULL;
+            CHECK(mm_within_plan_create_grid(e, G, gp, 1.0, 60.0, 1, 200, MM_PRECISION_F32_FAST, 0, 1, 1, &plan) == MM_OK && plan,
+                  "mm_within_plan_create_grid");
+            CHECK(mm_within_plan_run_sharded(plan, comm, lp2, &evals2, &unres2) == MM_OK, "mm_within_plan_run_sharded: %s", mm_last_error());
+            mm_within_plan_destroy(plan);
+            CHECK(evals2 == evals && unres2 == unresolved, "sharded run: pose-evals / re-searched steps");
+            for (int q = 0; q < G; ++q) {
+                CHECK(memcmp(logs2[q], ologs[q], sizeof ologs[q]) == 0, "sharded run: chain logs of pullback %d", q);
+                CHECK(memcmp(lum[q], o_lum[q], sizeof lum[q]) == 0 && memcmp(cath[q], o_cath[q], sizeof cath[q]) == 0 &&
+                      memcmp(cen[q], o_cen[q], sizeof cen[q]) == 0 && memcmp(lcen[q], o_lcen[q], sizeof lcen[q]) == 0,
+                      "sharded run: chain coordinates of pullback %d", q);
+            }
+            /* a plan made for another job size is refused, not run */
+            CHECK(mm_within_plan_create_grid(e, G, gp, 1.0, 60.0, 1, 200, MM_PRECISION_F32_FAST, 1, 1, 2, &plan) == MM_OK, "grid plan");
+            CHECK(mm_within_plan_search_sharded(plan, comm) == MM_ERR_INVALID, "a plan of another world must be refused");
+            mm_within_plan_destroy(plan);
+            mm_comm_destroy(comm);
+            printf("sharded entry points: world = 1 RCCL communicator, logs and coordinates identical to the oracle\n");
         }
         double best = 0.0, obest = 1.0; int64_t bevals = 0;
         mm_geometry* ga[1] = {&g[0]}; mm_geometry* gb[1] = {&g[1]};

@@ -24,3 +24,4 @@ def test_plain_c_host_runs_the_path_and_matches_the_oracle(oracle, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C_HOST_OK" in r.stdout and "identical to the oracle at all four precisions" in r.stdout
     assert "logs and coordinates identical to the oracle" in r.stdout
+    assert "sharded entry points: world = 1 RCCL communicator" in r.stdout

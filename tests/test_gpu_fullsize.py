@@ -91,6 +91,57 @@ def test_full_four_phase_alignment_equals_oracle(fresh_engine, oracle, mm, name,
         assert geoms_equal(g, og), f"coordinates of pullback {k} differ"
 
 
+@pytest.mark.parametrize("grid", [(1, 2), (2, 1), (1, 8), (8, 1), (2, 4)])
+def test_config4_sharded_full_size_equals_oracle(fresh_engine, oracle, mm, grid):
+    """BASELINE config 4 at its workload: the config3 alignment (4 x 512 frames, 721 candidates) with the
+    (frame pair x candidate) grid sharded over 2 and 8 ranks -- the pure candidate-axis split (1, W), the pure pair
+    split (W, 1) and a mixed tile (2, 4) -- every "rank" a shard plan of this process, driven level by level with the
+    device exchange (export kernels, key encoding and commit are the ones a multi-rank run uses; the all-reduces are
+    element-wise minima over the plans' device records).  EVERY rank must end with the oracle's logs and coordinates."""
+    from multimoda_rs_amd import distributed as D
+    cfg = CONFIGS["config3"]
+    ologs, _orot, ogeoms = _oracle_alignment(oracle, mm, "config3")
+    # the oracle's geometries have been through the between stage as well: compare with the within result
+    world = grid[0] * grid[1]
+    cases = [mm.synthetic_case(cfg["frames"], cfg["points"]) for _ in range(world)]
+    plans = [mm.WithinPlan(fresh_engine, cases[r], cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                           precision=mm.MM_PRECISION_F32_FAST, shard=(r, grid[0], grid[1])) for r in range(world)]
+    D.search_inprocess(plans)
+    single = mm.synthetic_case(cfg["frames"], cfg["points"])
+    wp = mm.WithinPlan(fresh_engine, single, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
+                       precision=mm.MM_PRECISION_F32_FAST)
+    slogs, sevals, sunres = wp.run()
+    wp.close()
+    for r, p in enumerate(plans):
+        logs, evals, unres = p.walk()
+        p.close()
+        assert evals == sevals == 4 * 511 * 721 and unres == sunres == 0
+        for k in range(4):
+            assert logs[k] == ologs[k] == slogs[k], f"rank {r}: within logs of pullback {k} differ"
+            assert geoms_equal(cases[r][k], single[k]), f"rank {r}: coordinates of pullback {k} differ"
+
+
+def test_bench_two_ranks_check_config2():
+    """`bench.py --gpus 2 --workload config2 --check` as the driver starts it (torch.distributed.run, here two `gloo`
+    ranks sharing the one GPU): the sharded step pipeline end to end, rank 0's result compared with the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MM_BENCH_BACKEND="gloo", OMP_NUM_THREADS="8")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "config2", "--steps", "3",
+           "--warmup", "1", "--check", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["config"]["all_timed_steps_identical"]
+    assert out["check"]["within_logs_identical"] and out["check"]["between_rotations_identical"]
+    assert out["check"]["all_coordinates_identical"]
+
+
 def test_full_size_chain_mode_equals_oracle_config2(fresh_engine, oracle, mm):
     """The faithful per-step chain (mode 0) at config2 size: 127 dependent batched searches."""
     cfg = CONFIGS["config2"]

@@ -23,13 +23,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision, exchange="gather"):
-    """Run `world` shard plans in lockstep; returns per rank (geoms, logs, evals, unresolved)."""
+def drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision, exchange="gather", grid=None):
+    """Run `world` shard plans in lockstep; returns per rank (geoms, logs, evals, unresolved).
+    grid = (pair_blocks, cand_slices) with pair_blocks * cand_slices == world: tiles of the (frame pair x candidate)
+    grid (mm_within_plan_set_shard_grid); None = the pure candidate-axis split (set_shard)."""
     from multimoda_rs_amd import distributed as D
     cases = [[g.copy() for g in base] for _ in range(world)]
     plans = [mm.WithinPlan(engine, cases[r], step, rng_deg, bruteforce, ss, precision=precision) for r in range(world)]
     for r, p in enumerate(plans):
-        p.set_shard(r, world)
+        if grid is None:
+            p.set_shard(r, world)
+        else:
+            assert grid[0] * grid[1] == world
+            p.set_shard_grid(r, grid[0], grid[1])
     n_jobs, n_levels, tol = plans[0].dims()
     if exchange == "gather":
         for l in range(n_levels):
@@ -81,6 +87,68 @@ def test_sharded_within_plan_equals_single_rank_and_oracle(engine, oracle, mm, b
                 assert geoms_equal(geoms[k], ogeoms[k]) and geoms_equal(single[k], ogeoms[k])
     finally:
         engine.set_bound_min_candidates(16384)
+
+
+@pytest.mark.parametrize("exchange", ["gather", "device"])
+@pytest.mark.parametrize("precision", [2, 3])
+@pytest.mark.parametrize("grid", [(2, 1), (3, 1), (2, 2), (2, 4), (4, 2), (8, 1), (27, 1), (32, 1)])
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES)
+def test_grid_sharded_within_plan_equals_single_rank_and_oracle(engine, oracle, mm, bruteforce, step, rng_deg, ss, grid,
+                                                                precision, exchange):
+    """Tiles of the (frame pair x candidate) grid (include/mm_hausdorff.h, "multi-GPU"): pair blocks x candidate slices.
+    27 frame pairs here: (27, 1) gives every rank one pair, (32, 1) leaves five ranks without any."""
+    engine.set_bound_min_candidates(0)
+    try:
+        world = grid[0] * grid[1]
+        base = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((9, 6, 9, 7))]
+        ogeoms = [to_oracle(oracle, g) for g in base]
+        ologs = [oracle.align_within_chain(o, step, rng_deg, bruteforce, ss, n_threads=8) for o in ogeoms]
+        evals0 = None
+        for geoms, logs, evals, unres in drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision,
+                                                       exchange, grid=grid):
+            evals0 = evals if evals0 is None else evals0
+            assert evals == evals0 and unres == 0
+            for k in range(len(base)):
+                assert logs[k] == ologs[k]
+                assert geoms_equal(geoms[k], ogeoms[k])
+    finally:
+        engine.set_bound_min_candidates(16384)
+
+
+def test_default_shard_grid():
+    from multimoda_rs_amd import _native as N
+    assert N.shard_grid(8, 2044) == (8, 1)       # config3: frame pairs only
+    assert N.shard_grid(8, 508) == (4, 2)        # config2
+    assert N.shard_grid(8, 80) == (1, 8)         # a few pairs with long candidate lists: the candidate axis
+    assert N.shard_grid(1, 5) == (1, 1) and N.shard_grid(6, 1000) == (6, 1) and N.shard_grid(6, 200) == (3, 2)
+
+
+@pytest.mark.parametrize("precision", [2, 3])
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES)
+def test_native_rccl_search_world1(engine, oracle, mm, bruteforce, step, rng_deg, ss, precision):
+    """mm_within_plan_run_sharded's search half on a world = 1 RCCL communicator owned by the library (mm_comm_*):
+    the launch path a multi-GPU job takes -- export kernels, ncclAllReduce(MIN) x 2 on the engine's stream, commit --
+    without a peer.  Same logs and coordinates as the oracle."""
+    comm = mm.Comm(mm.Comm.unique_id(), 0, 1)
+    try:
+        assert comm.rank == 0 and comm.world == 1
+        base = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((9, 6, 9, 7))]
+        ogeoms = [to_oracle(oracle, g) for g in base]
+        ologs = [oracle.align_within_chain(o, step, rng_deg, bruteforce, ss, n_threads=8) for o in ogeoms]
+        plan = mm.WithinPlan(engine, base, step, rng_deg, bruteforce, ss, precision=precision)
+        plan.search_sharded(comm)
+        logs, _evals, unres = plan.walk()
+        plan.close()
+        assert unres == 0
+        for k in range(len(base)):
+            assert logs[k] == ologs[k] and geoms_equal(base[k], ogeoms[k])
+        # a plan made for another world is refused
+        plan = mm.WithinPlan(engine, [g.copy() for g in base], step, rng_deg, bruteforce, ss, precision=precision, shard=(0, 2))
+        with pytest.raises(RuntimeError, match="not the communicator"):
+            plan.search_sharded(comm)
+        plan.close()
+    finally:
+        comm.close()
 
 
 @pytest.mark.parametrize("exchange", ["gather", "device"])

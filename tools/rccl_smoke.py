@@ -57,6 +57,39 @@ for rep in range(3):
     print("device exchange, level 0, %d jobs: " % n_jobs + ", ".join("%s %.3f ms" % (n, 1e3 * (t[i + 1] - t[i])) for i, n in enumerate(names))
           + "; total %.3f ms" % (1e3 * (t[-1] - t[0])))
 
+# the same exchange issued by the LIBRARY on its own communicator (mm_comm_*, mm_within_plan_search_sharded's pieces)
+comm = mm.Comm(mm.Comm.unique_id(), 0, 1, 0)
+for rep in range(4):
+    p = plan()
+    n_jobs, n_levels, tol = p.dims()
+    b = D._buffers(p, n_jobs)
+    p.level_launch(0)
+    eng.synchronize()
+    t = [time.perf_counter()]
+    p.level_export_cost(0, b.cost.data_ptr()); t.append(time.perf_counter())
+    comm.all_reduce_min_f64(b.cost.data_ptr(), n_jobs, eng.stream); t.append(time.perf_counter())
+    p.level_export_keys(0, b.cost.data_ptr(), b.keys.data_ptr()); t.append(time.perf_counter())
+    comm.all_reduce_min_i64(b.keys.data_ptr(), 3 * n_jobs, eng.stream); t.append(time.perf_counter())
+    p.level_commit_dev(0, b.cost.data_ptr(), b.keys.data_ptr()); t.append(time.perf_counter())
+    logs, _, unres = p.walk()
+    assert [list(l) for l in logs] == [list(l) for l in ref_logs] and unres == 0
+    p.close()
+    names = ("export_cost (enqueue)", "ncclAllReduce cost (enqueue)", "export_keys (enqueue)", "ncclAllReduce keys (enqueue)",
+             "D2H + sync + commit")
+    print("library exchange (mm_comm), level 0, %d jobs: " % n_jobs + ", ".join("%s %.3f ms" % (n, 1e3 * (t[i + 1] - t[i])) for i, n in enumerate(names))
+          + "; total %.3f ms" % (1e3 * (t[-1] - t[0])))
+for rep in range(3):
+    p = plan()
+    p.level_launch(0)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    p.search_sharded(comm)                              # level 0 is already launched: exports, collectives, commit only
+    t1 = time.perf_counter()
+    logs, _, unres = p.walk()
+    assert [list(l) for l in logs] == [list(l) for l in ref_logs] and unres == 0
+    p.close()
+    print("mm_within_plan_search_sharded after the launch has finished (exchange alone): %.3f ms" % (1e3 * (t1 - t0)))
+
 # gather exchange through the host
 for rep in range(3):
     p = plan()
@@ -93,8 +126,15 @@ for rep in range(3):
     t3 = time.perf_counter()
     q.walk()
     q.close()
-    print("search with the device exchange (world = 1 over RCCL) %.3f ms; plain single-rank search %.3f ms" % (
-        1e3 * (t1 - t0), 1e3 * (t3 - t2)))
+    r = plan()
+    t4 = time.perf_counter()
+    r.search_sharded(comm)
+    t5 = time.perf_counter()
+    r.walk()
+    r.close()
+    print("search with the device exchange through torch (world = 1 over RCCL) %.3f ms; through the library's communicator "
+          "%.3f ms; plain single-rank search %.3f ms" % (1e3 * (t1 - t0), 1e3 * (t5 - t4), 1e3 * (t3 - t2)))
+comm.close()
 
 dist.barrier()
 dist.destroy_process_group()
