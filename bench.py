@@ -77,7 +77,7 @@ def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     return logs, rot, evals + e2, unresolved
 
 
-def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None, stager=False):
+def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None, stager=False, pre=None):
     """Run steps `ks`: search(k) then finish(k), and -- if `stage` is given -- stage(k + lookahead) after
     finish(k) (the caller has staged the first `lookahead` steps of `ks` itself: priming), so a call over K steps
     does K stagings, K searches and K finishes.
@@ -90,7 +90,10 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
     never share an engine.  Without it the finishing thread stages too (two engines suffice).
     begin (optional, pipelined only): the search split in two -- begin(k, prev) enqueues step k's launch behind step
     prev's long kernel and returns, search(k) then only collects -- so that step k+1 is already queued on the
-    device when step k's launch ends: the device does not idle while the host fetches, commits and launches."""
+    device when step k's launch ends: the device does not idle while the host fetches, commits and launches.
+    pre (optional, with begin): pre(k) is called before begin(k+1, k) -- the sharded search enqueues step k's whole
+    exchange there (exports, all-reduces, record copy; nothing waited for), so that begin(k+1, k) can order step k+1's
+    launch behind it."""
     ks = list(ks)
     if not pipelined:
         out = []
@@ -160,6 +163,8 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
                     break
                 search(k)
             else:
+                if pre is not None:
+                    pre(k)
                 if i + 1 < len(ks):
                     wait_ready(ks[i + 1])
                     if err:
@@ -254,14 +259,17 @@ class Runner:
     device, level 0 staged), search(k) (all levels: local search -> exchange -> commit) and finish(k) (chain walk,
     AB|CD and AC|BD between alignments).  Step k lives on engine k % len(engs) and works on its own copy of the case."""
 
-    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases, rehearse=0, grid=None, comm=None):
+    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases, rehearse=0, grid=None, comm=None, lazy_until=0):
         self.mm, self.engs, self.cfg, self.prec, self.mode, self.rank, self.world, self.ext = mm, engs, cfg, prec, mode, rank, world, ext
         self.rehearse = rehearse           # > 1: this process plays rank 0 of `rehearse` ranks without peers (timing only)
         self.grid = grid                   # (pair_blocks, cand_slices) of the shard grid (N > 1 / rehearsal)
         self.comm = comm                   # rehearsal: the library's world = 1 RCCL communicator (None: torch's)
         # the caller's input data: one fresh copy of the case per step (made before the timed region -- this is
         # the data a caller hands over, not work of the step)
-        self.cases = [base if ext is not None else [g.copy() for g in base] for _ in range(n_cases)]
+        # (lazy_until: the cases of the untimed clock-ramp steps are copied when they are staged and dropped when they
+        # are finished -- at N = 8 there are dozens of them)
+        self.base, self.lazy_until = base, lazy_until
+        self.cases = [base if ext is not None else (None if k < lazy_until else [g.copy() for g in base]) for k in range(n_cases)]
         self.plans = [None] * n_cases
         self.stage_s = 0.0
         self.staged = 0
@@ -275,6 +283,8 @@ class Runner:
         if k >= len(self.cases) or self.mode != 1 or self.ext is not None:
             return
         mm, cfg = self.mm, self.cfg
+        if self.cases[k] is None:
+            self.cases[k] = [g.copy() for g in self.base]
         t0 = time.perf_counter()
         self.plans[k] = mm.WithinPlan(self.engs[k % len(self.engs)], self.cases[k], cfg["step_deg"], cfg["range_deg"], True,
                                       cfg["sample_size"], precision=self.prec,
@@ -283,10 +293,34 @@ class Runner:
         self.stage_s += time.perf_counter() - t0
         self.staged += 1
 
+    def chained(self):
+        """N > 1 (or its rehearsal) over the library's communicator: step k+1's launch is ordered behind step k's whole
+        exchange (Engine.wait_exchange), so no collective runs beside a launch and the device never waits for the host."""
+        return self.native_comm() is not None and not os.environ.get("MM_BENCH_SHARD_LOOKAHEAD")
+
+    def native_comm(self):
+        if self.rehearse > 1:
+            return self.comm
+        if self.world > 1:
+            from multimoda_rs_amd import distributed as D
+            return D.native_comm() if D.exchange_mode() == "rccl" else None
+        return None
+
+    def pre(self, k):
+        if self.plans[k] is not None and self.ext is None and self.chained():
+            self.plans[k].search_sharded_begin(self.native_comm())
+
     def begin(self, k, prev):
-        """Enqueue step k's level-0 launch behind step prev's long kernel (Engine.wait_search) and return."""
+        """Enqueue step k's level-0 launch behind step prev's long kernel (Engine.wait_search) -- sharded: behind step
+        prev's whole exchange (Engine.wait_exchange) -- and return."""
         if self.plans[k] is not None and self.ext is None:
-            self.plans[k].search_begin(after=None if prev is None else self.engs[prev % len(self.engs)])
+            if self.chained():
+                if prev is not None:
+                    self.engs[k % len(self.engs)].wait_exchange(self.engs[prev % len(self.engs)])
+                self.plans[k].level_launch(0)
+                self.plans[k]._begun = True
+            else:
+                self.plans[k].search_begin(after=None if prev is None else self.engs[prev % len(self.engs)])
 
     def search(self, k):
         if self.plans[k] is not None and self.ext is None:
@@ -315,6 +349,8 @@ class Runner:
         if self.plans[k] is not None:
             self.plans[k].close()                        # HBM of the step is released; at most three plans are alive
             self.plans[k] = None
+        if k < self.lazy_until:
+            self.cases[k] = None
         return out
 
     def close(self):
@@ -423,7 +459,8 @@ def main():
     # three engines (main stream, side stream, staging buffers each): step k lives on engine k % 3, so the search of
     # step k+1, the finish of step k and the staging of step k+3 (which takes over step k's engine once that is
     # finished) never share one, and each of the three has a host thread of its own
-    LOOK = int(os.environ.get("MM_BENCH_ENGINES", "3"))
+    # (N > 1: four -- a step is an eighth as long there, and finish(k) -> stage(k + LOOK) has to fit into LOOK - 1 steps)
+    LOOK = int(os.environ.get("MM_BENCH_ENGINES", "4" if (world > 1 or rehearse > 1) else "3"))
     if LOOK < 2:
         raise SystemExit("MM_BENCH_ENGINES must be >= 2")
     engs = [mm.Engine(local_rank) for _ in range(LOOK)]
@@ -471,8 +508,20 @@ def main():
         steady-state throughput of a stream of cases, the last LOOK staged cases are not searched.
         resident: every case is staged before the timed region (inputs and search sets resident in HBM when it
         starts); the region then holds K searches and K finishes only."""
+        # The clocks need ~0.2 s of load to settle (the first launches after a pause run up to 20 % slower, DESIGN 7), and
+        # at N = 8 a step is 4 ms: the untimed warm-up is extended to that, by a count every rank computes alike
+        # (pose-evals of a step / 45 M/s / ranks -- an estimate of the step time, not a measurement).
+        ramp = 0
+        if mode == 1 and ext is None and pipe and not resident:
+            n_ang = len(mm.search_angles(cfg["step_deg"], cfg["range_deg"])[0])
+            est_ms = n_jobs * n_ang / 45e6 / max(world, rehearse, 1) * 1e3 * (3.0 if prec == mm.MM_PRECISION_F64 else 1.0)
+            ramp = max(0, min(96, int(np.ceil(200.0 / max(est_ms, 0.05))) - warmup))
+            if prec == mm.MM_PRECISION_F32_BOUNDED:
+                ramp = 0
+        warmup += ramp
         n_total = warmup + steps
-        r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK, rehearse, grid, rehearse_comm)
+        r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK, rehearse, grid, rehearse_comm,
+                   lazy_until=warmup - 1 if ramp else 0)
         for k in range(n_total if resident else LOOK):
             r.stage(k)                                   # priming (setup, untimed)
         stage_fn = None if resident else r.stage
@@ -481,19 +530,20 @@ def main():
         # all-reduces.  The order of the collectives is unchanged on every rank.
         sharded = world > 1 or rehearse > 1
         begin = r.begin if (pipe and mode == 1 and ext is None and not os.environ.get("MM_BENCH_NO_LOOKAHEAD")
-                            and (not sharded or os.environ.get("MM_BENCH_SHARD_LOOKAHEAD") == "1")) else None
+                            and (not sharded or os.environ.get("MM_BENCH_SHARD_LOOKAHEAD") == "1" or r.chained())) else None
+        pre = r.pre if (begin is not None and sharded and r.chained()) else None
         import gc
         gc.collect()
         gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
         # (collected BEFORE the warm-up: a collection between warm-up and timed region idles the device for ~40 ms,
         # and the first big launch after such a pause runs 34.9 instead of 31.3 ms -- the clocks have dropped)
-        run_steps(range(warmup), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER)
+        run_steps(range(warmup), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre)
         barrier()
         for e in engs:
             e.profile(True)
         r.stage_s, r.staged = 0.0, 0
         t0 = time.perf_counter()
-        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER)
+        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -501,7 +551,7 @@ def main():
         last_case = r.cases[n_total - 1]
         stage_ms = 1e3 * r.stage_s / max(r.staged, 1)
         r.close()
-        return dict(dt=reduce_max(dt), results=results, evals=sum(x[2] for x in results), unresolved=sum(x[3] for x in results),
+        return dict(ramp=ramp, dt=reduce_max(dt), results=results, evals=sum(x[2] for x in results), unresolved=sum(x[3] for x in results),
                     prof=prof, last_case=last_case, stage_ms=stage_ms, staged=r.staged)
 
     # setup, not a step: let both engines grow their transient buffers (between stage) now
@@ -678,6 +728,7 @@ def main():
                                           "when a step starts") if (mode == 1 and ext is None) else
                                          ("search only, point sets staged in HBM before the timed region" if ext is not None else
                                           "the whole step (faithful chain: sets built and uploaded per chain step)"),
+                       "untimed_steps_before_the_timed_region": args.warmup + main_leg["ramp"],
                        "staged_cases_in_timed_region": main_leg["staged"], "stage_ms_per_case": main_leg["stage_ms"],
                        "all_timed_steps_identical": steps_identical,
                        "parallelism": (f"(frame pair x candidate) grid in {grid[0]} x {grid[1]} tiles, one per GPU" if world > 1

@@ -98,6 +98,11 @@ void* mm_engine_stream(mm_engine* e);
  * uses it to keep the device busy across the hand-over: launch case k+1, then collect case k.  No-op if `other` has
  * not searched yet. */
 int  mm_engine_wait_search(mm_engine* waiter, mm_engine* other);
+/* The same for a SHARDED search: order `waiter`'s main stream behind the whole exchange of the level most recently
+ * enqueued on `other` by mm_within_plan_search_sharded_begin (export kernels, both all-reduces, the copy of the reduced
+ * records).  The next case's launch then starts when this case's last copy ends, and no collective ever has to find
+ * room beside a launch that fills the device.  No-op if `other` has not enqueued an exchange yet. */
+int  mm_engine_wait_exchange(mm_engine* waiter, mm_engine* other);
 
 /* Per-launch timing of the dominant (candidate-scoring) kernel with hipEvents recorded on
  * the engine's stream around every launch.  mm_engine_profile_read synchronizes, returns
@@ -389,6 +394,12 @@ int  mm_comm_all_reduce_min_i64(mm_comm* c, int64_t* dev, int64_t n, void* strea
  * mm_within_plan_level_launch (a driver that queues the next case's launch early) is not launched again.
  * run_sharded = search_sharded + walk: every rank ends with the same logs and geometry (the walk is host f64). */
 int  mm_within_plan_search_sharded(mm_within_plan* p, mm_comm* c);
+/* search_sharded split for a driver that aligns independent cases back to back: begin enqueues level 0 completely
+ * (launch unless already launched, exports, both all-reduces, the copy of the reduced records) and returns without
+ * waiting; the driver then queues the next case's launch behind it (mm_engine_wait_exchange + mm_within_plan_level_launch
+ * on another engine) and calls mm_within_plan_search_sharded, which collects level 0 and runs any further levels.
+ * The collectives are issued in the same order on every rank: begin(case k), then begin(case k+1), ... */
+int  mm_within_plan_search_sharded_begin(mm_within_plan* p, mm_comm* c);
 int  mm_within_plan_run_sharded(mm_within_plan* p, mm_comm* c, mm_alignlog** logs, int64_t* pose_evals,
                                 int64_t* n_unresolved);
 

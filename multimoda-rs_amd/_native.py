@@ -41,6 +41,7 @@ EXPORTS = [
     "mm_shard_grid", "mm_within_plan_create_grid", "mm_within_plan_set_shard_grid", "mm_comm_unique_id", "mm_comm_init_rank",
     "mm_comm_destroy", "mm_comm_rank", "mm_comm_world", "mm_comm_version", "mm_comm_all_reduce_min_f64",
     "mm_comm_all_reduce_min_i64", "mm_within_plan_search_sharded", "mm_within_plan_run_sharded",
+    "mm_within_plan_search_sharded_begin", "mm_engine_wait_exchange",
 ]
 # include/mm_centerline.h
 EXPORTS_CENTERLINE = [
@@ -279,6 +280,10 @@ def lib():
     L.mm_comm_all_reduce_min_i64.argtypes = [P, P, I64, P]
     L.mm_within_plan_search_sharded.restype = I
     L.mm_within_plan_search_sharded.argtypes = [P, P]
+    L.mm_within_plan_search_sharded_begin.restype = I
+    L.mm_within_plan_search_sharded_begin.argtypes = [P, P]
+    L.mm_engine_wait_exchange.restype = I
+    L.mm_engine_wait_exchange.argtypes = [P, P]
     L.mm_within_plan_run_sharded.restype = I
     L.mm_within_plan_run_sharded.argtypes = [P, P, P, C.POINTER(I64), C.POINTER(I64)]
     L.mm_within_plan_level_local.restype = I
@@ -603,6 +608,11 @@ class Engine:
         """Whatever this engine enqueues next on its main stream starts when `other`'s most recent search launch
         ends (``mm_engine_wait_search``)."""
         check(lib().mm_engine_wait_search(self._h, other._h), "mm_engine_wait_search")
+
+    def wait_exchange(self, other: "Engine"):
+        """Whatever this engine enqueues next on its main stream starts when the sharded level most recently enqueued on
+        `other` (WithinPlan.search_sharded_begin) has finished its exchange (``mm_engine_wait_exchange``)."""
+        check(lib().mm_engine_wait_exchange(self._h, other._h), "mm_engine_wait_exchange")
 
     def profile(self, enable: bool = True):
         """hipEvent timing around every launch of the scoring kernel (mm_engine_profile)."""

@@ -749,8 +749,10 @@ int mm_find_points_by_cl_region(mm_engine* h, const mm_clpoint* cl, const uint32
     Engine* e;
     int rc = engine_of(h, e);
     if (rc) return rc;
-    if (n < 0 || ncl <= 0 || !cl || n_frames < 2 || !frame_centroids || (n > 0 && (!pts || !label)))
-        return set_error(MM_ERR_INVALID, "mm_find_points_by_cl_region: bad arguments (needs a centerline and >= 2 frames)");
+    // (no frame at all: the reference's `frames.len() - 1` underflows and panics.  ONE frame is not an error there: the
+    // mean spacing is 0.0 / 0 = NaN, no centerline point is "in range" of it, every point is proximal or distal)
+    if (n < 0 || ncl <= 0 || !cl || n_frames < 1 || !frame_centroids || (n > 0 && (!pts || !label)))
+        return set_error(MM_ERR_INVALID, "mm_find_points_by_cl_region: bad arguments (needs a centerline and >= 1 frame)");
     double mean_dz = 0.0;                                                              // :268-272
     for (int64_t i = 1; i < n_frames; ++i) mean_dz += std::fabs(frame_centroids[3 * i + 2] - frame_centroids[3 * (i - 1) + 2]);
     mean_dz /= (double)(n_frames - 1);

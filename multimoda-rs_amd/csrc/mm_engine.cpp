@@ -239,10 +239,15 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // Non-finite (or overflowing) coordinates: the reference's metric skips the points whose distances are not finite
     // (process_utils.rs:112-114) and carries on.  The exact kernels do the same; a screen cannot bound such values, so
     // every candidate of this level is scored exactly.  (rho = inf marks such a set, see stage_sets / k_build_sets.)
+    // The same for finite coordinates an f32 screen cannot hold: squared distances reach (rho_r + rho_t)^2, which must
+    // stay below FLT_MAX (rho < 1e18 leaves a factor 1e2), and the error bounds of the screens (relative to rho) assume
+    // that u * rho^2 is far above the f32 denormals (rho > 1e-15 leaves a factor 1e8); rho == 0 (all points at the
+    // centre) is exact in any format.
+    auto f32_safe = [](double rho) { return rho < 1.0e18 && (rho == 0.0 || rho > 1.0e-15); };
     if (precision != MM_PRECISION_F64)
         for (const PairSpec& sp : pairs)
             if (sp.ref_set >= 0 && sp.tgt_set >= 0 && (size_t)sp.ref_set < set_rho.size() && (size_t)sp.tgt_set < set_rho.size() &&
-                (!(set_rho[sp.ref_set] < 1.0e150) || !(set_rho[sp.tgt_set] < 1.0e150) || !std::isfinite(sp.cx) || !std::isfinite(sp.cy))) {
+                (!f32_safe(set_rho[sp.ref_set]) || !f32_safe(set_rho[sp.tgt_set]) || !std::isfinite(sp.cx) || !std::isfinite(sp.cy))) {
                 precision = MM_PRECISION_F64;
                 break;
             }
@@ -888,6 +893,7 @@ void mm_engine_destroy(mm_engine* h)
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     if (e->search_done) (void)hipEventDestroy(e->search_done);
     if (e->pof_done) (void)hipEventDestroy(e->pof_done);
+    if (e->tail_done) (void)hipEventDestroy(e->tail_done);
     if (e->dev_stats) (void)hipFree(e->dev_stats);
     if (e->own_aux) (void)hipStreamDestroy(e->aux);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -910,6 +916,16 @@ int mm_engine_wait_search(mm_engine* waiter, mm_engine* other)
     if (w->device != o->device) return set_error(MM_ERR_INVALID, "mm_engine_wait_search: engines on different devices");
     MM_HIP(hipSetDevice(w->device));
     if (o->search_done_recorded) MM_HIP(hipStreamWaitEvent(w->stream, o->search_done, 0));
+    return MM_OK;
+}
+
+int mm_engine_wait_exchange(mm_engine* waiter, mm_engine* other)
+{
+    Engine *w = reinterpret_cast<Engine*>(waiter), *o = reinterpret_cast<Engine*>(other);
+    if (!w || !o) return set_error(MM_ERR_INVALID, "engine == NULL");
+    if (w->device != o->device) return set_error(MM_ERR_INVALID, "mm_engine_wait_exchange: engines on different devices");
+    MM_HIP(hipSetDevice(w->device));
+    if (o->tail_done_recorded) MM_HIP(hipStreamWaitEvent(w->stream, o->tail_done, 0));
     return MM_OK;
 }
 

@@ -36,6 +36,10 @@ struct Engine {
     // short tail (shortlist, re-score, argmin, fetch) and the host work of this case proceed beside it
     hipEvent_t search_done = nullptr;
     bool search_done_recorded = false;
+    // recorded on `stream` behind the last copy of a sharded level's exchange (export kernels, collectives, records to
+    // pinned memory): mm_engine_wait_exchange orders another engine's next launch behind the whole level
+    hipEvent_t tail_done = nullptr;
+    bool tail_done_recorded = false;
     Buf host_pts, host_lvl;   // pinned staging: point pool / level (+ results)
     Buf host_pof;             // pinned: job -> pair map of a sharded level (WithinPlan::upload_pair_of_job)
     hipEvent_t pof_done = nullptr; bool pof_busy = false;   // its upload in flight

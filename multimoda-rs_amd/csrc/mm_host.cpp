@@ -305,6 +305,8 @@ struct WithinPlan {
     }
     int upload_pair_of_job(size_t l);
     int search_sharded(Comm* c);
+    int search_sharded_begin(Comm* c);
+    int search_sharded_end(Comm* c);
     int prepare();
     int build_sets_host(int32_t n_sets);
     int build_sets_device(int32_t n_sets);
@@ -315,6 +317,10 @@ struct WithinPlan {
     int level_export_cost(size_t l, double* cost_dev);
     int level_export_keys(size_t l, const double* gcost_dev, long long* keys_dev);
     int level_commit_dev(size_t l, const double* gcost_dev, const long long* keys_dev);
+    int level_copy_records(const double* gcost_dev, const long long* keys_dev);
+    int level_commit_records(size_t l);
+    int exchange_enqueue(Comm* c, size_t l);
+    bool xchg_pending = false;        // search_sharded_begin has enqueued level 0's exchange
     void build_level_pairs(size_t l, const std::vector<double>& centres, const std::vector<uint8_t>& take,
                            std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out);
     int search();
@@ -566,8 +572,9 @@ int WithinPlan::upload_pair_of_job(size_t l)
     if (!d_pair_of_job) {
         if (int arc = e->blob_alloc((void**)&d_pair_of_job, (size_t)std::max(J, 1) * 4, &pof_cap)) return arc;
     }
-    const hipError_t hc = hipMemcpyAsync(d_pair_of_job, h, (size_t)J * 4, hipMemcpyHostToDevice, plan.stream);
-    if (hc != hipSuccess) return hip_error(hc, "hipMemcpyAsync(pair_of_job)");
+    // (the 256-thread copy kernel, not hipMemcpyAsync: behind a stream wait the runtime's copy is a 512-thread blit)
+    const hipError_t hc = launch_copy_small(d_pair_of_job, h, (size_t)J * 4, plan.stream);
+    if (hc != hipSuccess) return hip_error(hc, "copy(pair_of_job)");
     if (!e->pof_done && hipEventCreateWithFlags(&e->pof_done, hipEventDisableTiming) != hipSuccess) e->pof_done = nullptr;
     if (e->pof_done && hipEventRecord(e->pof_done, plan.stream) == hipSuccess) e->pof_busy = true;
     else (void)hipStreamSynchronize(plan.stream);
@@ -644,16 +651,36 @@ int WithinPlan::level_export_keys(size_t l, const double* gcost_dev, long long* 
 
 int WithinPlan::level_commit_dev(size_t l, const double* gcost_dev, const long long* keys_dev)
 {
+    if (int rc = level_copy_records(gcost_dev, keys_dev)) return rc;
+    return level_commit_records(l);
+}
+
+// reduced records -> pinned host memory (the engine's level staging buffer: free between stage_level and fetch),
+// enqueued on the plan's stream behind the collectives; Engine::tail_done marks the end of the level's device work
+int WithinPlan::level_copy_records(const double* gcost_dev, const long long* keys_dev)
+{
     const int J = (int)job_geom.size();
     if (J == 0) return MM_OK;
-    // reduced records -> pinned host memory (the engine's level staging buffer: free between stage_level and fetch)
     const size_t o_keys = ((size_t)J * 8 + 255) / 256 * 256;
     int rc = e->ensure(e->host_lvl, o_keys + (size_t)J * 24, true);
     if (rc) return rc;
     unsigned char* hp = (unsigned char*)e->host_lvl.p;
     hipError_t he = launch_copy_small(hp, gcost_dev, (size_t)J * 8, plan.stream);
     if (he == hipSuccess) he = launch_copy_small(hp + o_keys, keys_dev, (size_t)J * 24, plan.stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(plan.stream);
+    if (he != hipSuccess) return hip_error(he, "exchange records D2H");
+    if (!e->tail_done && hipEventCreateWithFlags(&e->tail_done, hipEventDisableTiming) != hipSuccess) e->tail_done = nullptr;
+    e->tail_done_recorded = e->tail_done && hipEventRecord(e->tail_done, plan.stream) == hipSuccess;
+    return MM_OK;
+}
+
+// wait for the records, decode them and commit the level (identical on every rank)
+int WithinPlan::level_commit_records(size_t l)
+{
+    const int J = (int)job_geom.size();
+    if (J == 0) return MM_OK;
+    const size_t o_keys = ((size_t)J * 8 + 255) / 256 * 256;
+    unsigned char* hp = (unsigned char*)e->host_lvl.p;
+    const hipError_t he = hipStreamSynchronize(plan.stream);
     if (he != hipSuccess) return hip_error(he, "exchange records D2H");
     const double* h_gcost = (const double*)hp;
     const long long* h_keys = (const long long*)(hp + o_keys);
@@ -714,7 +741,7 @@ int comm_all_reduce_min(Comm* c, void* dev, int64_t n, bool is_f64, hipStream_t 
 int comm_rank(const Comm* c);
 int comm_world(const Comm* c);
 
-int WithinPlan::search_sharded(Comm* c)
+int WithinPlan::exchange_enqueue(Comm* c, size_t l)
 {
     // MM_SHARD_REHEARSAL=1 (timing only, bench.py's MM_BENCH_REHEARSE_WORLD): one process plays a rank of a larger job on
     // a world = 1 communicator -- the reduced records then hold this rank's tile alone, the result is not an alignment
@@ -727,16 +754,42 @@ int WithinPlan::search_sharded(Comm* c)
         if (int rc = e->blob_alloc((void**)&d_xrec, o_keys + (size_t)std::max(J, 1) * 24, &xrec_cap)) return rc;
     double* xc = (double*)d_xrec;
     long long* xk = (long long*)(d_xrec + o_keys);
+    int rc;
+    if (launched_level != (int)l && (rc = level_launch(l))) return rc;   // (level 0 may have been queued early)
+    if ((rc = level_export_cost(l, xc))) return rc;
+    if (J > 0 && (rc = comm_all_reduce_min(c, xc, J, true, plan.stream))) return rc;
+    if (J > 0 && (rc = level_export_keys(l, xc, xk))) return rc;
+    if (J > 0 && (rc = comm_all_reduce_min(c, xk, 3 * (int64_t)J, false, plan.stream))) return rc;
+    return level_copy_records(xc, xk);
+}
+
+// Level 0 up to and including the copy of the reduced records, all enqueued, nothing waited for: a driver that aligns
+// independent cases back to back queues the NEXT case's launch behind this (mm_engine_wait_exchange) before it
+// collects this one -- the device goes from this level's last copy straight into the next launch, and no collective
+// ever runs beside a long kernel.
+int WithinPlan::search_sharded_begin(Comm* c)
+{
+    if (xchg_pending) return set_error(MM_ERR_INVALID, "search_sharded_begin called twice");
+    if (levels.empty()) return MM_OK;
+    if (int rc = exchange_enqueue(c, 0)) return rc;
+    xchg_pending = true;
+    return MM_OK;
+}
+
+int WithinPlan::search_sharded_end(Comm* c)
+{
     for (size_t l = 0; l < levels.size(); ++l) {
         int rc;
-        if (launched_level != (int)l && (rc = level_launch(l))) return rc;   // (level 0 may have been queued early)
-        if ((rc = level_export_cost(l, xc))) return rc;
-        if (J > 0 && (rc = comm_all_reduce_min(c, xc, J, true, plan.stream))) return rc;
-        if (J > 0 && (rc = level_export_keys(l, xc, xk))) return rc;
-        if (J > 0 && (rc = comm_all_reduce_min(c, xk, 3 * (int64_t)J, false, plan.stream))) return rc;
-        if ((rc = level_commit_dev(l, xc, xk))) return rc;
+        if (!(l == 0 && xchg_pending) && (rc = exchange_enqueue(c, l))) return rc;
+        xchg_pending = false;
+        if ((rc = level_commit_records(l))) return rc;
     }
     return MM_OK;
+}
+
+int WithinPlan::search_sharded(Comm* c)
+{
+    return search_sharded_end(c);     // (after search_sharded_begin: collects level 0 and runs the remaining levels)
 }
 
 int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
@@ -1329,6 +1382,14 @@ int mm_within_plan_search_sharded(mm_within_plan* h, mm_comm* ch)
     if (!wp || !ch) return set_error(MM_ERR_INVALID, "within plan / communicator == NULL");
     if (int drc = select_device(wp->e)) return drc;
     return wp->search_sharded(reinterpret_cast<Comm*>(ch));
+}
+
+int mm_within_plan_search_sharded_begin(mm_within_plan* h, mm_comm* ch)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || !ch) return set_error(MM_ERR_INVALID, "within plan / communicator == NULL");
+    if (int drc = select_device(wp->e)) return drc;
+    return wp->search_sharded_begin(reinterpret_cast<Comm*>(ch));
 }
 
 int mm_within_plan_run_sharded(mm_within_plan* h, mm_comm* ch, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)

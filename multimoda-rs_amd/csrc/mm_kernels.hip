@@ -325,8 +325,12 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
                 for (int r = 0; r < R; ++r) {
                     const T v = lane_min16(rmin[r]);
                     // process_utils.rs:112-114: `if min_sq.is_finite() && min_sq > local_max_sq` -- a point whose
-                    // distances are all inf / NaN (non-finite coordinates) does not take part in the maximum
-                    rowmax = (v > rowmax && v < TT::inf()) ? v : rowmax;
+                    // distances are all inf / NaN (non-finite coordinates) does not take part in the maximum.
+                    // Only where the value IS the reference's (EXACT): in a screen an inf is an f32 overflow of a
+                    // finite distance and must stay inf -- dropping it would understate the candidate's cost and
+                    // could shortlist past the true minimum.
+                    if constexpr (EXACT) rowmax = (v > rowmax && v < TT::inf()) ? v : rowmax;
+                    else rowmax = v > rowmax ? v : rowmax;
                 }
             }
             __syncthreads();  // S2: all column minima are in LDS
@@ -335,7 +339,8 @@ k_search(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work,
             T m = rowmax;
             for (int j = tid; j < nb; j += NT) {
                 const T v = TT::from(s_colmin[j]);
-                m = (v > m && v < TT::inf()) ? v : m;
+                if constexpr (EXACT) m = (v > m && v < TT::inf()) ? v : m;
+                else m = v > m ? v : m;
             }
             m = wave_max(m);
             if ((tid & 63) == 0) atomicMax(&s_red[0], TT::bits(m));

@@ -200,6 +200,56 @@ def search_device(plan, group=None):
         plan.level_commit_dev(l, b.cost.data_ptr(), b.keys.data_ptr())
 
 
+_checked_groups = set()
+
+
+def first_search_pending(group=None) -> bool:
+    """True until the first sharded search of this process on `group` has been cross-checked (MM_EXCHANGE_CHECK=0: never)."""
+    return os.environ.get("MM_EXCHANGE_CHECK", "1") != "0" and (group if group is not None else "default") not in _checked_groups
+
+
+def search_checked(plan, group=None, mode="rccl"):
+    """The FIRST sharded search of a process group runs the chosen on-device exchange (``rccl``: the library's
+    communicator, ``device``: torch's all-reduces) AND the gather exchange on every level, and compares them job by job
+    -- reduced cost, first index of minimal cost, decided flag -- before it commits: a transport that reduces wrongly
+    (in-place MIN on int64 / f64 records, stream ordering) fails here, loudly, not in a later alignment.
+    Costs one all_gather per level, once."""
+    import torch
+    n_jobs, n_levels, tol = plan.dims()
+    b = _buffers(plan, n_jobs)
+    comm = native_comm(group) if mode == "rccl" else None
+    begun = bool(getattr(plan, "_begun", False))
+    plan._begun = False
+    for l in range(n_levels):
+        if not (begun and l == 0):
+            plan.level_launch(l)
+        local = plan.level_collect(l, n_jobs)
+        ok_g, _angle_g, idx_g, cost_g = merge_level(local, tol, group)
+        plan.level_export_cost(l, b.cost.data_ptr())
+        if comm is not None:
+            comm.all_reduce_min_f64(b.cost.data_ptr(), n_jobs, plan.engine.stream)
+        else:
+            _all_reduce_min(b.cost, group, b.stream)
+        plan.level_export_keys(l, b.cost.data_ptr(), b.keys.data_ptr())
+        if comm is not None:
+            comm.all_reduce_min_i64(b.keys.data_ptr(), 3 * n_jobs, plan.engine.stream)
+        else:
+            _all_reduce_min(b.keys, group, b.stream)
+        plan.engine.synchronize()
+        torch.cuda.synchronize()
+        cost_d = b.cost[:n_jobs].cpu().numpy()
+        keys_d = b.keys[:3 * n_jobs].cpu().numpy()
+        act = local["active"] != 0
+        fin = act & np.isfinite(cost_g)
+        lo, hi = keys_d[n_jobs:2 * n_jobs], ~keys_d[2 * n_jobs:3 * n_jobs]
+        if not (np.array_equal(cost_d[act], cost_g[act]) and np.array_equal(keys_d[:n_jobs][fin], idx_g[fin].astype(np.int64))
+                and np.array_equal((lo == hi)[fin], ok_g[fin] != 0)):
+            raise RuntimeError(f"sharded search: the '{mode}' exchange and the gather exchange disagree on level {l} "
+                               f"(first search of this process group; set MM_EXCHANGE=gather to run without the device exchange)")
+        plan.level_commit_dev(l, b.cost.data_ptr(), b.keys.data_ptr())
+    _checked_groups.add(group if group is not None else "default")
+
+
 def search_inprocess(plans: Sequence):
     """`world` shard plans of ONE process driven in lockstep with the device exchange, the all-reduces
     replaced by element-wise minima over the plans' device records (tests: the kernels, the key encoding

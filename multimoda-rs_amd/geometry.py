@@ -290,6 +290,11 @@ class WithinPlan:
                 "mm_within_plan_set_shard_grid")
         self.shard = (int(rank), int(pair_blocks), int(cand_slices))
 
+    def search_sharded_begin(self, comm: "N.Comm"):
+        """Level 0 of the sharded search enqueued up to the copy of the reduced records, nothing waited for
+        (``mm_within_plan_search_sharded_begin``); ``search_sharded`` collects."""
+        N.check(N.lib().mm_within_plan_search_sharded_begin(self._h, comm.handle), "mm_within_plan_search_sharded_begin")
+
     def search_sharded(self, comm: "N.Comm"):
         """The sharded search with the exchange inside the library: per level launch -> export -> ncclAllReduce(MIN)
         x 2 on the engine's stream -> commit (``mm_within_plan_search_sharded``)."""
@@ -381,6 +386,8 @@ class WithinPlan:
         from . import distributed as D
         if D.world_size(group) > 1:
             mode = D.exchange_mode(group)
+            if mode in ("rccl", "device") and D.first_search_pending(group):
+                return D.search_checked(self, group, mode)
             if mode == "rccl":
                 return self.search_sharded(D.native_comm(group))
             if mode == "device":

@@ -159,10 +159,17 @@ def read_contour_data(path: str, with_aortic: bool = False):
     if fast is not None:
         return (fast, np.zeros(fast.shape[0], dtype=bool)) if with_aortic else fast
     rows, flags = [], []
+    width = None
     with open(path, "r", newline="") as f:
         for rec in csv.reader(f, delimiter=delim):
             if not rec:
                 continue                                   # the csv crate skips empty lines
+            # csv::ReaderBuilder's default is flexible(false): a record whose field count differs from the FIRST
+            # record's is Err(UnequalLengths) -> "Skipping invalid row" (input.rs:191), whatever it holds
+            if width is None:
+                width = len(rec)
+            elif len(rec) != width:
+                continue
             r = _parse_contour_row(rec)
             if r is not None:
                 rows.append(r[:4]); flags.append(r[4])

@@ -57,10 +57,15 @@ def _delimiter(path):
 
 def read_contour_data(path):
     pts = []
+    first_len = None
     with open(path, "r", newline="") as fh:
         for row in csv.reader(fh, delimiter=_delimiter(path)):
             if not row:
                 continue                                              # the csv crate skips empty lines
+            if first_len is None:                                     # csv::ReaderBuilder: flexible(false) -- a record of
+                first_len = len(row)                                  # another length than the first is an Err row,
+            if len(row) != first_len:                                 # "Skipping invalid row" (input.rs:191)
+                continue
             p = _parse_point(row)
             if p is not None:                                         # "Skipping invalid record" (input.rs:186-190)
                 pts.append(p)

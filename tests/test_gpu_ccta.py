@@ -154,6 +154,24 @@ def test_find_points_by_cl_region_matches_oracle(engine, mm, occ, n_pts, seed):
         assert (got[3] >= 3).any()                                # the clean-ups moved something
 
 
+def test_find_points_by_cl_region_single_frame_follows_the_reference(engine, mm, occ):
+    """One frame: scale_coronary.rs:268-272 divides 0.0 by 0 -> NaN radius, no centerline point is in
+    range, every point is proximal or distal relative to that frame's centroid, then the two clean-ups.  No frames at
+    all: the reference panics (usize underflow) -> an error here."""
+    cl, pts = _vessel(mm, 900, 5)
+    xyz = cl.xyz()
+    cen = xyz[len(xyz) // 2: len(xyz) // 2 + 1] + 0.05
+    got = mm.find_points_by_cl_region(cl, cen, pts, engine=engine, return_labels=True)
+    exp = occ.find_points_by_cl_region(to_oracle_cl(ocl_mod(), cl), cen, pts)
+    assert np.array_equal(got[3], exp[3])
+    for a, b in zip(got[:3], exp[:3]):
+        assert np.array_equal(a, b)
+    assert not (got[3] == 2).any()                               # nothing is "between" by the first pass
+    assert len(got[0]) + len(got[1]) + len(got[2]) == 900
+    with pytest.raises(RuntimeError):
+        mm.find_points_by_cl_region(cl, np.zeros((0, 3)), pts, engine=engine)
+
+
 def ocl_mod():
     from oracle import oracle_cl
     oracle_cl.lib()

@@ -159,6 +159,33 @@ def test_non_finite_coordinates_follow_the_reference(engine, oracle, mm, n):
             assert bi >= 0 and ba == o_angle and bc == o_cost, prec
 
 
+@pytest.mark.parametrize("scale", [1e17, 3e18, 1e19, 1e25, 1e30, 1e38, 1e-14, 1e-16, 1e-20, 1e-30])
+def test_coordinates_beyond_the_f32_range_of_the_screens(engine, oracle, mm, scale):
+    """Finite coordinates whose squared distances overflow (or underflow) f32: a screen must not drop an
+    overflowed row (that would understate the candidate and could shortlist past the true first minimum); sets beyond
+    what f32 holds take the exact f64 kernel.  One far outlier in an otherwise mm-sized set as well.  Winner, angle
+    and cost against the oracle at all four precisions."""
+    rng = np.random.default_rng(11)
+    n = 300
+    ref, tgt = blob(rng, n), blob(rng, n)
+    angles, _, _ = mm.search_angles(1.0, 45.0)
+    idx = np.arange(n)[:, None]
+    cases = [(ref * scale, tgt * scale)]
+    if scale > 1:
+        cases.append((np.where(idx == 5, ref * scale, ref), tgt))
+        cases.append((ref, np.where(idx == 9, tgt * scale, tgt)))
+    for r, t in cases:
+        c = t.mean(axis=0) if np.isfinite(t.mean(axis=0)).all() else np.zeros(2)
+        centre = (float(c[0]), float(c[1]))
+        oc = oracle.costs_over_angles(r, t, angles, centre[0], centre[1])
+        assert np.isfinite(oc).all()
+        want = int(np.argmin(oc))
+        assert engine.hausdorff(r, t) == oracle.hausdorff(r, t)
+        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+            bi, ba, bc = engine.best_rotation(r, t, angles, centre, skip_zero=True, precision=prec)
+            assert bi == want and ba == angles[want] and bc == oc[want], (prec, scale)
+
+
 @pytest.mark.parametrize("what", [np.nan, np.inf])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_chain_with_non_finite_points_equals_the_oracle_chain(engine, oracle, mm, mode, what):

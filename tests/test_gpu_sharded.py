@@ -151,6 +151,41 @@ def test_native_rccl_search_world1(engine, oracle, mm, bruteforce, step, rng_deg
         comm.close()
 
 
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES)
+def test_chained_cases_over_two_engines_native_comm(oracle, mm, bruteforce, step, rng_deg, ss):
+    """The driver's back-to-back flow over the library's communicator (bench.py at N > 1): case k's whole exchange is
+    enqueued (search_sharded_begin), case k+1's launch is ordered behind it on another engine (Engine.wait_exchange +
+    level_launch) BEFORE case k is collected.  Five cases over two engines; every case ends with the oracle's result."""
+    comm = mm.Comm(mm.Comm.unique_id(), 0, 1)
+    engs = [mm.Engine(), mm.Engine()]
+    try:
+        cases = [[mm.synthetic_pullback(f, 501, pullback_id=i, seed=k) for i, f in enumerate((9, 6, 7))] for k in range(5)]
+        want = []
+        for c in cases:
+            og = [to_oracle(oracle, g) for g in c]
+            want.append(([oracle.align_within_chain(o, step, rng_deg, bruteforce, ss, n_threads=8) for o in og], og))
+        plans = [None] * len(cases)
+        mk = lambda k: mm.WithinPlan(engs[k % 2], cases[k], step, rng_deg, bruteforce, ss, precision=mm.MM_PRECISION_F32_FAST)
+        plans[0] = mk(0)
+        plans[0].level_launch(0)
+        for k in range(len(cases)):
+            plans[k].search_sharded_begin(comm)
+            if k + 1 < len(cases):
+                plans[k + 1] = mk(k + 1)
+                engs[(k + 1) % 2].wait_exchange(engs[k % 2])
+                plans[k + 1].level_launch(0)
+            plans[k].search_sharded(comm)
+            logs, _ev, unres = plans[k].walk()
+            plans[k].close()
+            assert unres == 0
+            for g, lg, ol, o in zip(cases[k], logs, want[k][0], want[k][1]):
+                assert lg == ol and geoms_equal(g, o), k
+    finally:
+        for e in engs:
+            e.close()
+        comm.close()
+
+
 @pytest.mark.parametrize("exchange", ["gather", "device"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_cross_shard_ties_fall_back_to_chain_state(engine, oracle, mm, world, exchange):

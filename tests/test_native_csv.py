@@ -108,13 +108,15 @@ def test_rows_the_reference_skips_are_skipped(io, tmp_path, row):
                                      ("5,1E2,-2e-1,3", [5.0, 100.0, -0.2, 3.0]), ("5,inf,2,3", [5.0, np.inf, 2.0, 3.0]),
                                      ("5,1,2,3,true", [5.0, 1.0, 2.0, 3.0]), ("5,1,2,3,false", [5.0, 1.0, 2.0, 3.0])])
 def test_rows_the_reference_accepts_are_kept(io, tmp_path, row, exp):
-    got = io.read_contour_data(_write(tmp_path, "7,1.5,2.5,3.5\n" + row + "\n"))
+    # (the first record has the row's field count: csv::ReaderBuilder is not flexible, see the width test below)
+    first = "7,1.5,2.5,3.5,false\n" if row.count(",") == 4 else "7,1.5,2.5,3.5\n"
+    got = io.read_contour_data(_write(tmp_path, first + row + "\n"))
     assert got.shape == (2, 4) and np.array_equal(got[1], np.array(exp))
 
 
 def test_fifth_column_is_the_aortic_flag(io, tmp_path):
     arr, flags = io.read_contour_data(_write(tmp_path, "1,1,2,3,true\n1,2,3,4,false\n1,3,4,5\n"), with_aortic=True)
-    assert arr.shape == (3, 4) and flags.tolist() == [True, False, False]
+    assert arr.shape == (2, 4) and flags.tolist() == [True, False]      # the 4-field row is of another width: skipped
 
 
 def test_reference_point_first_record_must_parse(io, tmp_path):
@@ -143,3 +145,29 @@ def test_aortic_flags_follow_their_points_through_the_builder(io, tmp_path):
     fl = g.meta["lumen_aortic"]
     assert fl.shape[0] == g.lumen.shape[0] == 24
     assert np.array_equal(fl, g.lumen[:, 0] > 4.5)
+
+
+def test_rows_of_another_width_than_the_first_record_are_skipped(io, tmp_path):
+    """input.rs:172-194: csv::ReaderBuilder with its default flexible(false) -- a record whose field count differs from
+    the FIRST record's is Err(UnequalLengths) and skipped ("Skipping invalid row"), even if it would deserialize
+    (ADVICE r2 #2).  Expected rows worked out by hand; the independent reader of tests/refbuild.py must agree."""
+    import refbuild
+    mio = io
+    cases = {
+        # 4-field file with one valid 5-field row: that row is dropped
+        "a.csv": ("1,1.0,2.0,3.0\n1,1.5,2.5,3.0,true\n2,4.0,5.0,6.0\n", [(1, 1.0, 2.0, 3.0, False), (2, 4.0, 5.0, 6.0, False)]),
+        # 5-field file with 4-field rows: only the 5-field rows stay
+        "b.csv": ("1,1.0,2.0,3.0,true\n1,1.5,2.5,3.0\n2,4.0,5.0,6.0,false\n", [(1, 1.0, 2.0, 3.0, True), (2, 4.0, 5.0, 6.0, False)]),
+        # the first record decides even if it does not deserialize itself: three fields -> every 4-field row is skipped
+        "c.csv": ("junk,1,2\n1,1.0,2.0,3.0\n2,4.0,5.0,6.0\n", []),
+        # empty lines do not count as records
+        "d.csv": ("\n1,1.0,2.0,3.0\n\n2,4.0,5.0\n3,7.0,8.0,9.0\n", [(1, 1.0, 2.0, 3.0, False), (3, 7.0, 8.0, 9.0, False)]),
+    }
+    for name, (text, want) in cases.items():
+        p = tmp_path / name
+        p.write_text(text)
+        arr, flags = mio.read_contour_data(str(p), with_aortic=True)
+        got = [(int(r[0]), r[1], r[2], r[3], bool(f)) for r, f in zip(arr, flags)]
+        assert got == want, name
+        ref = [(q["frame"], q["x"], q["y"], q["z"], q["aortic"]) for q in refbuild.read_contour_data(str(p))]
+        assert ref == want, name

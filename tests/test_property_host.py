@@ -58,7 +58,8 @@ def test_reader_and_builder_equal_the_independent_builder(built, mm, tmp_path_fa
             x, y = 4.5 + r * math.cos(a) + 0.05 * rng.standard_normal(), 4.4 + 0.8 * r * math.sin(a) + 0.05 * rng.standard_normal()
             rows.append(sep.join([str(f), _fmt(rng, x), _fmt(rng, y), zs]))
     order = rng.permutation(len(rows)) if rng.integers(0, 2) else np.arange(len(rows))    # rows of a frame need not be adjacent
-    junk = ["", sep.join(["x", "1", "2", "3"]), sep.join(["7.0", "1", "2", "3"]), sep.join(["3", "1", "2"])]
+    junk = ["", sep.join(["x", "1", "2", "3"]), sep.join(["7.0", "1", "2", "3"]), sep.join(["3", "1", "2"]),
+            sep.join(["3", "1", "2", "3", "true"])]     # a valid 5-field record in a 4-field file: another width than the first row's
     lines = [rows[i] for i in order]
     for j in junk:                                                 # rows the reader must skip, anywhere but first
         lines.insert(int(rng.integers(1, len(lines) + 1)), j)

@@ -103,7 +103,11 @@ def test_rows_the_reference_reader_skips(tmp_path):
     p = tmp_path / "c.csv"
     p.write_text("1,1.0,2.0,3.0\n1.0,1.0,2.0,3.0\n2,1e0,2.5,3\n 3,1,2,3\n4,1_0,2,3\n5,1,2,3,true\n6,1,2,3,maybe\n7,1,2\n8,1,2,3abc\n")
     rows = refbuild.read_contour_data(str(p))
-    assert [(r["frame"], r["x"], r["aortic"]) for r in rows] == [(1, 1.0, False), (2, 1.0, False), (5, 1.0, True)]
+    # (row 5 would deserialize, but has another field count than the first record: csv::ReaderBuilder is not flexible)
+    assert [(r["frame"], r["x"], r["aortic"]) for r in rows] == [(1, 1.0, False), (2, 1.0, False)]
+    p.write_text("5,1,2,3,true\n6,1,2,3,maybe\n7,1.5,2,3,false\n8,1,2,3\n")
+    rows = refbuild.read_contour_data(str(p))
+    assert [(r["frame"], r["x"], r["aortic"]) for r in rows] == [(5, 1.0, True), (7, 1.5, False)]
 
 
 def test_native_builder_equals_python_builder_with_extras_and_ragged_input(mm, monkeypatch):
