@@ -185,26 +185,36 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
     return [out[k] for k in ks]
 
 
-def committed_traffic(workload, precision):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/, tools/gpu_pmc.sh): FETCH_SIZE + WRITE_SIZE in KiB, raw (on gfx950 FETCH_SIZE can
-    under-report wide streaming reads by up to 2x; these are dword loads, uncalibrated).  bench.py
-    cannot run the profiler itself, so this is null unless a matching profile is committed."""
-    name = {("config3", "fast"): "r2_config3_fast_pmc_summary.csv", ("config3", "f32"): "r1_config3_pmc_summary.csv"}.get(
-        (workload, precision))
-    path = os.path.join(ROOT, "profiles", name) if name else None
-    if not path or not os.path.exists(path):
+def committed_pmc(workload, precision):
+    """Figures of the dominant kernel's big launch from the committed rocprofv3 --pmc passes (profiles/, tools/gpu_pmc.sh;
+    bench.py cannot run the profiler itself): HBM bytes per launch (FETCH_SIZE + WRITE_SIZE in KiB, raw -- on gfx950
+    FETCH_SIZE can under-report wide streaming reads by up to 2x; these are dword loads, uncalibrated) and the quantity
+    that actually saturates: VALU issue.  None where no matching profile is committed."""
+    names = {("config3", "fast"): ["r3_config3_fast_pmc_summary.csv", "r2_config3_fast_pmc_summary.csv"],
+             ("config3", "f32"): ["r1_config3_pmc_summary.csv"]}.get((workload, precision), [])
+    path = next((os.path.join(ROOT, "profiles", n) for n in names if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    if not path:
         return None
     import csv
-    tot, grid = {}, 0
+    val, dur, grid = {}, {}, 0
     for r in csv.DictReader(open(path)):
-        if r["kernel"].startswith(("k_screen_fast", "k_search<float")) and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if r["kernel"].startswith(("k_screen_fast", "k_search<float")):
             g = int(r["grid_threads"])
             if g >= grid:
                 if g > grid:
-                    tot, grid = {}, g
-                tot[r["counter"]] = float(r["mean_value"]) * 1024.0
-    return sum(tot.values()) if len(tot) == 2 else None
+                    val, dur, grid = {}, {}, g
+                val[r["counter"]] = float(r["mean_value"])
+                dur[r["counter"]] = float(r.get("mean_duration_ns") or 0.0)
+    out = {"source": "profiles/" + os.path.basename(path), "grid_threads": grid}
+    if "FETCH_SIZE" in val and "WRITE_SIZE" in val:
+        out["traffic"] = (val["FETCH_SIZE"] + val["WRITE_SIZE"]) * 1024.0
+    if "GRBM_GUI_ACTIVE" in val and "SQ_INSTS_VALU" in val:
+        cycles = val["GRBM_GUI_ACTIVE"] / 8.0                     # summed over the 8 XCDs
+        out["valu_clk_per_instr"] = cycles / (val["SQ_INSTS_VALU"] / 1024.0)      # per SIMD (256 CUs x 4)
+        out["valu_instr_per_launch"] = val["SQ_INSTS_VALU"]
+        if dur.get("GRBM_GUI_ACTIVE"):
+            out["achieved_clock_ghz"] = cycles / dur["GRBM_GUI_ACTIVE"]
+    return out
 
 
 def cpu_baseline(cfg, geoms, threads, budget_s=10.0):
@@ -259,7 +269,8 @@ class Runner:
     device, level 0 staged), search(k) (all levels: local search -> exchange -> commit) and finish(k) (chain walk,
     AB|CD and AC|BD between alignments).  Step k lives on engine k % len(engs) and works on its own copy of the case."""
 
-    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases, rehearse=0, grid=None, comm=None, lazy_until=0):
+    def __init__(self, mm, engs, base, cfg, prec, mode, rank, world, ext, n_cases, rehearse=0, grid=None, comm=None, lazy_until=0, bruteforce=True):
+        self.bruteforce = bruteforce
         self.mm, self.engs, self.cfg, self.prec, self.mode, self.rank, self.world, self.ext = mm, engs, cfg, prec, mode, rank, world, ext
         self.rehearse = rehearse           # > 1: this process plays rank 0 of `rehearse` ranks without peers (timing only)
         self.grid = grid                   # (pair_blocks, cand_slices) of the shard grid (N > 1 / rehearsal)
@@ -286,8 +297,8 @@ class Runner:
         if self.cases[k] is None:
             self.cases[k] = [g.copy() for g in self.base]
         t0 = time.perf_counter()
-        self.plans[k] = mm.WithinPlan(self.engs[k % len(self.engs)], self.cases[k], cfg["step_deg"], cfg["range_deg"], True,
-                                      cfg["sample_size"], precision=self.prec,
+        self.plans[k] = mm.WithinPlan(self.engs[k % len(self.engs)], self.cases[k], cfg["step_deg"], cfg["range_deg"],
+                                      self.bruteforce, cfg["sample_size"], precision=self.prec,
                                       shard=(self.rank, *self.grid) if self.world > 1 else
                                       ((0, *self.grid) if self.rehearse > 1 else None))
         self.stage_s += time.perf_counter() - t0
@@ -501,7 +512,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0].item())
 
-    def timed_leg(prec, warmup, steps, pipe, resident=False):
+    def timed_leg(prec, warmup, steps, pipe, resident=False, cfg=cfg, bruteforce=True):
         """W untimed + K timed steps of one precision.  Inside the timed region: K stagings (raw pullbacks ->
         HBM -> search sets), K searches, K finishes.  The pipeline is primed before it (the first LOOK cases are
         staged during set-up / warm-up), so the stagings in the region are those of steps W+LOOK .. W+K+LOOK-1:
@@ -521,7 +532,7 @@ def main():
         warmup += ramp
         n_total = warmup + steps
         r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK, rehearse, grid, rehearse_comm,
-                   lazy_until=warmup - 1 if ramp else 0)
+                   lazy_until=warmup - 1 if ramp else 0, bruteforce=bruteforce)
         for k in range(n_total if resident else LOOK):
             r.stage(k)                                   # priming (setup, untimed)
         stage_fn = None if resident else r.stage
@@ -553,6 +564,87 @@ def main():
         r.close()
         return dict(ramp=ramp, dt=reduce_max(dt), results=results, evals=sum(x[2] for x in results), unresolved=sum(x[3] for x in results),
                     prof=prof, last_case=last_case, stage_ms=stage_ms, staged=r.staged)
+
+    def ladder_leg():
+        """The reference's DEFAULT search (bruteforce=False: coarse -> fine, dependent levels, align_within.rs:193-247) on the
+        same pullbacks with its default grid (0.5 deg, +-90 deg: a 1 deg pass, then +-5 deg at 0.5 deg = 202 evaluations per
+        frame pair): whole steps like the headline (stage, search: two dependent launches, chain walk, between alignments)."""
+        try:
+            lcfg = dict(cfg, step_deg=0.5, range_deg=90.0)
+            k = max(args.steps, 10)
+            leg = timed_leg(PREC, 2, k, pipelined, cfg=lcfg, bruteforce=False)
+            lms, lpe, lprof, _ = leg["prof"]
+            dom = dominant_launch(lms, lpe)
+            # the oracle's ladder chain on the first 64 frames of pullback 0 (a chain's first steps do not depend on the rest)
+            from oracle import oracle as orc
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import to_oracle  # type: ignore
+            head = mm.synthetic_pullback(64, cfg["points"], pullback_id=0)
+            same_inputs = bool(np.array_equal(head.lumen, base[0].lumen[:head.lumen.shape[0]]))
+            ol = orc.align_within_chain(to_oracle(orc, head), 0.5, 90.0, False, cfg["sample_size"], n_threads=min(16, os.cpu_count() or 1))
+            got = list(leg["results"][-1][0][0])[:63]
+            return {"value": leg["evals"] / leg["dt"], "unit": "pose-evals/s (the reference's evaluation count: 202 per frame pair)",
+                    "ms_per_step": leg["dt"] / k * 1e3, "steps": k, "pose_evals_per_step": leg["evals"] // k,
+                    "grid": "bruteforce=False, 0.5 deg x +-90 deg (levels: 1 deg x +-90, 0.5 deg x +-5 around the level-1 winner)",
+                    "chain_steps_researched_on_chain_state": leg["unresolved"],
+                    "dominant_launch": dom, "kernel": "mm::k_screen_fast<33, false> (level 0: 181 candidates per pair)",
+                    "identical_to_oracle_first_63_chain_steps_of_pullback_0": bool(same_inputs and got == list(ol)),
+                    "note": "two dependent launches per step (the second level's candidate lists depend on the first level's "
+                            "winners: one host round trip between them); the full-size oracle comparison runs in "
+                            "tests/test_gpu_fullsize.py"}
+        except Exception as ex:
+            return {"error": f"{type(ex).__name__}: {ex}"}
+
+    def extension_leg():
+        """EXTENSION grid (absent from the reference's 4-phase path; BASELINE config 3's "~720 x 100 candidates"):
+        every frame against the 100 frames of a +-50 window x 721 rotations, 4 x 512 frames, as extra set pairs through
+        the same primitive.  One brute-force step (one launch of ~3 s) and one step through the bounded search."""
+        try:
+            ecfg = WORKLOADS["config3ext"]
+            lo, hi = ecfg["shift"]
+            eng = engs[0]
+            out = {}
+            res = {}
+            for name, prec in (("bruteforce", mm.MM_PRECISION_F32_FAST), ("bounded", mm.MM_PRECISION_F32_BOUNDED)):
+                srs = mm.ShiftRotationSearch(eng, base, lo, hi, ecfg["step_deg"], ecfg["range_deg"], ecfg["sample_size"], precision=prec)
+                eng.synchronize()
+                eng.profile(True)
+                t0 = time.perf_counter()
+                r = srs.run()
+                dt_ = time.perf_counter() - t0
+                lms, lpe = eng.profile_launches()
+                eng.bound_stats()
+                pr = eng.profile_read()
+                eng.profile(False)
+                res[name] = (r, srs.meta.copy(), srs.pose_evals)
+                srs.close()
+                if name == "bruteforce":
+                    tf = pr["pair_evals"] * FLOPS_PER_PAIR_EVAL / (pr["ms"] * 1e-3) * 1e-12 if pr["ms"] > 0 else 0.0
+                    out.update({"value": srs.pose_evals / dt_, "unit": "pose-evals/s", "ms_per_step": dt_ * 1e3, "steps": 1,
+                                "pose_evals_per_step": srs.pose_evals, "pairs": int(srs.meta.shape[0]), "candidates_per_pair": len(srs.angles),
+                                "roofline": {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "executed_op_frac": tf / FP32_VECTOR_PEAK_TFLOPS * 7.0 / 12.0,
+                                             "kernel": "mm::k_screen_fast<33, false>", "launches": pr["launches"],
+                                             "avg_launch_ms": pr["ms"] / max(pr["launches"], 1)}})
+                else:
+                    out["bounded"] = {"candidates_resolved_per_s": srs.pose_evals / dt_, "ms_per_step": dt_ * 1e3}
+            rb, meta, _ = res["bruteforce"]
+            rq = res["bounded"][0]
+            out["bounded"]["identical_to_bruteforce_result"] = bool(
+                np.array_equal(rb["best_idx"], rq["best_idx"]) and np.array_equal(rb["best_cost"], rq["best_cost"]) and rb["winners"] == rq["winners"])
+            # at shift 0 a pair is a step of the reference's chain: its winner must be the headline's log entry
+            logs = results[-1][0]
+            ok = True
+            for p in np.nonzero(meta[:, 2] == 0)[0]:
+                gi, i = int(meta[p, 0]), int(meta[p, 1])
+                ok = ok and (rb["best_angle"][p] * (180.0 / np.pi) == logs[gi][i - 1][2])
+            out["shift0_winners_identical_to_headline_logs"] = bool(ok)
+            out["note"] = ("EXTENSION axis: not part of the reference's 4-phase path and never folded into `value`; point sets staged "
+                           "before the timed call (the Python-side set construction is set-up); parity of shifted pairs is against the "
+                           "oracle's metric / search (tests/test_gpu_fullsize.py)")
+            return out
+        except Exception as ex:
+            return {"error": f"{type(ex).__name__}: {ex}"}
 
     # setup, not a step: let both engines grow their transient buffers (between stage) now
     if ext is None:
@@ -690,6 +782,9 @@ def main():
                                    "stage_ms_per_step": leg["stage_ms"]}
         except Exception as ex:
             extra["sequential"] = {"error": f"{type(ex).__name__}: {ex}"}
+        if args.workload == "config3":
+            extra["ladder_default"] = ladder_leg()
+            extra["extension_grid"] = extension_leg()
 
     if rank == 0:
         na = nb = cfg["sample_size"] + 20
@@ -697,6 +792,7 @@ def main():
         achieved_tflops = prof["pair_evals"] * FLOPS_PER_PAIR_EVAL / kern_s * 1e-12 if kern_s > 0 else 0.0
         algo_gbs = prof["candidates"] * BYTES_PER_POSE_EVAL(na, nb) / kern_s * 1e-9 if kern_s > 0 else 0.0
         f64_main = args.precision == "f64"
+        pmc = committed_pmc(args.workload, args.precision)
         peak = FP64_VECTOR_PEAK_TFLOPS if f64_main else FP32_VECTOR_PEAK_TFLOPS
         # executed VALU lane-operations per squared distance the reference counts twice (2 x 6 = 12 algorithmic FLOP):
         # fast screen 4 packed-FMA lanes (8 FLOP) + 1 add + 2 min -> 7 issue slots; direct form 8; f64 kernel 7
@@ -754,7 +850,14 @@ def main():
                 "bound": "valu", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak,
                 "executed_op_frac": (achieved_tflops / peak) * exec_per_12 / 12.0 if exec_per_12 else None,
-                "traffic": committed_traffic(args.workload, args.precision),
+                "traffic": (pmc or {}).get("traffic"),
+                # what saturates (committed --pmc passes of the same launch): a SIMD issues one VALU wave-instruction
+                # per 4 clocks at best -> valu_clk_per_instr 4.0 = back-to-back issue; the nominal peak assumes 2.4 GHz
+                "valu_clk_per_instr": (pmc or {}).get("valu_clk_per_instr"),
+                "achieved_clock_ghz": (pmc or {}).get("achieved_clock_ghz"),
+                "frac_at_achieved_clock": ((achieved_tflops / peak) * 2.4 / pmc["achieved_clock_ghz"]
+                                           if pmc and pmc.get("achieved_clock_ghz") else None),
+                "pmc_source": (pmc or {}).get("source"),
                 "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
                            "bounded": "mm::k_screen_lb<5, false>",
                            "f64": "mm::k_search<double,11,16,true,true,3>"}[args.precision], "launches": prof["launches"],
@@ -765,7 +868,11 @@ def main():
                         "the kernel's stream); executed_op_frac = the same launches priced by the lane-operations the kernel "
                         "executes (each squared distance is computed once and serves both directed terms: 7 issue slots "
                         "against 12 algorithmic FLOP); traffic = HBM bytes per launch of the big launch (FETCH_SIZE+WRITE_SIZE, "
-                        "committed rocprofv3 --pmc passes in profiles/)",
+                        "committed rocprofv3 --pmc passes in profiles/); valu_clk_per_instr = (GRBM_GUI_ACTIVE / 8 XCDs) / "
+                        "(SQ_INSTS_VALU / 1024 SIMDs) of that launch: 4.0 is back-to-back VALU issue, the kernel's real ceiling; "
+                        "achieved_clock_ghz = those cycles / the launch's duration in the same pass; frac_at_achieved_clock = frac "
+                        "re-priced with the peak at that clock instead of 2.4 GHz (> 1 is possible: 12 algorithmic FLOP per 7 "
+                        "executed lane-operations)",
                 "hbm": {"bound": "hbm", "achieved": algo_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_gbs / HBM_PEAK_GBS,
                         "note": "algorithmic no-reuse bytes ((Na+Nb)*8+8 per pose-eval) / kernel time"},

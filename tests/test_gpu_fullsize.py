@@ -121,6 +121,24 @@ def test_config4_sharded_full_size_equals_oracle(fresh_engine, oracle, mm, grid)
             assert geoms_equal(cases[r][k], single[k]), f"rank {r}: coordinates of pullback {k} differ"
 
 
+@pytest.mark.parametrize("step,rng_deg", [(0.5, 90.0), (0.05, 90.0)])
+def test_default_ladder_full_size_equals_oracle(fresh_engine, oracle, mm, step, rng_deg):
+    """The reference's DEFAULT mode (bruteforce=False, align_within.rs:193-247) at the config3 shape: 4 x 512 frames,
+    0.5 deg x +-90 deg (two dependent levels, 202 evaluations per frame pair) and 0.05 deg (three levels, 303) -- the
+    decoupled path's logs, evaluation count and coordinates against the oracle's sequential ladder chain."""
+    geoms = mm.synthetic_case(512, 501)
+    og = [to_oracle(oracle, g) for g in geoms]
+    th = _threads()
+    ologs = [oracle.align_within_chain(o, step, rng_deg, False, 501, n_threads=th) for o in og]
+    plan = mm.WithinPlan(fresh_engine, geoms, step, rng_deg, False, 501, precision=mm.MM_PRECISION_F32_FAST)
+    logs, evals, unresolved = plan.run()
+    plan.close()
+    assert evals == 4 * 511 * oracle.count_evals(step, rng_deg, False)
+    for k in range(4):
+        assert logs[k] == ologs[k], f"ladder logs of pullback {k} differ"
+        assert geoms_equal(geoms[k], og[k]), f"coordinates of pullback {k} differ"
+
+
 def test_bench_two_ranks_check_config2():
     """`bench.py --gpus 2 --workload config2 --check` as the driver starts it (torch.distributed.run, here two `gloo`
     ranks sharing the one GPU): the sharded step pipeline end to end, rank 0's result compared with the oracle."""
