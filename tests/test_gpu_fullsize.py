@@ -133,7 +133,11 @@ def test_default_ladder_full_size_equals_oracle(fresh_engine, oracle, mm, step, 
     plan = mm.WithinPlan(fresh_engine, geoms, step, rng_deg, False, 501, precision=mm.MM_PRECISION_F32_FAST)
     logs, evals, unresolved = plan.run()
     plan.close()
-    assert evals == 4 * 511 * oracle.count_evals(step, rng_deg, False)
+    # evaluations per search: 202 / 303 unless a finer level's window is clipped at +-range (limes);
+    # oracle.count_evals counts the fully clipped case (its dummy cost makes the first candidate, -range, win)
+    full = {0.5: 202, 0.05: 303}[step]
+    assert 4 * 511 * oracle.count_evals(step, rng_deg, False) <= evals <= 4 * 511 * full
+    assert evals > 4 * 511 * (full - 1)               # generic data: hardly any window touches the limit
     for k in range(4):
         assert logs[k] == ologs[k], f"ladder logs of pullback {k} differ"
         assert geoms_equal(geoms[k], og[k]), f"coordinates of pullback {k} differ"

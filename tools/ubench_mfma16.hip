@@ -1,0 +1,157 @@
+// ubench_mfma16.hip -- does the f16 matrix instruction of gfx950 (v_mfma_f32_32x32x16_f16, the matrix pipe proper)
+// run BESIDE the integer minima of the Hausdorff screen?  (tools/ubench_mfma.hip measured the f32-input MFMA:
+// it shares the vector ALUs -- MFMA and VALU time ADD there.)  One 32x32x16 MFMA gives 1024 squared distances
+// (d^2 = |a|^2 + |b|^2 - 2 a.b as a K = 12 product of f16 hi/lo pieces); the screen then needs 16 v_min3_i32 per tile.
+// Also checks the operand / result layout the kernel relies on.
+// Build: hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 tools/ubench_mfma16.hip -o tools/bin/ubench_mfma16
+// (VGPR-form MFMA: the results land where the minima can read them; the default AGPR form costs a v_accvgpr_read each)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int min3i(int a, int b, int c) { int m = a < b ? a : b; return m < c ? m : c; }
+
+// layout check: A[i][k] = lane i + 32 * (k / 8), element k % 8;  B[k][j] = lane j + 32 * (k / 8), element k % 8;
+// D[i][j] = lane j + 32 * ((i / 4) % 2), register (i % 4) + 4 * (i / 8)
+__global__ void k_layout(const float* A, const float* B, float* D)
+{
+    const int l = threadIdx.x;
+    h8 a, b;
+    for (int e = 0; e < 8; ++e) {
+        a[e] = (_Float16)A[(l % 32) * 16 + 8 * (l / 32) + e];
+        b[e] = (_Float16)B[(8 * (l / 32) + e) * 32 + (l % 32)];
+    }
+    f16v c = {0};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    for (int v = 0; v < 16; ++v) {
+        const int i = (v % 4) + 4 * (l / 32) + 8 * (v / 4), j = l % 32;
+        D[i * 32 + j] = c[v];
+    }
+}
+
+// MODE 0: MFMA only (2 per iteration)   MODE 1: 32 min3 only   MODE 2: software pipeline -- MFMA into one buffer
+// while the 16 minima (8 column, 8 row) of the other buffer issue   MODE 3: same, the minima on unrelated registers
+template <int MODE>
+__global__ void __launch_bounds__(256) k(int* out, int iters)
+{
+    __shared__ h8 s_b[64 * 34];
+    for (int i = threadIdx.x; i < 64 * 34; i += 256) {
+        h8 t;
+        for (int e = 0; e < 8; ++e) t[e] = (_Float16)(0.002f * ((i * 7 + e) % 97));
+        s_b[i] = t;
+    }
+    __syncthreads();
+    const int l = threadIdx.x & 63;
+    h8 a;
+    for (int e = 0; e < 8; ++e) a[e] = (_Float16)(0.001f * (l + e));
+    f16v d0 = {0}, d1 = {0};
+    const f16v zero = {0};
+    int cm = 0x7f800000, rm[16], u[16];
+    for (int v = 0; v < 16; ++v) { rm[v] = 0x7f800000; u[v] = threadIdx.x * 131 + v; }
+    if (MODE == 2) d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, s_b[l], zero, 0, 0, 0);
+    for (int it = 0; it < iters; ++it) {
+        const int t = (it & 15) * 2;
+        if (MODE == 0) {
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, s_b[t * 64 + l], zero, 0, 0, 0);
+            asm volatile("" : "+v"(d0));
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, s_b[(t + 1) * 64 + l], zero, 0, 0, 0);
+            asm volatile("" : "+v"(d1));
+        } else if (MODE == 1) {
+            for (int q = 0; q < 2; ++q)
+                for (int v = 0; v < 16; ++v)
+                    asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(u[v]) : "v"(u[(v + 1) & 15]), "v"(u[(v + 2) & 15]));
+        } else if (MODE == 2) {
+            const h8 b1 = s_b[(t + 1) * 64 + l], b2 = s_b[(t + 2) * 64 + l];
+            __builtin_amdgcn_sched_barrier(0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int v = 0; v < 16; v += 2) cm = min3i(cm, __float_as_int(d0[v]), __float_as_int(d0[v + 1]));
+            for (int v = 0; v < 8; ++v) rm[v] = min3i(rm[v], __float_as_int(d0[v]), __float_as_int(d0[v + 8]));
+            __builtin_amdgcn_sched_barrier(0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b2, zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int v = 0; v < 16; v += 2) cm = min3i(cm, __float_as_int(d1[v]), __float_as_int(d1[v + 1]));
+            for (int v = 0; v < 8; ++v) rm[v + 8] = min3i(rm[v + 8], __float_as_int(d1[v]), __float_as_int(d1[v + 8]));
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, s_b[t * 64 + l], zero, 0, 0, 0);
+            asm volatile("" : "+v"(d0));
+            for (int v = 0; v < 16; ++v)
+                asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(u[v]) : "v"(u[(v + 1) & 15]), "v"(u[(v + 2) & 15]));
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, s_b[(t + 1) * 64 + l], zero, 0, 0, 0);
+            asm volatile("" : "+v"(d1));
+            for (int v = 0; v < 16; ++v)
+                asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(u[v]) : "v"(u[(v + 1) & 15]), "v"(u[(v + 2) & 15]));
+        }
+    }
+    unsigned s = (unsigned)cm;
+    for (int v = 0; v < 16; ++v) s ^= (unsigned)rm[v] * (2u * v + 3u) ^ (unsigned)u[v] ^ __float_as_uint(d0[v]) ^ __float_as_uint(d1[v]);
+    if (s == 123456789u) out[0] = (int)s;
+}
+
+template <int MODE>
+int run(const char* name, int* dout)
+{
+    hipEvent_t t0, t1;
+    CHECK(hipEventCreate(&t0)); CHECK(hipEventCreate(&t1));
+    const int iters = 16384;
+    for (int wps : {1, 2, 3, 4}) {
+        const int grid = 256 * wps;
+        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, dout, 2048);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(t0));
+        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, dout, iters);
+        CHECK(hipEventRecord(t1));
+        CHECK(hipEventSynchronize(t1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, t0, t1));
+        // per SIMD: wps waves x iters x 2 tiles
+        const double tiles = (double)iters * 2.0 * wps;
+        printf("%-34s waves/SIMD=%d  %8.3f ms  %7.2f ns per tile per SIMD  (= %5.1f clk at 2.2 GHz)  -> %6.1f Gdist/s per chip\n", name, wps, ms,
+               ms * 1e6 / tiles, ms * 1e6 / tiles * 2.2, tiles * 1024.0 * 1024.0 / (ms * 1e-3) * 1e-9);
+    }
+    return 0;
+}
+
+int main()
+{
+    // layout
+    {
+        std::vector<float> A(32 * 16), B(16 * 32), D(32 * 32), R(32 * 32, 0.f);
+        for (int i = 0; i < 32; ++i) for (int kk = 0; kk < 16; ++kk) A[i * 16 + kk] = (float)((i * 7 + kk * 3) % 11 - 5);
+        for (int kk = 0; kk < 16; ++kk) for (int j = 0; j < 32; ++j) B[kk * 32 + j] = (float)((kk * 5 + j * 2) % 13 - 6);
+        for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) for (int kk = 0; kk < 16; ++kk) R[i * 32 + j] += A[i * 16 + kk] * B[kk * 32 + j];
+        float *dA, *dB, *dD;
+        CHECK(hipMalloc(&dA, A.size() * 4)); CHECK(hipMalloc(&dB, B.size() * 4)); CHECK(hipMalloc(&dD, D.size() * 4));
+        CHECK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        CHECK(hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < 1024; ++i) bad += D[i] != R[i];
+        printf("layout check (A[i][k]: lane i+32*(k/8), B[k][j]: lane j+32*(k/8), D[i][j]: lane j+32*((i/4)%%2), reg i%%4+4*(i/8)): %s (%d mismatches)\n",
+               bad ? "WRONG" : "ok", bad);
+        // subnormal f16 inputs and f32 accumulation: 2^-20 * 2^-4 pieces must not be flushed
+        for (auto& x : A) x = 0.f; for (auto& x : B) x = 0.f;
+        A[0] = 3.0e-6f; B[0] = 1024.f;      // a subnormal f16 (min normal 6.1e-5) times 1024
+        A[1] = 1000.f; B[32] = 1000.f;      // 1e6 beside it
+        CHECK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        CHECK(hipMemcpy(D.data(), dD, 4, hipMemcpyDeviceToHost));
+        printf("f16 subnormal input: 3.0e-6 (f16: %.9g) * 1024 + 1000 * 1000 = %.9g (exact sum of the f16 values %.9g)\n",
+               (double)(float)(_Float16)3.0e-6f, (double)D[0], (double)(float)(_Float16)3.0e-6f * 1024.0 + 1.0e6);
+    }
+    int* dout;
+    CHECK(hipMalloc(&dout, 1024));
+    run<0>("mfma 32x32x16 f16 only", dout);
+    run<1>("16 min3 per tile only", dout);
+    run<2>("pipelined: mfma || 16 min3 (its data)", dout);
+    run<3>("mfma + 16 indep min3", dout);
+    CHECK(hipFree(dout));
+    return 0;
+}
