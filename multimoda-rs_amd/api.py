@@ -348,12 +348,11 @@ def align_frames_in_geometries(geoms: Sequence[G.FlatGeometry], step_deg: float,
         raise RuntimeError("sample_size must be > 0")
     ref_idx = [_ref_or_proximal(g) for g in geoms]       # :42-44, before the chain
     logs, _ = G.align_within(eng, geoms, step_deg, range_deg, bruteforce, sample_size, precision=precision, mode=mode)
+    _mark("  within: mm_align_within (sets, search, chain walk)")
     if len(geoms) > 1:
         # the reference finishes the pullbacks in parallel threads (entry.rs:140-203); the bulk numpy and
         # C-ABI calls of the post-steps release the GIL
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=len(geoms)) as ex:
-            flags = list(ex.map(lambda gr: _finish_within(gr[0], gr[1], smooth), zip(geoms, ref_idx)))
+        flags = list(_pool().map(lambda gr: _finish_within(gr[0], gr[1], smooth), zip(geoms, ref_idx)))
     else:
         flags = [_finish_within(g, r, smooth) for g, r in zip(geoms, ref_idx)]
     return logs, flags
@@ -382,9 +381,7 @@ def _prepare_from_paths(paths: Sequence[str], labels, n_expected, image_center, 
 def _prepare_from_inputs(inputs: Sequence[InputData], image_center, radius, n_points):
     build = lambda d: build_geometry_from_inputdata(d, None, d.label, d.diastole, image_center, radius, n_points)
     if len(inputs) > 1:              # the native builder releases the interpreter lock: the pullbacks build in parallel
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=len(inputs)) as ex:
-            return list(ex.map(build, inputs))
+        return list(_pool().map(build, inputs))
     return [build(d) for d in inputs]
 
 
@@ -439,37 +436,70 @@ def _maybe_postprocess(pair: GeometryPair, anomalous: bool, postprocessing: bool
 # ---------------------------------------------------------------------------------------
 # the four modes (entry.rs:71, 363, 572, 691)
 # ---------------------------------------------------------------------------------------
+_TRACE = [] if os.environ.get("MM_API_TRACE") else None      # [(label, perf_counter)]: tools/bench_api.py --stages
+
+
+def _mark(label):
+    if _TRACE is not None:
+        import time
+        _TRACE.append((label, time.perf_counter()))
+
+
 def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batches=True, postprocessing=False):
     eng = engine or default_engine()
+    _mark("geometries built")
     logs, flags = align_frames_in_geometries(geoms, step, rng, smooth, bruteforce, sample_size, eng)
+    _mark("within: search + chain + post-steps")
     anomalous = any(flags)                                                         # entry.rs:279-280
     post = lambda pr: _maybe_postprocess(pr, anomalous, postprocessing)
     a, b, c, d = geoms
     G.align_between(eng, [(a, b), (c, d)], rng, step, sample_size)                 # entry.rs:206-240
+    _mark("between AB | CD")
     b.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True         # moved last by a translation
     # The reference clones the geometries into every pair.  With the native post-processing each pair's geometries are
     # rebuilt from (and never written through) the ones handed in, so a, b -- final after the first batch -- and the
     # final c, d can be handed in as they are; only the state of c and d BEFORE the second batch needs a snapshot.
     share = postprocessing and not os.environ.get("MM_PY_POSTPROC")
     keep = (lambda g: g) if share else (lambda g: g.copy())
-    pair_ab = _make_pair(keep(a), keep(b))
-    pair_cd = _make_pair(keep(c), keep(d)) if not both_batches else _make_pair(c.copy(), d.copy())
-    def post_all(pairs):
-        # the pairs are independent (maybe_postprocess x4, entry.rs:282-290); the native post-processing releases
-        # the interpreter lock
-        if not postprocessing or len(pairs) < 2:
-            return [post(p) for p in pairs]
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=len(pairs)) as ex:
-            return list(ex.map(post, pairs))
-
+    pool = _pool()
     if not both_batches:
-        return (*post_all([pair_ab, pair_cd]), tuple(logs))
+        pair_ab, pair_cd = _make_pair(keep(a), keep(b)), _make_pair(keep(c), keep(d))
+        out = [post(pair_ab), post(pair_cd)] if not postprocessing else list(pool.map(post, [pair_ab, pair_cd]))
+        return (*out, tuple(logs))
+    # The pairs are independent (maybe_postprocess x4, entry.rs:282-290) and the native post-processing releases the
+    # interpreter lock: AB and CD are post-processed on pool threads WHILE the second batch of between alignments runs
+    # (a and b are final after the first batch; c and d move again, so pair CD works on snapshots taken -- in parallel
+    # -- before the second batch starts).
+    snap_c, snap_d = pool.map(lambda g: g.copy(), (c, d))
+    pair_ab = _make_pair(keep(a), keep(b))
+    pair_cd = _make_pair(snap_c, snap_d)
+    early = [pool.submit(post, pr) for pr in (pair_ab, pair_cd)] if postprocessing else None
+    _mark("snapshot of C, D; post-processing of AB, CD started")
     G.align_between(eng, [(a, c), (b, d)], rng, step, sample_size)                 # entry.rs:243-277
+    _mark("between AC | BD")
     c.meta["lumen_centroid_fresh"] = d.meta["lumen_centroid_fresh"] = True
     pair_ac = _make_pair(keep(a), keep(c))
     pair_bd = _make_pair(keep(b), keep(d))
-    return (*post_all([pair_ab, pair_cd, pair_ac, pair_bd]), tuple(logs))
+    if postprocessing:
+        late = [pool.submit(post, pr) for pr in (pair_ac, pair_bd)]
+        out = [f.result() for f in early + late]
+    else:
+        out = [pair_ab, pair_cd, pair_ac, pair_bd]
+    _mark("postprocess x 4")
+    return (*out, tuple(logs))
+
+
+_POOL = None
+
+
+def _pool():
+    """One small thread pool for the per-pullback / per-pair host work of the entry points (the reference uses crossbeam
+    scopes of 4 and 2 threads, entry.rs:140-290); created once -- starting and joining one per call costs a millisecond."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="mm-api")
+    return _POOL
 
 
 def from_array_full(input_data_a: InputData, input_data_b: InputData, input_data_c: InputData, input_data_d: InputData,

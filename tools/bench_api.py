@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--stages", action="store_true", help="per-stage wall times of one call (MM_API_TRACE)")
     a = ap.parse_args()
     base = mm.synthetic_case(a.frames, 501)
     data = [input_data(g, lab, dia) for g, lab, dia in zip(base, ("rest", "rest", "stress", "stress"), (True, False, True, False))]
@@ -54,6 +55,20 @@ def main():
            "ms_median": 1e3 * statistics.median(ts), "ms_all": [1e3 * t for t in ts],
            "frames_out": [int(p.geom_a.n_frames) for p in out[:4]]}
     print(json.dumps(res))
+    if a.stages:
+        from multimoda_rs_amd import api as API
+        for rep in range(3):
+            API._TRACE = []
+            t0 = time.perf_counter()
+            mm.from_array_full(*data, **kw)
+            t1 = time.perf_counter()
+            prev = t0
+            print(f"-- call {rep}: {1e3 * (t1 - t0):.2f} ms")
+            for label, t in API._TRACE:
+                print(f"   {1e3 * (t - prev):8.3f} ms  {label}")
+                prev = t
+            print(f"   {1e3 * (t1 - prev):8.3f} ms  (return)")
+        API._TRACE = None
     if a.profile:
         pr = cProfile.Profile()
         pr.enable()
