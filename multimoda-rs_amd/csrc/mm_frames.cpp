@@ -482,7 +482,10 @@ void resample_by_diff(std::vector<FFrame>& fr, double diff)           // :116-14
     }
     if (fr.empty()) return;
     const double start = fr[0].c[2];
-    for (size_t i = 1; i < fr.size(); ++i) fr[i].set_z(start + (double)i * diff);
+    const int n = (int)fr.size();
+    parallel_for((n + 31) / 32, [&](int blk) {               // frames are independent
+        for (int i = std::max(1, blk * 32); i < std::min(n, (blk + 1) * 32); ++i) fr[(size_t)i].set_z(start + (double)i * diff);
+    });
 }
 
 std::vector<double> predict_z_positions(double ref_z, double start_z, double stop_z, double z_diff)   // :142-195
@@ -561,9 +564,9 @@ int new_frames_by_sample_rate(const std::vector<FFrame>& fr, std::vector<double>
 void trim_one(std::vector<FFrame>& fr, int64_t r, int64_t before, int64_t after)   // trim_geom_pair (:342-409)
 {
     const int64_t s = r - before, e = r + after;
-    if (s < e && e <= (int64_t)fr.size() && s >= 0) {
-        std::vector<FFrame> sel(fr.begin() + (ptrdiff_t)s, fr.begin() + (ptrdiff_t)e);
-        fr.swap(sel);
+    if (s < e && e <= (int64_t)fr.size() && s >= 0) {      // keep [s, e): frames are moved, never copied
+        fr.erase(fr.begin() + (ptrdiff_t)e, fr.end());
+        fr.erase(fr.begin(), fr.begin() + (ptrdiff_t)s);
     }
     for (size_t i = 0; i < fr.size(); ++i) fr[i].set_ids((uint32_t)i);
 }
@@ -586,27 +589,34 @@ int postprocess_pair(std::vector<FFrame>& A, std::vector<FFrame>& B, double tol,
     for (size_t i = 0; i < A.size(); ++i) orig_za[i] = A[i].c[2];
     for (size_t i = 0; i < B.size(); ++i) orig_zb[i] = B[i].c[2];
     std::vector<FFrame> ra, rb;
+    // (A and B are replaced at the end and nothing below reads them again -- the original z values are saved above --
+    // so a geometry that is only re-spaced is MOVED into its result: no deep copy of 512 frames x 3 contours)
     if (same) {
         const double mean = (da + db) / 2.0;
-        ra = A; rb = B;
+        ra = std::move(A); rb = std::move(B);
         resample_by_diff(ra, mean); resample_by_diff(rb, mean);
     } else if (da < db) {
         double lo, hi;
         span(B, lo, hi);
         if ((rc = new_frames_by_sample_rate(B, predict_z_positions(ref_z_b, lo, hi, da), rb))) return rc;
-        ra = A; resample_by_diff(ra, da);
+        ra = std::move(A); resample_by_diff(ra, da);
     } else {
         double lo, hi;
         span(A, lo, hi);
         if ((rc = new_frames_by_sample_rate(A, predict_z_positions(ref_z_a, lo, hi, db), ra))) return rc;
-        rb = B; resample_by_diff(rb, db);
+        rb = std::move(B); resample_by_diff(rb, db);
     }
     // :70-76 -- the reference indexes the ORIGINAL pair with the resampled geometries' reference indices
     int64_t ja, jb;
     if ((rc = find_ref_frame_idx(ra, ja)) || (rc = find_ref_frame_idx(rb, jb))) return rc;
     if (ja >= (int64_t)orig_za.size() || jb >= (int64_t)orig_zb.size()) return set_error(MM_ERR_REF_INDEX, "index out of bounds");
     const double translation = orig_za[(size_t)ja] - orig_zb[(size_t)jb];
-    for (FFrame& f : ra) f.translate(0.0, 0.0, translation);
+    {
+        const int n = (int)ra.size();
+        parallel_for((n + 31) / 32, [&](int blk) {
+            for (int i = blk * 32; i < std::min(n, (blk + 1) * 32); ++i) ra[(size_t)i].translate(0.0, 0.0, translation);
+        });
+    }
     auto ref_or_zero = [](const std::vector<FFrame>& fr) { for (const FFrame& f : fr) if (f.has_ref) return (int64_t)f.id; return (int64_t)0; };
     const int64_t qa = ref_or_zero(ra), qb = ref_or_zero(rb);
     const int64_t before = std::min(qa, qb), after = std::min((int64_t)ra.size() - qa, (int64_t)rb.size() - qb);
@@ -643,8 +653,18 @@ int mm_frames_from_flat(const mm_flat_geometry* in, mm_frames** out)
         return set_error(MM_ERR_INVALID, "mm_frames_from_flat: geometry arrays missing");
     Frames* F = new Frames();
     F->f.resize((size_t)g.n_frames);
-    int64_t lum_at = 0, wall_at = 0;
+    // per-frame positions in the per-point flag arrays first (a serial prefix sum), then the frames are filled over the
+    // worker pool: 512 frames x 3 contours are ~1500 allocations and 12 MB of copies per geometry
+    std::vector<int64_t> lum_pos((size_t)g.n_frames + 1, 0), wall_pos((size_t)g.n_frames + 1, 0);
     for (int32_t i = 0; i < g.n_frames; ++i) {
+        lum_pos[(size_t)i + 1] = lum_pos[(size_t)i] + (g.lumen_off[i + 1] - g.lumen_off[i]);
+        const int64_t nw = (g.extra_off && in->extra_counts) ? std::max<int64_t>(in->extra_counts[4 * i + 3], 0) : 0;
+        wall_pos[(size_t)i + 1] = wall_pos[(size_t)i] + nw;
+    }
+    const int nfr = g.n_frames;
+    parallel_for((nfr + 15) / 16, [&](int blk) {
+    for (int32_t i = blk * 16; i < std::min(nfr, (blk + 1) * 16); ++i) {
+        int64_t lum_at = lum_pos[(size_t)i], wall_at = wall_pos[(size_t)i];
         FFrame& f = F->f[(size_t)i];
         f.id = g.id[i];
         std::memcpy(f.c, g.centroid + 3 * i, 24);
@@ -689,6 +709,7 @@ int mm_frames_from_flat(const mm_flat_geometry* in, mm_frames** out)
         }
         if (g.has_ref && g.has_ref[i]) { f.has_ref = true; std::memcpy(f.ref, g.ref + 3 * i, 24); }
     }
+    });
     *out = reinterpret_cast<mm_frames*>(F);
     return MM_OK;
 }
@@ -727,8 +748,20 @@ int mm_frames_export(const mm_frames* h, mm_flat_geometry* out)
         (nc > 0 && (!g.cath_off || !g.cath)) || (ne > 0 && (!g.extra_off || !g.extra)))
         return set_error(MM_ERR_INVALID, "mm_frames_export: destination arrays missing");
     g.n_frames = nf; g.has_catheter = nc > 0 ? 1 : 0;
-    int64_t ol = 0, oc = 0, oe = 0, ow = 0;
+    // output positions per frame (serial prefix sums), then the copies over the worker pool
+    std::vector<int64_t> pl((size_t)nf + 1, 0), pc((size_t)nf + 1, 0), pe((size_t)nf + 1, 0), pw((size_t)nf + 1, 0);
     for (int32_t i = 0; i < nf; ++i) {
+        const FFrame& f = F->f[(size_t)i];
+        pl[(size_t)i + 1] = pl[(size_t)i] + f.lumen.n();
+        pc[(size_t)i + 1] = pc[(size_t)i] + (nc > 0 ? f.ext[K_CATH].n() : 0);
+        int64_t e = 0;
+        for (int k : {K_EEM, K_CALC, K_SIDE, K_WALL}) if (f.has[k]) e += f.ext[k].n();
+        pe[(size_t)i + 1] = pe[(size_t)i] + e;
+        pw[(size_t)i + 1] = pw[(size_t)i] + (f.has[K_WALL] ? f.ext[K_WALL].n() : 0);
+    }
+    parallel_for(((int)nf + 15) / 16, [&](int blk) {
+    for (int32_t i = blk * 16; i < std::min<int32_t>(nf, (blk + 1) * 16); ++i) {
+        int64_t ol = pl[(size_t)i], oc = pc[(size_t)i], oe = pe[(size_t)i], ow = pw[(size_t)i];
         const FFrame& f = F->f[(size_t)i];
         g.id[i] = f.id; g.lumen_id[i] = f.lumen.id; g.orig_frame[i] = f.lumen.orig;
         std::memcpy(g.centroid + 3 * i, f.c, 24);
@@ -756,9 +789,10 @@ int mm_frames_export(const mm_frames* h, mm_flat_geometry* out)
         g.has_ref[i] = f.has_ref ? 1 : 0;
         for (int k = 0; k < 3; ++k) g.ref[3 * i + k] = f.has_ref ? f.ref[k] : 0.0;
     }
-    g.lumen_off[nf] = ol;
-    if (nc > 0) g.cath_off[nf] = oc;
-    if (ne > 0) g.extra_off[nf] = oe;
+    });
+    g.lumen_off[nf] = pl[(size_t)nf];
+    if (nc > 0) g.cath_off[nf] = pc[(size_t)nf];
+    if (ne > 0) g.extra_off[nf] = pe[(size_t)nf];
     return MM_OK;
 }
 

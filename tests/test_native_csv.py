@@ -26,7 +26,8 @@ def _write(tmp_path, text, name="c.csv"):
 
 def test_golden_files_equal_the_python_readers(io):
     files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "**", "*.csv"), recursive=True))
-    files = [f for f in files if "records" not in os.path.basename(f) and "manual" not in os.path.basename(f)]
+    files = [f for f in files if "records" not in os.path.basename(f) and "manual" not in os.path.basename(f)
+             and "centerline" not in os.path.basename(f)]          # (x,y,z centerline table: three columns, not a contour file)
     assert len(files) >= 12
     for f in files:
         d = io._detect_delimiter(f)

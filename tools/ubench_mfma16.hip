@@ -95,6 +95,92 @@ __global__ void __launch_bounds__(256) k(int* out, int iters)
     if (s == 123456789u) out[0] = (int)s;
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// 16x16x32 f16: 256 distances per MFMA in 4 VGPRs; 4 of them per "tile" of 1024 distances.
+// MODE 0: MFMA only   MODE 2: software pipeline (4 MFMAs into one buffer set while the 16 minima of the other issue)
+template <int MODE>
+__global__ void __launch_bounds__(256) k16(int* out, int iters)
+{
+    __shared__ h8 s_b[64 * 40];
+    for (int i = threadIdx.x; i < 64 * 40; i += 256) {
+        h8 t;
+        for (int e = 0; e < 8; ++e) t[e] = (_Float16)(0.002f * ((i * 7 + e) % 97));
+        s_b[i] = t;
+    }
+    __syncthreads();
+    const int l = threadIdx.x & 63;
+    h8 a;
+    for (int e = 0; e < 8; ++e) a[e] = (_Float16)(0.001f * (l + e));
+    const f4v zero = {0, 0, 0, 0};
+    f4v d0[4], d1[4];
+    for (int q = 0; q < 4; ++q) { d0[q] = zero; d1[q] = zero; }
+    int cm = 0x7f800000, rm[16];
+    for (int v = 0; v < 16; ++v) rm[v] = 0x7f800000;
+    if (MODE == 2)
+        for (int q = 0; q < 4; ++q) d0[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, s_b[q * 64 + l], zero, 0, 0, 0);
+    for (int it = 0; it < iters; ++it) {
+        const int t = (it & 3) * 8;
+        if (MODE == 0) {
+            for (int q = 0; q < 4; ++q) { d0[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, s_b[(t + q) * 64 + l], zero, 0, 0, 0); asm volatile("" : "+v"(d0[q])); }
+            for (int q = 0; q < 4; ++q) { d1[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, s_b[(t + 4 + q) * 64 + l], zero, 0, 0, 0); asm volatile("" : "+v"(d1[q])); }
+        } else {
+            h8 b1[4], b2[4];
+            for (int q = 0; q < 4; ++q) { b1[q] = s_b[(t + q) * 64 + l]; b2[q] = s_b[(t + 4 + q) * 64 + l]; }
+            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) d1[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1[q], zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) {
+                cm = min3i(cm, __float_as_int(d0[q][0]), __float_as_int(d0[q][1]));
+                cm = min3i(cm, __float_as_int(d0[q][2]), __float_as_int(d0[q][3]));
+            }
+            for (int v = 0; v < 4; ++v) {
+                rm[v] = min3i(rm[v], __float_as_int(d0[0][v]), __float_as_int(d0[1][v]));
+                rm[v + 4] = min3i(rm[v + 4], __float_as_int(d0[2][v]), __float_as_int(d0[3][v]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) d0[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2[q], zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) {
+                cm = min3i(cm, __float_as_int(d1[q][0]), __float_as_int(d1[q][1]));
+                cm = min3i(cm, __float_as_int(d1[q][2]), __float_as_int(d1[q][3]));
+            }
+            for (int v = 0; v < 4; ++v) {
+                rm[v + 8] = min3i(rm[v + 8], __float_as_int(d1[0][v]), __float_as_int(d1[1][v]));
+                rm[v + 12] = min3i(rm[v + 12], __float_as_int(d1[2][v]), __float_as_int(d1[3][v]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    unsigned s = (unsigned)cm;
+    for (int v = 0; v < 16; ++v) s ^= (unsigned)rm[v] * (2u * v + 3u);
+    for (int q = 0; q < 4; ++q) for (int v = 0; v < 4; ++v) s ^= __float_as_uint(d0[q][v]) ^ __float_as_uint(d1[q][v]);
+    if (s == 123456789u) out[0] = (int)s;
+}
+
+template <int MODE>
+int run16(const char* name, int* dout)
+{
+    hipEvent_t t0, t1;
+    CHECK(hipEventCreate(&t0)); CHECK(hipEventCreate(&t1));
+    const int iters = 16384;
+    for (int wps : {1, 2, 3, 4}) {
+        const int grid = 256 * wps;
+        hipLaunchKernelGGL(k16<MODE>, dim3(grid), dim3(256), 0, 0, dout, 2048);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(t0));
+        hipLaunchKernelGGL(k16<MODE>, dim3(grid), dim3(256), 0, 0, dout, iters);
+        CHECK(hipEventRecord(t1));
+        CHECK(hipEventSynchronize(t1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, t0, t1));
+        const double tiles = (double)iters * 2.0 * wps;      // 1024 distances each
+        printf("%-34s waves/SIMD=%d  %8.3f ms  %7.2f ns per 1024 distances per SIMD  -> %6.1f Gdist/s per chip\n", name, wps, ms,
+               ms * 1e6 / tiles, tiles * 1024.0 * 1024.0 / (ms * 1e-3) * 1e-9);
+    }
+    return 0;
+}
+
 template <int MODE>
 int run(const char* name, int* dout)
 {
@@ -152,6 +238,8 @@ int main()
     run<1>("16 min3 per tile only", dout);
     run<2>("pipelined: mfma || 16 min3 (its data)", dout);
     run<3>("mfma + 16 indep min3", dout);
+    run16<0>("4 x mfma 16x16x32 f16 only", dout);
+    run16<2>("pipelined: 4 x 16x16x32 || 16 min3", dout);
     CHECK(hipFree(dout));
     return 0;
 }
