@@ -15,11 +15,11 @@ objs=()
 for s in mm_kernels.hip mm_nn_kernels.hip; do
     $HIPCC -x hip $COMMON -O3 -c "$CSRC/$s" -o "$OUT/${s%.*}.o" & objs+=("$OUT/${s%.*}.o")
 done
-for s in mm_engine.cpp mm_host.cpp mm_centerline.cpp mm_ccta.cpp mm_build.cpp mm_frames.cpp; do
+for s in mm_engine.cpp mm_host.cpp mm_centerline.cpp mm_ccta.cpp mm_build.cpp mm_frames.cpp mm_comm.cpp; do
     $HIPCC -x hip $COMMON $SAN -c "$CSRC/$s" -o "$OUT/${s%.*}.o" & objs+=("$OUT/${s%.*}.o")
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address,undefined -shared-libsan -o "$OUT/libmm_hausdorff.so" "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address,undefined -shared-libsan -o "$OUT/libmm_hausdorff.so" "${objs[@]}" -ldl
 RT="$(dirname "$($HIPCC -print-file-name=libclang_rt.asan-x86_64.so)")"
 cd "$ROOT"
 # detect_leaks=0: the interpreter itself never frees everything; halt on the first real error
