@@ -830,6 +830,7 @@ def main():
                        "parallelism": (f"(frame pair x candidate) grid in {grid[0]} x {grid[1]} tiles, one per GPU" if world > 1
                                        else "single GPU"),
                        "shard_grid": {"pair_blocks": grid[0], "cand_slices": grid[1]} if world > 1 else None,
+                       "exchange_mode": os.environ.get("MM_EXCHANGE", "device") if world > 1 else None,
                        "exchange": ({"rccl": "ncclAllReduce(MIN) x 2 per level on device records, issued by the library on its own "
                                              "RCCL communicator (mm_within_plan_search_sharded)",
                                      "device": "2 all-reduces(MIN) per level on device records through torch.distributed",

@@ -45,5 +45,7 @@ def test_bench_contract_on_a_small_workload():
 def test_bench_starts_its_own_ranks(exchange):
     d = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny", "--no-extra-legs", "--no-cpu-baseline"],
                   {"MM_BENCH_BACKEND": "gloo", "MM_EXCHANGE": exchange, "OMP_NUM_THREADS": "4"})
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "candidate-axis x2"
-    assert d["config"]["exchange"].startswith(exchange)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "tiles" in d["config"]["parallelism"]
+    assert d["config"]["shard_grid"] == {"pair_blocks": 1, "cand_slices": 2}      # 44 frame pairs: the candidate axis
+    assert d["config"]["exchange_mode"] == exchange
+    assert "checked at start-up" in d["config"]["exchange"]
