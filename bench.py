@@ -378,7 +378,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)   # the first two big launches of a process run at ramping clocks
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
-    ap.add_argument("--precision", default="fast", choices=["f32", "fast", "bounded", "f64"],
+    ap.add_argument("--precision", default="fast", choices=["f32", "fast", "bounded", "f64", "matrix"],
                     help="candidate scoring: f32 = direct-form f32 screen + exact f64 re-score; fast = expanded-form "
                          "f32 screen + exact f64 re-score (default; the same workload through the bounded search and "
                          "through the all-f64 kernel is reported beside it); bounded = lower bounds rule candidates out "
@@ -458,7 +458,7 @@ def main():
     cfg = WORKLOADS[args.workload]
     mode = 0 if args.mode == "chain" else 1
     PRECS = {"f32": mm.MM_PRECISION_F32, "fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED,
-             "f64": mm.MM_PRECISION_F64}
+             "f64": mm.MM_PRECISION_F64, "matrix": mm.MM_PRECISION_F32_MATRIX}
     PREC = PRECS[args.precision]
     base = mm.synthetic_case(cfg["frames"], cfg["points"])
     # N > 1: the (frame pair x candidate) grid is cut into pair_blocks x cand_slices tiles, one per rank
@@ -796,7 +796,7 @@ def main():
         peak = FP64_VECTOR_PEAK_TFLOPS if f64_main else FP32_VECTOR_PEAK_TFLOPS
         # executed VALU lane-operations per squared distance the reference counts twice (2 x 6 = 12 algorithmic FLOP):
         # fast screen 4 packed-FMA lanes (8 FLOP) + 1 add + 2 min -> 7 issue slots; direct form 8; f64 kernel 7
-        exec_per_12 = {"fast": 7.0, "f32": 8.0, "bounded": None, "f64": 7.0}[args.precision]
+        exec_per_12 = {"fast": 7.0, "f32": 8.0, "bounded": None, "f64": 7.0, "matrix": None}[args.precision]
         out = {
             "metric": "Hausdorff pose-evals/sec (frames x poses) for 4-phase full align; best-pose match",
             "value": evals / dt,
@@ -808,7 +808,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": {"f32": "f32 screen (direct form) + f64 exact re-score", "fast": "f32 screen (expanded form) + f64 exact re-score",
+            "dtype": {"matrix": "f16 hi+lo matrix-pipe screen (fp32 accumulate) + f64 exact re-score",
+                      "f32": "f32 screen (direct form) + f64 exact re-score", "fast": "f32 screen (expanded form) + f64 exact re-score",
                       "bounded": "f32 lower bound + f32 screen (expanded form) of the survivors + f64 exact re-score",
                       "f64": "f64"}[args.precision],
             "data": "synthetic",
@@ -859,7 +860,7 @@ def main():
                 "frac_at_achieved_clock": ((achieved_tflops / peak) * 2.4 / pmc["achieved_clock_ghz"]
                                            if pmc and pmc.get("achieved_clock_ghz") else None),
                 "pmc_source": (pmc or {}).get("source"),
-                "kernel": {"f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
+                "kernel": {"matrix": "mm::k_screen_mx", "f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
                            "bounded": "mm::k_screen_lb<5, false>",
                            "f64": "mm::k_search<double,11,16,true,true,3>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),

@@ -57,7 +57,7 @@ enum {
     MM_PRECISION_F32_FAST = 2, /* same contract; screening in the expanded distance form
                              |a|^2 + |b|^2 - 2ab (25 % fewer packed instructions; absolute error
                              5*2^-24*(rho_a+rho_b)^2 on the squared value -> wider shortlist) */
-    MM_PRECISION_F32_BOUNDED = 3 /* same contract (winner and cost bit-identical to MM_PRECISION_F64);
+    MM_PRECISION_F32_BOUNDED = 3, /* same contract (winner and cost bit-identical to MM_PRECISION_F64);
                              before the expanded-form screen every candidate gets a LOWER bound of its
                              Hausdorff distance from every k-th point of either set against all points
                              of the other (2/k of the distance matrix), one full evaluation per pair
@@ -66,6 +66,11 @@ enum {
                              Falls back to MM_PRECISION_F32_FAST when per-candidate costs are requested,
                              the batch is small (mm_engine_set_bound_min_candidates)
                              or a set exceeds the bound kernel's LDS budget                          */
+    MM_PRECISION_F32_MATRIX = 4 /* same contract; the screen's squared distances come from the f16 matrix pipe: one
+                             v_mfma_f32_32x32x16_f16 per 32 x 32 tile over coordinates split into f16 hi + lo pieces
+                             (22 significant bits, fp32 accumulation; absolute error 128*2^-24*(rho_a+rho_b)^2 on the
+                             squared value -> a wider shortlist, same winners and costs after the exact re-score).  For
+                             sets of 449 .. 544 points; other levels fall back to MM_PRECISION_F32_FAST             */
 };
 
 /* flags of one search */

@@ -10,7 +10,7 @@ package directory name contains a hyphen.
 from __future__ import annotations
 
 from . import _native
-from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_BOUNDED, MM_PRECISION_F32_FAST, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Comm, Engine,
+from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_BOUNDED, MM_PRECISION_F32_FAST, MM_PRECISION_F32_MATRIX, MM_PRECISION_F64, MM_SEARCH_SKIP_ZERO, Batch, Comm, Engine,
                       IndexedBatch, Plan,
                       device_count, filter_points_in_region, refine_angles, refine_downsample_count, search_angles)
 from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
@@ -49,5 +49,5 @@ __all__ = [
     "find_aortic_wall_scaling", "find_distal_and_proximal_scaling", "find_aorta_scaling",
     "find_points_by_cl_region", "clean_outlier_points",
     "synthetic_case", "synthetic_pullback", "catheter_points", "contour_centroid",
-    "MM_PRECISION_F32", "MM_PRECISION_F32_BOUNDED", "MM_PRECISION_F32_FAST", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
+    "MM_PRECISION_F32", "MM_PRECISION_F32_BOUNDED", "MM_PRECISION_F32_FAST", "MM_PRECISION_F32_MATRIX", "MM_PRECISION_F64", "MM_SEARCH_SKIP_ZERO",
 ]

@@ -22,6 +22,7 @@ MM_PRECISION_F64 = 0
 MM_PRECISION_F32 = 1
 MM_PRECISION_F32_FAST = 2
 MM_PRECISION_F32_BOUNDED = 3
+MM_PRECISION_F32_MATRIX = 4
 MM_SEARCH_SKIP_ZERO = 1
 
 EXPORTS = [

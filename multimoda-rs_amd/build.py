@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmm_hausdorff.so")
 SOURCES = ["mm_kernels.hip", "mm_nn_kernels.hip", "mm_engine.cpp", "mm_host.cpp", "mm_centerline.cpp", "mm_ccta.cpp",
            "mm_build.cpp", "mm_frames.cpp", "mm_comm.cpp"]
-HEADERS = ["mm_device.h", "mm_engine.h", "mm_pool.h", "mm_sort.h", "mm_trace.h", os.path.join("..", "..", "include", "mm_hausdorff.h"),
+HEADERS = ["mm_device.h", "mm_engine.h", "mm_pool.h", "mm_sort.h", "mm_trace.h", "mm_screen_mx_asm.inc", os.path.join("..", "..", "include", "mm_hausdorff.h"),
            os.path.join("..", "..", "include", "mm_centerline.h"), os.path.join("..", "..", "include", "mm_ccta.h"),
            os.path.join("..", "..", "include", "mm_build.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

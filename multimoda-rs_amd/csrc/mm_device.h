@@ -20,7 +20,7 @@ struct PairDesc {
     int32_t ang_full;         // length of the pair's full candidate list (>= n_ang)
     int32_t ang_begin;        // first candidate of the slice this plan owns
     int32_t n_slice;          // candidates in the slice (== n_ang, except for empty-set pairs: n_ang = 0 there)
-    int32_t pad0;
+    int32_t pad0;             // k_screen_mx: scale exponent e (coordinates are multiplied by 2^e); otherwise 0
     double  cx, cy;           // rotation centre (exact kernel)
     double  delta;            // f32 screening error bound (same unit as the costs)
     double  tol2;             // candidates within tol2 of the exact minimum are reported as near-ties
@@ -89,6 +89,11 @@ struct BatchDev {
 // Launchers (mm_kernels.hip).  All asynchronous on `s`.
 hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
+// matrix-pipe screen (MM_PRECISION_F32_MATRIX): every pair's sets must have mx_min_points() .. mx_max_points() points and
+// PairDesc::pad0 must hold the pair's scale exponent (k_screen_mx)
+hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s);
+int        mx_min_points();
+int        mx_max_points();
 int        max_rows_fast();
 int        max_target_points_fast();
 // bounded screen: lower bound of every lb_candidate_step()-th candidate -> per-pair pick -> full screen of

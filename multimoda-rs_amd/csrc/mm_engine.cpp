@@ -233,9 +233,9 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     slice_end = angle_end;
     P = (int)pairs.size();
     if (precision != MM_PRECISION_F64 && precision != MM_PRECISION_F32 && precision != MM_PRECISION_F32_FAST &&
-        precision != MM_PRECISION_F32_BOUNDED)
-        return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64, MM_PRECISION_F32, MM_PRECISION_F32_FAST or "
-                                         "MM_PRECISION_F32_BOUNDED");
+        precision != MM_PRECISION_F32_BOUNDED && precision != MM_PRECISION_F32_MATRIX)
+        return set_error(MM_ERR_INVALID, "precision must be MM_PRECISION_F64, MM_PRECISION_F32, MM_PRECISION_F32_FAST, "
+                                         "MM_PRECISION_F32_BOUNDED or MM_PRECISION_F32_MATRIX");
     // Non-finite (or overflowing) coordinates: the reference's metric skips the points whose distances are not finite
     // (process_utils.rs:112-114) and carries on.  The exact kernels do the same; a screen cannot bound such values, so
     // every candidate of this level is scored exactly.  (rho = inf marks such a set, see stage_sets / k_build_sets.)
@@ -251,7 +251,8 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
                 precision = MM_PRECISION_F64;
                 break;
             }
-    const bool expanded = precision == MM_PRECISION_F32_FAST || precision == MM_PRECISION_F32_BOUNDED;
+    const bool expanded = precision == MM_PRECISION_F32_FAST || precision == MM_PRECISION_F32_BOUNDED ||
+                          precision == MM_PRECISION_F32_MATRIX;
     if (angle_begin < 0) angle_begin = 0;
 
     TraceTimer tt_desc("stage_level: descriptors");
@@ -322,6 +323,33 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     use_fast = expanded && max_na <= max_rows_fast() && max_nbp <= max_target_points_fast();
     if (expanded && !use_fast)
         for (PairDesc& d : host_pairs) d.e2 = 0.0;
+    // Matrix-pipe screen: every non-trivial pair's sets within the kernel's fixed 17 x 17 tiling, a scale exponent that
+    // puts the larger radius into [256, 512) (f16 pieces, their doubles and |x|^2 / 256 stay in range), and the wider
+    // error bound of its squared values: e2 = 128 u (rho_a + rho_b)^2 -- f16 hi + lo split of both points (<= 2^-22 rho
+    // per coordinate, 2^-13 absolute if a lo piece were flushed), the norms' f32 rounding and split, twelve fp32
+    // accumulations of unknown rounding mode (2 u each at the magnitude of (rho_a + rho_b)^2).  Anything else: the
+    // packed-FMA screen.
+    use_mx = false;
+    if (precision == MM_PRECISION_F32_MATRIX && use_fast && A > 0) {
+        use_mx = true;
+        for (int p = 0; p < P && use_mx; ++p) {
+            PairDesc& d = host_pairs[p];
+            if (trivial[p] || d.n_ang == 0) continue;
+            const double rmax = std::max(set_rho[pairs[p].ref_set], set_rho[pairs[p].tgt_set]);
+            if (d.n_ref < mx_min_points() || d.n_ref > mx_max_points() || d.n_tgt < mx_min_points() || d.n_tgt > mx_max_points() ||
+                !(rmax > 1.0e-30) || !(rmax < 1.0e30)) { use_mx = false; break; }
+        }
+        if (use_mx)
+            for (int p = 0; p < P; ++p) {
+                PairDesc& d = host_pairs[p];
+                if (trivial[p] || d.n_ang == 0) continue;
+                const double rs = set_rho[pairs[p].ref_set] + set_rho[pairs[p].tgt_set];
+                int k = 0;
+                (void)std::frexp(std::max(set_rho[pairs[p].ref_set], set_rho[pairs[p].tgt_set]) * (1.0 + 1e-6), &k);   // radius < 2^k
+                d.pad0 = 9 - k;
+                d.e2 = 128.0 * 5.9604644775390625e-08 * rs * rs;
+            }
+    }
     // the bound rounds pay for themselves on sets of a few dozen points or more and on batches that keep
     // the device busy for several rounds of workgroups (a dozen dependent launches cost more than
     // screening a small batch outright: the between stage's 2 x 722 candidates are 40 % faster without);
@@ -495,7 +523,8 @@ int Plan::run(bool screen_only)
             if (eng->profile) { eng->bound_offered += A; eng->bound_round1 += lb_sparse_total; }
         } else {
             if ((prc = eng->profile_begin(s))) return prc;
-            e = use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s);
+            e = use_mx ? launch_screen_mx(dev, s)
+                       : (use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s));
             if (e != hipSuccess) return hip_error(e, "screen kernel launch");
             if ((prc = eng->profile_end(s, pair_evals, A))) return prc;
         }

@@ -126,6 +126,7 @@ struct Plan {
     std::vector<uint8_t> trivial;             // pair has an empty set: every cost is 0.0
     bool want_costs = false;
     bool use_fast = false;                    // expanded-form screening kernel selected
+    bool use_mx = false;                      // matrix-pipe screening kernel selected (MM_PRECISION_F32_MATRIX)
     bool use_lb = false;                      // lower-bound pass in front of the screen (MM_PRECISION_F32_BOUNDED)
     int W_lb = 0, lb_stride = 0, lb_runs_cap = 0, max_nt = 1;
     double lb_pair_evals = 0.0;               // pair-distances of the first bound round

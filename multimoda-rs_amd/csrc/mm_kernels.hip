@@ -520,6 +520,196 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
     }
 }
 
+
+// -------------------------------------------------------------------------------------
+// Matrix-pipe screening kernel (MM_PRECISION_F32_MATRIX).  Same contract and work decomposition as
+// k_screen_fast -- one workgroup = (pair, <= 8 consecutive candidates), one screened squared Hausdorff
+// value per candidate, the exact f64 re-score decides every winner -- but the squared distances come from
+// the f16 matrix pipe:
+//     d^2 = |a|^2 + |b|^2 - 2 a.b   as ONE v_mfma_f32_32x32x16_f16 per 32 x 32 tile (1024 distances),
+// every coordinate split into f16 hi + lo pieces (22 significant bits), fp32 accumulation.  K slots of a
+// fragment (lane l: row or column l & 31, slots 8 * (l >> 5) .. + 7):
+//     rows    A:  [-2x1, -2x1, -2y1, -2y1, -2x2, -2x2, -2y2, -2y2 | n2h, n2l, 256, 1,   0, 0,   0,   0]
+//     columns B:  [  x1,   x2,   y1,   y2,   x1,   x2,   y1,   y2 | 256,   1, n2h, n2l, 256, 1, n2h, n2l]
+// (a column fragment's slots 4..7 repeat its slots 0..3, so it is stored as 8 bytes and read twice)
+// with x = S * (coordinate), S = 2^e chosen per pair so that the larger set radius lands in [256, 512) (all pieces,
+// their doubles and n2 / 256 stay inside f16's range), n2 = |x~|^2 of the split point, n2 = 256 * n2h + n2l.
+// The vector pipe is left with the minima: per tile 8 v_min3_i32 fold its 16 values into the column minimum and
+// 8 more take the elementwise row minima of two tiles at once.  tools/ubench_mfma16c.hip: hand-ordered, the MFMA
+// runs entirely beside the 16 minima (34 ns per tile per SIMD against 82 for the packed-FMA form); the compiler's
+// own schedule does not (46 ns), so the main phase is one generated asm block (tools/gen_screen_mx.py).
+// Wave w of the workgroup owns row tiles w, w + 4, w + 8, w + 12 and, for candidate c, wave c & 3 the 17th.
+// Row minima cross the 32 column lanes through a wave-private LDS transpose; column minima cross the waves through
+// ds_min_i32.  Error of the screened value: PairDesc::e2 = 128 u (rho_a + rho_b)^2 (mm_engine.cpp).
+// Sets of 449 .. 544 points (15 - 17 tiles a side are computed as 17); anything else takes k_screen_fast.
+// -------------------------------------------------------------------------------------
+#include "mm_screen_mx_asm.inc"
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+
+static constexpr int MX_T = 17;                 // tiles a side
+static constexpr int MX_N = MX_T * 32;          // 544 padded points
+static constexpr int MX_RED = 32 * (MM_SCREEN_MX_RED_STRIDE / 4);   // ints of one wave's reduction scratch
+
+static __device__ __forceinline__ void mx_split(float X, _Float16& h, _Float16& l)
+{
+    h = (_Float16)X;
+    l = (_Float16)(X - (float)h);
+}
+
+// fragment of one point for lane half `hi` (0: coordinate slots, 1: norm slots); ROWS: the A (row) form
+template <bool ROWS>
+static __device__ __forceinline__ h8v mx_fragment(float X, float Y, int hi)
+{
+    _Float16 x1, x2, y1, y2;
+    mx_split(X, x1, x2);
+    mx_split(Y, y1, y2);
+    h8v f;
+    if (hi == 0) {
+        if (ROWS) {
+            const _Float16 m = (_Float16)-2.0f;
+            f = h8v{m * x1, m * x1, m * y1, m * y1, m * x2, m * x2, m * y2, m * y2};
+        } else {
+            f = h8v{x1, x2, y1, y2, x1, x2, y1, y2};
+        }
+    } else {
+        const float xs = (float)x1 + (float)x2, ys = (float)y1 + (float)y2;          // the split point, exact in f32
+        const float n2 = __builtin_fmaf(xs, xs, ys * ys);
+        const _Float16 nh = (_Float16)(n2 * 0.00390625f);
+        const _Float16 nl = (_Float16)__builtin_fmaf(-256.0f, (float)nh, n2);
+        const _Float16 c256 = (_Float16)256.0f, one = (_Float16)1.0f, z = (_Float16)0.0f;
+        if (ROWS) f = h8v{nh, nl, c256, one, z, z, z, z};
+        else      f = h8v{c256, one, nh, nl, c256, one, nh, nl};
+    }
+    return f;
+}
+
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+
+size_t lds_bytes_mx()
+{
+    return (size_t)MX_T * 64 * 16 + (size_t)MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + (size_t)MX_N * 4 + 32 * 4 + 16;
+}
+
+// both (8-byte) fragments of one column -- the coordinate half and the norm half -- from the rotated, scaled point
+static __device__ __forceinline__ void mx_col_fragments(float X, float Y, h4v& f0, h4v& f1)
+{
+    _Float16 x1, x2, y1, y2;
+    mx_split(X, x1, x2);
+    mx_split(Y, y1, y2);
+    f0 = h4v{x1, x2, y1, y2};
+    const float xs = (float)x1 + (float)x2, ys = (float)y1 + (float)y2;
+    const float n2 = __builtin_fmaf(xs, xs, ys * ys);
+    const _Float16 nh = (_Float16)(n2 * 0.00390625f);
+    const _Float16 nl = (_Float16)__builtin_fmaf(-256.0f, (float)nh, n2);
+    f1 = h4v{(_Float16)256.0f, (_Float16)1.0f, nh, nl};
+}
+
+__global__ void __launch_bounds__(256, 3)
+k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
+            const float* __restrict__ ptx, const float* __restrict__ pty,
+            const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [17][64] row fragments
+    h4v* s_bf = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [17][64] column fragments of the candidate, 8 bytes each
+    int* s_redx = reinterpret_cast<int*>(s_bf + MX_T * 64);          // [4][MX_RED] row-reduction scratch, one per wave
+    int* s_colmin = s_redx + 4 * MX_RED;                             // [544]
+    int* s_row16 = s_colmin + MX_N;                                  // [32] row minima of row tile 16 (all four waves)
+    int* s_red = s_row16 + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
+    // LDS byte addresses of this lane's slots (generator docstring); a generic pointer's low 32 bits are its LDS offset
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned vB = lds0 + (unsigned)((size_t)s_bf - (size_t)smem) + lane * 8;
+    const unsigned vA = lds0 + (unsigned)((size_t)s_a - (size_t)smem) + (wave * 64 + lane) * 16;
+    const unsigned vA16 = lds0 + (unsigned)((size_t)s_a - (size_t)smem) + (16 * 64 + lane) * 16;
+    const unsigned red_w = lds0 + (unsigned)((size_t)s_redx - (size_t)smem) + wave * MX_RED * 4;
+    const unsigned vRW = red_w + (hi * 16) * MM_SCREEN_MX_RED_STRIDE + l32 * 4;
+    const int rh = (l32 >> 2) & 1, rv = (l32 & 3) + 4 * (l32 >> 3);        // row l32 of a tile lives at (half rh, element rv)
+    const unsigned vRR = red_w + (rh * 16 + rv) * MM_SCREEN_MX_RED_STRIDE + hi * 64;
+    const unsigned vCM = lds0 + (unsigned)((size_t)s_colmin - (size_t)smem) + l32 * 4;
+    const unsigned vR16 = lds0 + (unsigned)((size_t)s_row16 - (size_t)smem) + l32 * 4;
+    const unsigned vPERM = (unsigned)((lane ^ 32) * 4);
+
+    for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
+         wi += gridDim.x) {
+        const WorkItem w = work[wi];
+        const PairDesc pd = pairs[w.pair];
+        const int na = pd.n_ref, nb = pd.n_tgt;
+        const float S = __builtin_ldexpf(1.0f, pd.pad0), inv_s2 = __builtin_ldexpf(1.0f, -2 * pd.pad0);
+
+        __syncthreads();
+        for (int slot = tid; slot < MX_T * 64; slot += 256) {
+            const int rt = slot >> 6, l = slot & 63, row = rt * 32 + (l & 31);
+            const int rc = row < na ? row : na - 1;      // padding rows duplicate the last reference point
+            s_a[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], l >> 5);
+        }
+        // this thread's columns (their unrotated, scaled coordinates stay in registers for all candidates)
+        float tx[3], ty[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = tid + 256 * q;
+            const int jc = j < nb ? j : nb - 1;          // padding columns duplicate the last point (see k_screen_fast)
+            tx[q] = S * ptx[pd.tgt_off + jc]; ty[q] = S * pty[pd.tgt_off + jc];
+        }
+
+        for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
+            const float c = cosv[pd.tab_off + a], s = sinv[pd.tab_off + a];
+            __syncthreads();  // S0: the previous candidate's readers are done with s_bf / s_colmin / s_red
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int j = tid + 256 * q;
+                if (j < MX_N) {
+                    const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
+                    const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
+                    h4v f0, f1;
+                    mx_col_fragments(bx, by, f0, f1);
+                    const int slot = (j >> 5) * 64 + (j & 31);
+                    s_bf[slot] = f0;
+                    s_bf[slot + 32] = f1;
+                    s_colmin[j] = 0x7f800000;
+                }
+            }
+            if (tid < 32) s_row16[tid] = 0x7f800000;
+            if (tid == 0) s_red[0] = 0;
+            __syncthreads();  // S1
+
+            int rowmax;
+            const int variant = __builtin_amdgcn_readfirstlane((wave + a) & 3);   // which quarter of row tile 16 is this wave's
+            asm volatile(MM_SCREEN_MX_ASM
+                         : "=v"(rowmax)
+                         : "v"(vB), "v"(vA), "v"(vA16), "v"(vRW), "v"(vRR), "v"(vCM), "v"(vPERM), "v"(vR16), "s"(variant)
+                         : MM_SCREEN_MX_CLOBBERS);
+
+            __syncthreads();  // S2: all column minima and the row minima of tile 16 are in LDS
+            int m = rowmax;
+            for (int j = tid; j < nb; j += 256) {
+                const int v = s_colmin[j];
+                m = v > m ? v : m;
+            }
+            if (tid < 32) { const int v = s_row16[tid]; m = v > m ? v : m; }
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
+            if (lane == 0) atomicMax(&s_red[0], m);
+            __syncthreads();  // S3
+            if (tid == 0) out_sq[pd.out_off + a] = __int_as_float(s_red[0]) * inv_s2;
+        }
+    }
+}
+
+hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s)
+{
+    const size_t lds = lds_bytes_mx();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_screen_mx, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y, b.cos32,
+                       b.sin32, b.sq32);
+    return hipGetLastError();
+}
+int mx_min_points() { return 449; }
+int mx_max_points() { return MX_N; }
+
 // -------------------------------------------------------------------------------------
 // Bounded screen.  For subsets A' of the reference set and B' of the target set,
 //     L = max( max_{a in A'} min_{b in B} d(a,b),  max_{b in B'} min_{a in A} d(a,b) )  <=  H(A,B):

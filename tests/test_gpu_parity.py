@@ -781,3 +781,59 @@ def test_shift_rotation_extension_bounded_equals_full_screen(engine, mm):
     a, b = out
     assert np.array_equal(a["best_idx"], b["best_idx"]) and np.array_equal(a["best_cost"], b["best_cost"])
     assert np.array_equal(a["best_angle"], b["best_angle"]) and a["winners"] == b["winners"]
+
+
+# ---------------------------------------------------------------------------------------
+# MM_PRECISION_F32_MATRIX: the screen on the f16 matrix pipe (k_screen_mx)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("na,nb", [(521, 521), (544, 544), (449, 544), (500, 470), (543, 449)])
+@pytest.mark.parametrize("scale,offset", [(1.0, (4.5, 4.5)), (37.0, (-900.0, 120.0)), (1e-3, (0.0, 0.0)), (2.0 ** 20, (1e7, -3e6))])
+def test_matrix_screen_winner_cost_and_interval(engine, oracle, mm, na, nb, scale, offset):
+    """One search through the matrix-pipe screen at set sizes across its 15 .. 17 tile range, at coordinate scales far
+    from mm: the winner, its angle and its cost are the oracle's (exact re-score), and EVERY candidate's exact cost lies
+    in the interval the screened value promises, [sqrt(max(0, S - e2)) - delta, sqrt(S + e2) + delta] with
+    e2 = 128 * 2^-24 * (rho_a + rho_b)^2 -- observed errors stay far inside it."""
+    rng = np.random.default_rng(na * 1000 + nb)
+    ref = (blob(rng, na) - 4.5) * scale + np.array(offset)
+    tgt = (blob(rng, nb) - 4.5) * scale + np.array(offset)
+    c = tgt.mean(axis=0)
+    centre = (float(c[0]), float(c[1]))
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    oc = oracle.costs_over_angles(ref, tgt, angles, centre[0], centre[1])
+    want = int(np.argmin(oc))
+    bi, ba, bc, costs = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True, precision=mm.MM_PRECISION_F32_MATRIX,
+                                             return_costs=True)
+    assert bi == want and ba == angles[want] and bc == oc[want]
+    rho = max(np.sqrt(((ref - c) ** 2).sum(1)).max(), 0.0) + np.sqrt(((tgt - c) ** 2).sum(1)).max()
+    e2 = 128 * 2.0 ** -24 * rho * rho
+    delta = 24 * 2.0 ** -24 * rho + 2.0 ** -49 * (abs(c).sum() + rho) + 1e-300
+    S = np.asarray(costs) ** 2
+    lo = np.sqrt(np.maximum(0.0, S - e2)) - delta
+    hi = np.sqrt(S + e2) + delta
+    exact = np.isclose(costs, oc, rtol=0, atol=0)                 # re-scored candidates carry the exact cost
+    assert ((oc >= lo) & (oc <= hi))[~exact].all()
+    err2 = np.abs(S - oc ** 2)[~exact]
+    assert err2.size and err2.max() < 0.25 * e2                   # the bound is not tight: a factor 4 in hand
+
+
+def test_matrix_screen_falls_back_outside_its_tile_range(engine, oracle, mm):
+    """Sets of fewer than 449 or more than 544 points take the packed-FMA screen; same results either way."""
+    rng = np.random.default_rng(5)
+    angles, _, _ = mm.search_angles(2.0, 90.0)
+    for na, nb in ((200, 200), (448, 521), (600, 521), (521, 30)):
+        ref, tgt = blob(rng, na), blob(rng, nb)
+        c = tgt.mean(axis=0)
+        oc = oracle.costs_over_angles(ref, tgt, angles, float(c[0]), float(c[1]))
+        bi, ba, bc = engine.best_rotation(ref, tgt, angles, (float(c[0]), float(c[1])), skip_zero=True,
+                                          precision=mm.MM_PRECISION_F32_MATRIX)
+        assert bi == int(np.argmin(oc)) and bc == oc[bi]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_matrix_screen_chain_equals_oracle(engine, oracle, mm, mode):
+    g = [mm.synthetic_pullback(9, 501, pullback_id=i) for i in range(2)]
+    og = [to_oracle(oracle, x) for x in g]
+    logs, _ = mm.align_within(engine, g, 1.0, 180.0, True, 501, precision=mm.MM_PRECISION_F32_MATRIX, mode=mode)
+    for x, o, lg in zip(g, og, logs):
+        assert lg == oracle.align_within_chain(o, 1.0, 180.0, True, 501, n_threads=8)
+        assert geoms_equal(x, o)
