@@ -656,7 +656,8 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
 
         for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
             const float c = cosv[pd.tab_off + a], s = sinv[pd.tab_off + a];
-            __syncthreads();  // S0: the previous candidate's readers are done with s_bf / s_colmin / s_red
+            // (no barrier here: the loop top follows S3 of the previous candidate, or the barrier above -- every reader of
+            // s_bf / s_colmin / s_row16 is past it, and s_red[0] is read and reset by the same thread)
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int j = tid + 256 * q;
