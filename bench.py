@@ -191,6 +191,7 @@ def committed_pmc(workload, precision):
     FETCH_SIZE can under-report wide streaming reads by up to 2x; these are dword loads, uncalibrated) and the quantity
     that actually saturates: VALU issue.  None where no matching profile is committed."""
     names = {("config3", "fast"): ["r3_config3_fast_pmc_summary.csv", "r2_config3_fast_pmc_summary.csv"],
+             ("config3", "matrix"): ["r3_config3_matrix_pmc_summary.csv"],
              ("config3", "f32"): ["r1_config3_pmc_summary.csv"]}.get((workload, precision), [])
     path = next((os.path.join(ROOT, "profiles", n) for n in names if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if not path:
@@ -198,7 +199,7 @@ def committed_pmc(workload, precision):
     import csv
     val, dur, grid = {}, {}, 0
     for r in csv.DictReader(open(path)):
-        if r["kernel"].startswith(("k_screen_fast", "k_search<float")):
+        if r["kernel"].startswith(("k_screen_mx",) if precision == "matrix" else ("k_screen_fast", "k_search<float")):
             g = int(r["grid_threads"])
             if g >= grid:
                 if g > grid:
@@ -214,6 +215,13 @@ def committed_pmc(workload, precision):
         out["valu_instr_per_launch"] = val["SQ_INSTS_VALU"]
         if dur.get("GRBM_GUI_ACTIVE"):
             out["achieved_clock_ghz"] = cycles / dur["GRBM_GUI_ACTIVE"]
+        if "SQ_INSTS_MFMA" in val and val["SQ_INSTS_MFMA"] > 0:
+            # matrix-pipe screen: one MFMA per 32 x 32 tile; the vector pipe folds it with 16 minima at best.  An MFMA holds
+            # the SIMD's vector issue for 8 of its 32 cycles (MI355X_MICROARCH.md), a vector instruction for 4.
+            out["mfma_per_launch"] = val["SQ_INSTS_MFMA"]
+            out["valu_instr_per_tile"] = val["SQ_INSTS_VALU"] / val["SQ_INSTS_MFMA"]
+            out["vector_issue_busy"] = (4.0 * val["SQ_INSTS_VALU"] + 8.0 * val["SQ_INSTS_MFMA"]) / 1024.0 / cycles
+            out["matrix_pipe_busy"] = 32.0 * val["SQ_INSTS_MFMA"] / 1024.0 / cycles
     return out
 
 
@@ -378,10 +386,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)   # the first two big launches of a process run at ramping clocks
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="decoupled", choices=["chain", "decoupled"])
-    ap.add_argument("--precision", default="fast", choices=["f32", "fast", "bounded", "f64", "matrix"],
-                    help="candidate scoring: f32 = direct-form f32 screen + exact f64 re-score; fast = expanded-form "
-                         "f32 screen + exact f64 re-score (default; the same workload through the bounded search and "
-                         "through the all-f64 kernel is reported beside it); bounded = lower bounds rule candidates out "
+    ap.add_argument("--precision", default="matrix", choices=["f32", "fast", "bounded", "f64", "matrix"],
+                    help="candidate scoring: matrix = squared distances from the f16 matrix pipe (hi + lo split, fp32 "
+                         "accumulate), minima on the vector pipe + exact f64 re-score (default; the same workload through "
+                         "the packed-FMA screen, the bounded search and the all-f64 kernel is reported beside it); f32 = "
+                         "direct-form f32 screen + exact f64 re-score; fast = expanded-form "
+                         "f32 screen + exact f64 re-score; bounded = lower bounds rule candidates out "
                          "before the screen (not pose-evals in SURVEY 8(d)'s sense: for measurements of that path, "
                          "never the headline); f64 = every candidate in exact f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -587,7 +597,8 @@ def main():
                     "ms_per_step": leg["dt"] / k * 1e3, "steps": k, "pose_evals_per_step": leg["evals"] // k,
                     "grid": "bruteforce=False, 0.5 deg x +-90 deg (levels: 1 deg x +-90, 0.5 deg x +-5 around the level-1 winner)",
                     "chain_steps_researched_on_chain_state": leg["unresolved"],
-                    "dominant_launch": dom, "kernel": "mm::k_screen_fast<33, false> (level 0: 181 candidates per pair)",
+                    "dominant_launch": dom,
+                    "kernel": ("mm::k_screen_mx" if args.precision == "matrix" else "mm::k_screen_fast<33, false>") + " (level 0: 181 candidates per pair)",
                     "identical_to_oracle_first_63_chain_steps_of_pullback_0": bool(same_inputs and got == list(ol)),
                     "note": "two dependent launches per step (the second level's candidate lists depend on the first level's "
                             "winners: one host round trip between them); the full-size oracle comparison runs in "
@@ -605,7 +616,7 @@ def main():
             eng = engs[0]
             out = {}
             res = {}
-            for name, prec in (("bruteforce", mm.MM_PRECISION_F32_FAST), ("bounded", mm.MM_PRECISION_F32_BOUNDED)):
+            for name, prec in (("bruteforce", PREC), ("bounded", mm.MM_PRECISION_F32_BOUNDED)):
                 srs = mm.ShiftRotationSearch(eng, base, lo, hi, ecfg["step_deg"], ecfg["range_deg"], ecfg["sample_size"], precision=prec)
                 eng.synchronize()
                 eng.profile(True)
@@ -623,8 +634,9 @@ def main():
                     out.update({"value": srs.pose_evals / dt_, "unit": "pose-evals/s", "ms_per_step": dt_ * 1e3, "steps": 1,
                                 "pose_evals_per_step": srs.pose_evals, "pairs": int(srs.meta.shape[0]), "candidates_per_pair": len(srs.angles),
                                 "roofline": {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                             "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "executed_op_frac": tf / FP32_VECTOR_PEAK_TFLOPS * 7.0 / 12.0,
-                                             "kernel": "mm::k_screen_fast<33, false>", "launches": pr["launches"],
+                                             "frac": tf / FP32_VECTOR_PEAK_TFLOPS,
+                                             "kernel": "mm::k_screen_mx" if args.precision == "matrix" else "mm::k_screen_fast<33, false>",
+                                             "launches": pr["launches"],
                                              "avg_launch_ms": pr["ms"] / max(pr["launches"], 1)}})
                 else:
                     out["bounded"] = {"candidates_resolved_per_s": srs.pose_evals / dt_, "ms_per_step": dt_ * 1e3}
@@ -732,7 +744,19 @@ def main():
 
     extra = {}
     # (N = 1 only: at N > 1 the line is the scaling measurement and nothing else is put between it and the driver)
-    if args.precision == "fast" and ext is None and mode == 1 and not args.no_extra_legs and world == 1:
+    if args.precision in ("fast", "matrix") and ext is None and mode == 1 and not args.no_extra_legs and world == 1:
+        if args.precision == "matrix":
+            # The packed-FMA screen (MM_PRECISION_F32_FAST), the headline kernel of rounds 1-2, on the same steps
+            try:
+                leg = timed_leg(mm.MM_PRECISION_F32_FAST, 1, args.steps, pipelined)
+                lms, lpe, lprof, _ = leg["prof"]
+                extra["fast_screen"] = {"value": leg["evals"] / leg["dt"], "unit": "pose-evals/s", "ms_per_step": leg["dt"] / args.steps * 1e3,
+                                        "steps": args.steps, "identical_to_headline_result": same_result(leg),
+                                        "kernel": "mm::k_screen_fast<33, false>", "dominant_launch": dominant_launch(lms, lpe),
+                                        "note": "expanded-form f32 screen on the vector pipe alone: 2.5 instructions per distance, "
+                                                "issue-saturated (4.02 clk per wave-instruction, profiles/r3_config3_fast_pmc_summary.csv)"}
+            except Exception as ex:
+                extra["fast_screen"] = {"error": f"{type(ex).__name__}: {ex}"}
         # The same workload through MM_PRECISION_F32_BOUNDED (lower bounds rule most candidates out before the
         # screen; winners identical).  Reported beside the headline, never as `value`: a candidate that is ruled
         # out is resolved, not evaluated, so these are not pose-evals in SURVEY 8(d)'s sense.
@@ -855,7 +879,11 @@ def main():
                 "traffic": (pmc or {}).get("traffic"),
                 # what saturates (committed --pmc passes of the same launch): a SIMD issues one VALU wave-instruction
                 # per 4 clocks at best -> valu_clk_per_instr 4.0 = back-to-back issue; the nominal peak assumes 2.4 GHz
-                "valu_clk_per_instr": (pmc or {}).get("valu_clk_per_instr"),
+                "valu_clk_per_instr": (pmc or {}).get("valu_clk_per_instr") if args.precision != "matrix" else None,
+                # matrix-pipe screen: what saturates is still vector ISSUE -- 16 minima per 1024-distance tile at best
+                "valu_instr_per_tile": (pmc or {}).get("valu_instr_per_tile"),
+                "vector_issue_busy": (pmc or {}).get("vector_issue_busy"),
+                "matrix_pipe_busy": (pmc or {}).get("matrix_pipe_busy"),
                 "achieved_clock_ghz": (pmc or {}).get("achieved_clock_ghz"),
                 "frac_at_achieved_clock": ((achieved_tflops / peak) * 2.4 / pmc["achieved_clock_ghz"]
                                            if pmc and pmc.get("achieved_clock_ghz") else None),
@@ -865,7 +893,13 @@ def main():
                            "f64": "mm::k_search<double,11,16,true,true,3>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "dominant_launch": dominant_launch(launch_ms, launch_pe, peak),
-                "note": "point-set min/max metric: bounded by VALU issue (SURVEY 8(d)), not HBM/MFMA; achieved = ALGORITHMIC "
+                "note": ("MATRIX-PIPE SCREEN: d^2 = |a|^2 + |b|^2 - 2 a.b as one v_mfma_f32_32x32x16_f16 per 32 x 32 tile (f16 hi + lo "
+                         "pieces, fp32 accumulate), the vector pipe keeps the minima (16 v_min3_i32 per tile at best).  `frac` is "
+                         "SURVEY 8(d)'s algorithmic FLOP against the fp32 VECTOR peak and exceeds 1 because the distance arithmetic no "
+                         "longer runs there; what bounds the kernel is vector issue: vector_issue_busy = (4 clk x vector "
+                         "instructions + 8 clk x MFMAs) / cycles per SIMD, valu_instr_per_tile against the floor of 16; "
+                         "matrix_pipe_busy = 32 clk x MFMAs / cycles.  " if args.precision == "matrix" else "") +
+                        "point-set min/max metric: bounded by VALU issue (SURVEY 8(d)), not HBM/MFMA; achieved = ALGORITHMIC "
                         "rate: pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every launch on "
                         "the kernel's stream); executed_op_frac = the same launches priced by the lane-operations the kernel "
                         "executes (each squared distance is computed once and serves both directed terms: 7 issue slots "

@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
+#include <cstdio>
 
 #include "mm_device.h"
 #include "../../include/mm_hausdorff.h"
@@ -553,7 +555,14 @@ static constexpr int MX_RED = 32 * (MM_SCREEN_MX_RED_STRIDE / 4);   // ints of o
 
 static __device__ __forceinline__ void mx_split(float X, _Float16& h, _Float16& l)
 {
-    h = (_Float16)X;
+    // X and h are made opaque to the optimiser.  Without that the compiler fuses the producer of X (the rotation's fma)
+    // with the conversion (v_fma_mixlo_f16: ONE rounding of the exact fma to f16) where it computes the residual, and
+    // converts the f32 value (v_cvt_pk_f16_f32) where it packs the fragment: at f16 ties the two disagree by one ulp of h
+    // and the stored pair (h, l) no longer sums to X -- one column in a few thousand came out a quarter unit off.
+    asm volatile("" : "+v"(X));
+    unsigned hb = __builtin_bit_cast(unsigned short, (_Float16)X);
+    asm volatile("" : "+v"(hb));
+    h = __builtin_bit_cast(_Float16, (unsigned short)hb);
     l = (_Float16)(X - (float)h);
 }
 
@@ -586,10 +595,6 @@ static __device__ __forceinline__ h8v mx_fragment(float X, float Y, int hi)
 
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
-size_t lds_bytes_mx()
-{
-    return (size_t)MX_T * 64 * 16 + (size_t)MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + (size_t)MX_N * 4 + 32 * 4 + 16;
-}
 
 // both (8-byte) fragments of one column -- the coordinate half and the norm half -- from the rotated, scaled point
 static __device__ __forceinline__ void mx_col_fragments(float X, float Y, h4v& f0, h4v& f1)
@@ -605,18 +610,19 @@ static __device__ __forceinline__ void mx_col_fragments(float X, float Y, h4v& f
     f1 = h4v{(_Float16)256.0f, (_Float16)1.0f, nh, nl};
 }
 
-__global__ void __launch_bounds__(256, 3)
+template <int NB>   // candidates per barrier round: their column fragments are resident together
+__global__ void __launch_bounds__(256, NB == 1 ? 3 : 2)
 k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
             const float* __restrict__ ptx, const float* __restrict__ pty,
             const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [17][64] row fragments
-    h4v* s_bf = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [17][64] column fragments of the candidate, 8 bytes each
-    int* s_redx = reinterpret_cast<int*>(s_bf + MX_T * 64);          // [4][MX_RED] row-reduction scratch, one per wave
-    int* s_colmin = s_redx + 4 * MX_RED;                             // [544]
-    int* s_row16 = s_colmin + MX_N;                                  // [32] row minima of row tile 16 (all four waves)
-    int* s_red = s_row16 + 32;
+    h4v* s_bf = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [NB][17][64] column fragments, 8 bytes each
+    int* s_redx = reinterpret_cast<int*>(s_bf + NB * MX_T * 64);     // [4][MX_RED] row-reduction scratch, one per wave
+    int* s_colmin = s_redx + 4 * MX_RED;                             // [NB][544]
+    int* s_row16 = s_colmin + NB * MX_N;                             // [NB][32] row minima of row tile 16 (all four waves)
+    int* s_red = s_row16 + NB * 32;                                  // [NB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
     // LDS byte addresses of this lane's slots (generator docstring); a generic pointer's low 32 bits are its LDS offset
@@ -654,59 +660,90 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
             tx[q] = S * ptx[pd.tgt_off + jc]; ty[q] = S * pty[pd.tgt_off + jc];
         }
 
-        for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
-            const float c = cosv[pd.tab_off + a], s = sinv[pd.tab_off + a];
-            // (no barrier here: the loop top follows S3 of the previous candidate, or the barrier above -- every reader of
-            // s_bf / s_colmin / s_row16 is past it, and s_red[0] is read and reset by the same thread)
+        for (int a0 = w.a0; a0 < w.a0 + w.cnt; a0 += NB) {
+            const int nc = (w.a0 + w.cnt - a0) < NB ? (w.a0 + w.cnt - a0) : NB;
+            // (no barrier here: the loop top follows S3 of the previous round, or the barrier above -- every reader of
+            // s_bf / s_colmin / s_row16 is past it, and s_red is read and reset by the same thread)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int j = tid + 256 * q;
-                if (j < MX_N) {
-                    const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
-                    const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
-                    h4v f0, f1;
-                    mx_col_fragments(bx, by, f0, f1);
-                    const int slot = (j >> 5) * 64 + (j & 31);
-                    s_bf[slot] = f0;
-                    s_bf[slot + 32] = f1;
-                    s_colmin[j] = 0x7f800000;
+            for (int u = 0; u < NB; ++u) {
+                if (u >= nc) break;
+                const float c = cosv[pd.tab_off + a0 + u], s = sinv[pd.tab_off + a0 + u];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = tid + 256 * q;
+                    if (j < MX_N) {
+                        const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
+                        const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
+                        h4v f0, f1;
+                        mx_col_fragments(bx, by, f0, f1);
+                        const int slot = u * MX_T * 64 + (j >> 5) * 64 + (j & 31);
+                        s_bf[slot] = f0;
+                        s_bf[slot + 32] = f1;
+                        s_colmin[u * MX_N + j] = 0x7f800000;
+                    }
                 }
+                if (tid < 32) s_row16[u * 32 + tid] = 0x7f800000;
+                if (tid == 0) s_red[u] = 0;
             }
-            if (tid < 32) s_row16[tid] = 0x7f800000;
-            if (tid == 0) s_red[0] = 0;
             __syncthreads();  // S1
 
-            int rowmax;
-            const int variant = __builtin_amdgcn_readfirstlane((wave + a) & 3);   // which quarter of row tile 16 is this wave's
-            asm volatile(MM_SCREEN_MX_ASM
-                         : "=v"(rowmax)
-                         : "v"(vB), "v"(vA), "v"(vA16), "v"(vRW), "v"(vRR), "v"(vCM), "v"(vPERM), "v"(vR16), "s"(variant)
-                         : MM_SCREEN_MX_CLOBBERS);
+            int rowmax[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                rowmax[u] = 0;
+                if (u >= nc) break;
+                const int variant = __builtin_amdgcn_readfirstlane((wave + a0 + u) & 3);   // this wave's quarter of row tile 16
+                const unsigned vBu = vB + u * MX_T * 64 * 8, vCMu = vCM + u * MX_N * 4, vR16u = vR16 + u * 32 * 4;
+                asm volatile(MM_SCREEN_MX_ASM
+                             : "=v"(rowmax[u])
+                             : "v"(vBu), "v"(vA), "v"(vA16), "v"(vRW), "v"(vRR), "v"(vCMu), "v"(vPERM), "v"(vR16u), "s"(variant)
+                             : MM_SCREEN_MX_CLOBBERS);
+            }
 
             __syncthreads();  // S2: all column minima and the row minima of tile 16 are in LDS
-            int m = rowmax;
-            for (int j = tid; j < nb; j += 256) {
-                const int v = s_colmin[j];
-                m = v > m ? v : m;
-            }
-            if (tid < 32) { const int v = s_row16[tid]; m = v > m ? v : m; }
 #pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
-            if (lane == 0) atomicMax(&s_red[0], m);
+            for (int u = 0; u < NB; ++u) {
+                if (u >= nc) break;
+                int m = rowmax[u];
+                for (int j = tid; j < nb; j += 256) {
+                    const int v = s_colmin[u * MX_N + j];
+                    m = v > m ? v : m;
+                }
+                if (tid < 32) { const int v = s_row16[u * 32 + tid]; m = v > m ? v : m; }
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
+                if (lane == 0) atomicMax(&s_red[u], m);
+            }
             __syncthreads();  // S3
-            if (tid == 0) out_sq[pd.out_off + a] = __int_as_float(s_red[0]) * inv_s2;
+            if (tid < nc) out_sq[pd.out_off + a0 + tid] = __int_as_float(s_red[tid]) * inv_s2;
         }
     }
 }
 
-hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s)
+template <int NB>
+static size_t lds_bytes_mx_nb()
 {
-    const size_t lds = lds_bytes_mx();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return (size_t)MX_T * 64 * 16 + (size_t)NB * MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + (size_t)NB * MX_N * 4 + NB * 32 * 4 + 16;
+}
+size_t lds_bytes_mx() { return lds_bytes_mx_nb<1>(); }
+
+template <int NB>
+static hipError_t launch_screen_mx_nb(const BatchDev& b, hipStream_t s)
+{
+    const size_t lds = lds_bytes_mx_nb<NB>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_screen_mx, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y, b.cos32,
+    hipLaunchKernelGGL(k_screen_mx<NB>, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y, b.cos32,
                        b.sin32, b.sq32);
     return hipGetLastError();
+}
+
+hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s)
+{
+    // one candidate per barrier round and three workgroups per CU; two per round (their column fragments resident
+    // together, fewer barriers, two workgroups per CU) measured 4 % slower: MM_MX_NB=2 (tuning knob, tools only)
+    static const int nb = std::getenv("MM_MX_NB") ? std::atoi(std::getenv("MM_MX_NB")) : 1;
+    return nb == 2 ? launch_screen_mx_nb<2>(b, s) : launch_screen_mx_nb<1>(b, s);
 }
 int mx_min_points() { return 449; }
 int mx_max_points() { return MX_N; }

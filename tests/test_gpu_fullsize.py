@@ -68,11 +68,11 @@ def _oracle_alignment(oracle, mm, name):
     return _oracle_cache[name]
 
 
-@pytest.mark.parametrize("precision", ["fast", "bounded"])
+@pytest.mark.parametrize("precision", ["fast", "bounded", "matrix"])
 @pytest.mark.parametrize("name", ["config2", "config3"])
 def test_full_four_phase_alignment_equals_oracle(fresh_engine, oracle, mm, name, precision):
     cfg = CONFIGS[name]
-    prec = {"fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED}[precision]
+    prec = {"fast": mm.MM_PRECISION_F32_FAST, "bounded": mm.MM_PRECISION_F32_BOUNDED, "matrix": mm.MM_PRECISION_F32_MATRIX}[precision]
     ologs, orot, ogeoms = _oracle_alignment(oracle, mm, name)
     geoms = mm.synthetic_case(cfg["frames"], cfg["points"])
     plan = mm.WithinPlan(fresh_engine, geoms, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"], precision=prec)
@@ -91,8 +91,9 @@ def test_full_four_phase_alignment_equals_oracle(fresh_engine, oracle, mm, name,
         assert geoms_equal(g, og), f"coordinates of pullback {k} differ"
 
 
+@pytest.mark.parametrize("precision", ["fast", "matrix"])
 @pytest.mark.parametrize("grid", [(1, 2), (2, 1), (1, 8), (8, 1), (2, 4)])
-def test_config4_sharded_full_size_equals_oracle(fresh_engine, oracle, mm, grid):
+def test_config4_sharded_full_size_equals_oracle(fresh_engine, oracle, mm, grid, precision):
     """BASELINE config 4 at its workload: the config3 alignment (4 x 512 frames, 721 candidates) with the
     (frame pair x candidate) grid sharded over 2 and 8 ranks -- the pure candidate-axis split (1, W), the pure pair
     split (W, 1) and a mixed tile (2, 4) -- every "rank" a shard plan of this process, driven level by level with the
@@ -104,12 +105,13 @@ def test_config4_sharded_full_size_equals_oracle(fresh_engine, oracle, mm, grid)
     # the oracle's geometries have been through the between stage as well: compare with the within result
     world = grid[0] * grid[1]
     cases = [mm.synthetic_case(cfg["frames"], cfg["points"]) for _ in range(world)]
+    prec = {"fast": mm.MM_PRECISION_F32_FAST, "matrix": mm.MM_PRECISION_F32_MATRIX}[precision]
     plans = [mm.WithinPlan(fresh_engine, cases[r], cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                           precision=mm.MM_PRECISION_F32_FAST, shard=(r, grid[0], grid[1])) for r in range(world)]
+                           precision=prec, shard=(r, grid[0], grid[1])) for r in range(world)]
     D.search_inprocess(plans)
     single = mm.synthetic_case(cfg["frames"], cfg["points"])
     wp = mm.WithinPlan(fresh_engine, single, cfg["step_deg"], cfg["range_deg"], True, cfg["sample_size"],
-                       precision=mm.MM_PRECISION_F32_FAST)
+                       precision=prec)
     slogs, sevals, sunres = wp.run()
     wp.close()
     for r, p in enumerate(plans):
@@ -121,8 +123,9 @@ def test_config4_sharded_full_size_equals_oracle(fresh_engine, oracle, mm, grid)
             assert geoms_equal(cases[r][k], single[k]), f"rank {r}: coordinates of pullback {k} differ"
 
 
+@pytest.mark.parametrize("precision", ["fast", "matrix"])
 @pytest.mark.parametrize("step,rng_deg", [(0.5, 90.0), (0.05, 90.0)])
-def test_default_ladder_full_size_equals_oracle(fresh_engine, oracle, mm, step, rng_deg):
+def test_default_ladder_full_size_equals_oracle(fresh_engine, oracle, mm, step, rng_deg, precision):
     """The reference's DEFAULT mode (bruteforce=False, align_within.rs:193-247) at the config3 shape: 4 x 512 frames,
     0.5 deg x +-90 deg (two dependent levels, 202 evaluations per frame pair) and 0.05 deg (three levels, 303) -- the
     decoupled path's logs, evaluation count and coordinates against the oracle's sequential ladder chain."""
@@ -130,7 +133,8 @@ def test_default_ladder_full_size_equals_oracle(fresh_engine, oracle, mm, step, 
     og = [to_oracle(oracle, g) for g in geoms]
     th = _threads()
     ologs = [oracle.align_within_chain(o, step, rng_deg, False, 501, n_threads=th) for o in og]
-    plan = mm.WithinPlan(fresh_engine, geoms, step, rng_deg, False, 501, precision=mm.MM_PRECISION_F32_FAST)
+    plan = mm.WithinPlan(fresh_engine, geoms, step, rng_deg, False, 501,
+                         precision={"fast": mm.MM_PRECISION_F32_FAST, "matrix": mm.MM_PRECISION_F32_MATRIX}[precision])
     logs, evals, unresolved = plan.run()
     plan.close()
     # evaluations per search: 202 / 303 unless a finer level's window is clipped at +-range (limes);

@@ -127,7 +127,7 @@ def test_point_sets_far_smaller_than_their_coordinates(engine, oracle, mm):
     assert not ocosts.any()
     for q in (p, p + np.array([[0.0, 0.0], [3e-16, 0.0], [0.0, 5e-16]])):      # and a cloud of a few ulps
         oc = oracle.costs_over_angles(p, q, angles, float(c[0]), float(c[1]))
-        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED, mm.MM_PRECISION_F32_MATRIX):
             bi, ba, bc = engine.best_rotation(p, q, angles, (float(c[0]), float(c[1])), skip_zero=True, precision=prec)
             assert bi == int(np.argmin(oc)) and ba == angles[bi] and bc == oc[bi], prec
 
@@ -154,7 +154,7 @@ def test_non_finite_coordinates_follow_the_reference(engine, oracle, mm, n):
         o_angle = oracle.bruteforce_rotation(r, t, 1.0, 30.0, centre[0], centre[1], n_threads=8)
         o_cost = oracle.cost_within(r, t, o_angle, centre[0], centre[1])
         assert math.isfinite(o_cost)
-        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED, mm.MM_PRECISION_F32_MATRIX):
             bi, ba, bc = engine.best_rotation(r, t, angles, centre, skip_zero=True, precision=prec)
             assert bi >= 0 and ba == o_angle and bc == o_cost, prec
 
@@ -181,7 +181,7 @@ def test_coordinates_beyond_the_f32_range_of_the_screens(engine, oracle, mm, sca
         assert np.isfinite(oc).all()
         want = int(np.argmin(oc))
         assert engine.hausdorff(r, t) == oracle.hausdorff(r, t)
-        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+        for prec in (mm.MM_PRECISION_F64, mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED, mm.MM_PRECISION_F32_MATRIX):
             bi, ba, bc = engine.best_rotation(r, t, angles, centre, skip_zero=True, precision=prec)
             assert bi == want and ba == angles[want] and bc == oc[want], (prec, scale)
 
@@ -706,7 +706,7 @@ def test_four_concurrent_callers_each_with_its_own_engine(oracle, mm):
             out = []
             for rep in range(3):
                 ref, tgt = blob(rng, 200 + 40 * t), blob(rng, 180 + 30 * t)
-                prec = (mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED, mm.MM_PRECISION_F64)[(t + rep) % 4]
+                prec = (mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED, mm.MM_PRECISION_F64, mm.MM_PRECISION_F32_MATRIX)[(t + rep) % 5]
                 out.append((ref, tgt, eng.best_rotation(ref, tgt, angles, (4.5, 4.5), precision=prec)))
             geoms = [mm.synthetic_pullback(6 + t, 160, pullback_id=t), mm.synthetic_pullback(7, 160, pullback_id=t + 1)]
             logs, _ = mm.align_within(eng, geoms, 1.0, 90.0, True, 160, mode=t % 2)
@@ -837,3 +837,25 @@ def test_matrix_screen_chain_equals_oracle(engine, oracle, mm, mode):
     for x, o, lg in zip(g, og, logs):
         assert lg == oracle.align_within_chain(o, 1.0, 180.0, True, 501, n_threads=8)
         assert geoms_equal(x, o)
+
+
+def test_matrix_screen_against_the_packed_fma_screen_on_a_large_batch(engine, oracle, mm):
+    """108 300 candidates (300 pairs x 361 rotations, 8 candidates per workgroup): every screened cost of the matrix-pipe
+    screen within 1e-4 of the packed-FMA screen's, winners and exact costs identical.  Regression test: the compiler
+    once fused the rotation's fma into ONE of the two f32 -> f16 conversions of a coordinate (v_fma_mixlo_f16 against
+    v_cvt_pk_f16_f32), so that at f16 ties the hi and lo pieces of a column no longer summed to the coordinate -- 18 of
+    these candidates were off by up to 1e-2 while every smaller test passed (mx_split makes the value opaque now)."""
+    rng = np.random.default_rng(1)
+    P = 300
+    refs = [blob(rng, 521) for _ in range(P)]
+    tgts = [blob(rng, 521) for _ in range(P)]
+    angles, _, _ = mm.search_angles(1.0, 180.0)
+    cs = [t.mean(axis=0) for t in tgts]
+    batch = mm.Batch(refs, tgts, [angles] * P, [(float(c[0]), float(c[1])) for c in cs])
+    a = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32_FAST, return_costs=True)
+    b = engine.best_rotation_batch(batch, precision=mm.MM_PRECISION_F32_MATRIX, return_costs=True)
+    assert np.array_equal(a["best_idx"], b["best_idx"]) and np.array_equal(a["best_cost"], b["best_cost"])
+    assert np.abs(a["costs"] - b["costs"]).max() < 1e-4
+    for p in range(0, P, 37):                                # and the winners are the oracle's
+        o = oracle.bruteforce_rotation(refs[p], tgts[p], 1.0, 180.0, float(cs[p][0]), float(cs[p][1]), n_threads=8)
+        assert b["best_angle"][p] == o

@@ -78,7 +78,7 @@ def test_one_search_all_precisions_match_the_oracle(engine, oracle, mm, seed, na
     bi64, ba, bc, costs = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True, precision=mm.MM_PRECISION_F64,
                                                return_costs=True)
     assert bi64 == int(np.argmin(costs)) and ba == o_angle and bc == o_cost == costs[bi64], (bi64, ba, o_angle, bc, o_cost)
-    for prec in (mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED):
+    for prec in (mm.MM_PRECISION_F32, mm.MM_PRECISION_F32_FAST, mm.MM_PRECISION_F32_BOUNDED, mm.MM_PRECISION_F32_MATRIX):
         bi, ba, bc = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True, precision=prec)
         assert bi == bi64 and ba == o_angle and bc == o_cost, (prec, bi, bi64, ba, o_angle, bc, o_cost)
 

@@ -65,7 +65,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("exchange", ["gather", "device"])
-@pytest.mark.parametrize("precision", [2, 3])
+@pytest.mark.parametrize("precision", [2, 3, 4])
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES)
 def test_sharded_within_plan_equals_single_rank_and_oracle(engine, oracle, mm, bruteforce, step, rng_deg, ss, world,
@@ -90,7 +90,7 @@ def test_sharded_within_plan_equals_single_rank_and_oracle(engine, oracle, mm, b
 
 
 @pytest.mark.parametrize("exchange", ["gather", "device"])
-@pytest.mark.parametrize("precision", [2, 3])
+@pytest.mark.parametrize("precision", [2, 3, 4])
 @pytest.mark.parametrize("grid", [(2, 1), (3, 1), (2, 2), (2, 4), (4, 2), (8, 1), (27, 1), (32, 1)])
 @pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES)
 def test_grid_sharded_within_plan_equals_single_rank_and_oracle(engine, oracle, mm, bruteforce, step, rng_deg, ss, grid,
@@ -123,7 +123,7 @@ def test_default_shard_grid():
     assert N.shard_grid(1, 5) == (1, 1) and N.shard_grid(6, 1000) == (6, 1) and N.shard_grid(6, 200) == (3, 2)
 
 
-@pytest.mark.parametrize("precision", [2, 3])
+@pytest.mark.parametrize("precision", [2, 3, 4])
 @pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES)
 def test_native_rccl_search_world1(engine, oracle, mm, bruteforce, step, rng_deg, ss, precision):
     """mm_within_plan_run_sharded's search half on a world = 1 RCCL communicator owned by the library (mm_comm_*):

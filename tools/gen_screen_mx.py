@@ -31,6 +31,8 @@ PART = [(0, 5), (5, 9), (9, 13), (13, 17)]          # column tiles of row tile 1
 
 out = []
 emit = out.append
+DBG_NOP = int(os.environ.get("MX_DBG_NOP", "0"))           # s_nop 15 count in front of every group of minima
+DBG_BLOCKING = os.environ.get("MX_DBG_BLOCKING") == "1"    # no staged reductions
 
 
 def mfma(d, a, b):
@@ -166,6 +168,8 @@ def row_tile(a, tiles, previous, a_next=None):
         m = mins_pair(px, py, CM + tiles[2 * p - 2], CM + tiles[2 * p - 1], first=(p == 1))
         emit("s_waitcnt lgkmcnt(0)")
         mfma(x, a, BSET[p & 1])
+        for _ in range(DBG_NOP):
+            emit("s_nop 15")
         for line in m[:16]:
             emit(line)
         mfma(y, a, BSET[p & 1] + 4)
@@ -180,9 +184,13 @@ def row_tile(a, tiles, previous, a_next=None):
         tb = bufs(npairs)[0]
         emit("s_waitcnt lgkmcnt(0)")
         mfma(tb, a, BSET[npairs & 1])
+    for _ in range(DBG_NOP):
+        emit("s_nop 15")
     for line in m:
         emit(line)
     if odd:
+        for _ in range(DBG_NOP):
+            emit("s_nop 15")
         mins_single(tb, CM + tiles[n - 1])
 
 
@@ -192,7 +200,7 @@ for ct in range(NCT):
 emit(f"v_mov_b32 v{ROWMAX}, 0")
 for k in range(4):
     nxt = (ASET[(k + 1) & 1], "%2", 4096 * (k + 1)) if k < 3 else (ASET[0], "%3", 0)
-    row_tile(ASET[k & 1], list(range(NCT)), "staged" if k > 0 else None, nxt)
+    row_tile(ASET[k & 1], list(range(NCT)), ("blocking" if DBG_BLOCKING else "staged") if k > 0 else None, nxt)
 # the wave's share of row tile 16 (its A fragment is in ASET[0])
 for var in range(4):
     if var < 3:
