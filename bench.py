@@ -77,7 +77,7 @@ def full_alignment(mm, eng, geoms, cfg, plan=None, precision=1):
     return logs, rot, evals + e2, unresolved
 
 
-def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None, stager=False, pre=None):
+def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None, stager=False, pre=None, finishers=1):
     """Run steps `ks`: search(k) then finish(k), and -- if `stage` is given -- stage(k + lookahead) after
     finish(k) (the caller has staged the first `lookahead` steps of `ks` itself: priming), so a call over K steps
     does K stagings, K searches and K finishes.
@@ -93,7 +93,9 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
     device when step k's launch ends: the device does not idle while the host fetches, commits and launches.
     pre (optional, with begin): pre(k) is called before begin(k+1, k) -- the sharded search enqueues step k's whole
     exchange there (exports, all-reduces, record copy; nothing waited for), so that begin(k+1, k) can order step k+1's
-    launch behind it."""
+    launch behind it.
+    finishers: host threads that finish steps (chain walk + between alignments, ~2.8 ms per step): one keeps up with a
+    20-30 ms step; at N = 8 a step is 2.5 ms and two take turns."""
     ks = list(ks)
     if not pipelined:
         out = []
@@ -142,7 +144,8 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
             stage(j)
             ready[j].set()
 
-    threads = [threading.Thread(target=guarded(finisher), name="bench-finish")]
+    threads = [threading.Thread(target=guarded(finisher), name=f"bench-finish-{i}") for i in range(max(1, finishers))]
+    n_fin = len(threads)
     if stage is not None and stager:
         threads.append(threading.Thread(target=guarded(stage_worker), name="bench-stage"))
     for th in threads:
@@ -175,10 +178,12 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
                 search(k)                         # collect step k (waits for its kernels), remaining levels, commit
             q.put(k)
     finally:
-        q.put(None)
-        threads[0].join()
+        for _ in range(n_fin):
+            q.put(None)
+        for th in threads[:n_fin]:
+            th.join()
         sq.put(None)
-        for th in threads[1:]:
+        for th in threads[n_fin:]:
             th.join()
     if err:
         raise err[0]
@@ -480,8 +485,9 @@ def main():
     # three engines (main stream, side stream, staging buffers each): step k lives on engine k % 3, so the search of
     # step k+1, the finish of step k and the staging of step k+3 (which takes over step k's engine once that is
     # finished) never share one, and each of the three has a host thread of its own
-    # (N > 1: four -- a step is an eighth as long there, and finish(k) -> stage(k + LOOK) has to fit into LOOK - 1 steps)
-    LOOK = int(os.environ.get("MM_BENCH_ENGINES", "4" if (world > 1 or rehearse > 1) else "3"))
+    # (N > 1: five, and two finishing threads -- a step is an eighth as long there: finish(k) -> stage(k + LOOK) has to fit
+    # into LOOK - 1 steps, and with two steps being finished at once two more engines are taken)
+    LOOK = int(os.environ.get("MM_BENCH_ENGINES", "5" if (world > 1 or rehearse > 1) else "3"))
     if LOOK < 2:
         raise SystemExit("MM_BENCH_ENGINES must be >= 2")
     engs = [mm.Engine(local_rank) for _ in range(LOOK)]
@@ -558,13 +564,14 @@ def main():
         gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
         # (collected BEFORE the warm-up: a collection between warm-up and timed region idles the device for ~40 ms,
         # and the first big launch after such a pause runs 34.9 instead of 31.3 ms -- the clocks have dropped)
-        run_steps(range(warmup), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre)
+        nfin = int(os.environ.get("MM_BENCH_FINISHERS", "2" if sharded else "1"))
+        run_steps(range(warmup), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre, nfin)
         barrier()
         for e in engs:
             e.profile(True)
         r.stage_s, r.staged = 0.0, 0
         t0 = time.perf_counter()
-        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre)
+        results = run_steps(range(warmup, n_total), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre, nfin)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
