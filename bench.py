@@ -16,7 +16,9 @@ AC|BD between-pullback alignments, all through the product's C ABI.  Workloads
 `value` is the WHOLE step: the case starts on the host, its raw pullbacks go to HBM over PCIe, the
 search sets are built on the device, then search (N > 1: + the RCCL exchange), chain walk and between
 alignments.  Consecutive (independent) cases are pipelined: K stagings, K searches, K finishes inside
-the timed region.
+the timed region.  Candidates are scored by the matrix-pipe screen (MM_PRECISION_F32_MATRIX: squared distances from
+the f16 matrix pipe, minima on the vector pipe) + exact f64 re-score; the packed-FMA screen, the all-f64 kernel, the
+bounded search, the reference's default ladder and the extension grid are legs of the same line.
 
 Usage: python bench.py --gpus N --steps K --warmup W   (N > 1: under torch.distributed.run, or plainly --
 then the N ranks are started as a child job)

@@ -9,7 +9,8 @@
 // row-min (per reference point) and column-min (per target point) yields both directed
 // distances exactly.
 //
-// Mapping to the hardware (no MFMA: this is min/max over a point-set metric):
+// Mapping to the hardware (vector pipe; the one kernel that puts the distance arithmetic on the f16 matrix pipe and
+// keeps only the minima here is k_screen_mx, further down):
 //   * one workgroup = (pair, slice of its candidate angles); threads form a 16-wide
 //     lane grid: lj = tid & 15 picks columns (target points), li = tid >> 4 picks rows
 //     (reference points).  A DPP row (16 lanes) shares li, so row-min reduction is
