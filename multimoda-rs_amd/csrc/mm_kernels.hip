@@ -611,19 +611,36 @@ static __device__ __forceinline__ void mx_col_fragments(float X, float Y, h4v& f
     f1 = h4v{(_Float16)256.0f, (_Float16)1.0f, nh, nl};
 }
 
-template <int NB>   // candidates per barrier round: their column fragments are resident together
-__global__ void __launch_bounds__(256, NB == 1 ? 3 : 2)
+template <int CTRL>
+static __device__ __forceinline__ int dpp_max_i32(int v)
+{
+    const int o = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xF, 0xF, false);
+    return o > v ? o : v;
+}
+// max over the wave without an LDS round trip: four DPP steps inside each row of 16 lanes, then the four rows as scalars
+static __device__ __forceinline__ int wave_max_i32_dpp(int v)
+{
+    v = dpp_max_i32<0xB1>(v); v = dpp_max_i32<0x4E>(v); v = dpp_max_i32<0x141>(v); v = dpp_max_i32<0x140>(v);
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int a = r0 > r1 ? r0 : r1, c = r2 > r3 ? r2 : r3;
+    return a > c ? a : c;
+}
+
+__global__ void __launch_bounds__(256, 3)
 k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
             const float* __restrict__ ptx, const float* __restrict__ pty,
             const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [17][64] row fragments
-    h4v* s_bf = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [NB][17][64] column fragments, 8 bytes each
-    int* s_redx = reinterpret_cast<int*>(s_bf + NB * MX_T * 64);     // [4][MX_RED] row-reduction scratch, one per wave
-    int* s_colmin = s_redx + 4 * MX_RED;                             // [NB][544]
-    int* s_row16 = s_colmin + NB * MX_N;                             // [NB][32] row minima of row tile 16 (all four waves)
-    int* s_red = s_row16 + NB * 32;                                  // [NB]
+    h4v* s_bf = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [17][64] column fragments of the candidate, 8 bytes each
+    int* s_redx = reinterpret_cast<int*>(s_bf + MX_T * 64);          // [4][MX_RED] row-reduction scratch, one per wave
+    int* s_colmin = s_redx + 4 * MX_RED;                             // [2][544]   (double-buffered by candidate parity: the
+    int* s_row16 = s_colmin + 2 * MX_N;                              // [2][32]     fold of candidate c runs beside the
+    int* s_red = s_row16 + 2 * 32;                                   // [2]         fragment construction of c + 1)
+    int* s_cnt = s_red + 2;                                          // [2] waves that have folded their share
+    float* s_cs = reinterpret_cast<float*>(s_cnt + 2);               // [8][2] cos, sin of the work item's candidates
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
     // LDS byte addresses of this lane's slots (generator docstring); a generic pointer's low 32 bits are its LDS offset
@@ -647,6 +664,8 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         const float S = __builtin_ldexpf(1.0f, pd.pad0), inv_s2 = __builtin_ldexpf(1.0f, -2 * pd.pad0);
 
         __syncthreads();
+        // the candidates' cos / sin once per work item (a global load at the top of every candidate would be exposed)
+        if (tid < 16 && (tid >> 1) < w.cnt) s_cs[tid] = (tid & 1) ? sinv[pd.tab_off + w.a0 + (tid >> 1)] : cosv[pd.tab_off + w.a0 + (tid >> 1)];
         for (int slot = tid; slot < MX_T * 64; slot += 256) {
             const int rt = slot >> 6, l = slot & 63, row = rt * 32 + (l & 31);
             const int rc = row < na ? row : na - 1;      // padding rows duplicate the last reference point
@@ -660,91 +679,74 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
             const int jc = j < nb ? j : nb - 1;          // padding columns duplicate the last point (see k_screen_fast)
             tx[q] = S * ptx[pd.tgt_off + jc]; ty[q] = S * pty[pd.tgt_off + jc];
         }
+        __syncthreads();
 
-        for (int a0 = w.a0; a0 < w.a0 + w.cnt; a0 += NB) {
-            const int nc = (w.a0 + w.cnt - a0) < NB ? (w.a0 + w.cnt - a0) : NB;
-            // (no barrier here: the loop top follows S3 of the previous round, or the barrier above -- every reader of
-            // s_bf / s_colmin / s_row16 is past it, and s_red is read and reset by the same thread)
+        for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
+            const int pb = (a - w.a0) & 1;                                   // buffer of this candidate
+            // (no barrier here: every reader of s_bf is past S2 of the previous candidate; buffer pb of the minima was
+            // last read by the fold of the candidate before that one, which every wave finished before its S1 since)
+            const float c = s_cs[2 * (a - w.a0)], s = s_cs[2 * (a - w.a0) + 1];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                if (u >= nc) break;
-                const float c = cosv[pd.tab_off + a0 + u], s = sinv[pd.tab_off + a0 + u];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int j = tid + 256 * q;
-                    if (j < MX_N) {
-                        const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
-                        const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
-                        h4v f0, f1;
-                        mx_col_fragments(bx, by, f0, f1);
-                        const int slot = u * MX_T * 64 + (j >> 5) * 64 + (j & 31);
-                        s_bf[slot] = f0;
-                        s_bf[slot + 32] = f1;
-                        s_colmin[u * MX_N + j] = 0x7f800000;
-                    }
+            for (int q = 0; q < 3; ++q) {
+                const int j = tid + 256 * q;
+                if (j < MX_N) {
+                    const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
+                    const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
+                    h4v f0, f1;
+                    mx_col_fragments(bx, by, f0, f1);
+                    const int slot = (j >> 5) * 64 + (j & 31);
+                    s_bf[slot] = f0;
+                    s_bf[slot + 32] = f1;
+                    s_colmin[pb * MX_N + j] = 0x7f800000;
                 }
-                if (tid < 32) s_row16[u * 32 + tid] = 0x7f800000;
-                if (tid == 0) s_red[u] = 0;
             }
+            if (tid < 32) s_row16[pb * 32 + tid] = 0x7f800000;
+            if (tid == 0) { s_red[pb] = 0; s_cnt[pb] = 0; }
             __syncthreads();  // S1
 
-            int rowmax[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                rowmax[u] = 0;
-                if (u >= nc) break;
-                const int variant = __builtin_amdgcn_readfirstlane((wave + a0 + u) & 3);   // this wave's quarter of row tile 16
-                const unsigned vBu = vB + u * MX_T * 64 * 8, vCMu = vCM + u * MX_N * 4, vR16u = vR16 + u * 32 * 4;
-                asm volatile(MM_SCREEN_MX_ASM
-                             : "=v"(rowmax[u])
-                             : "v"(vBu), "v"(vA), "v"(vA16), "v"(vRW), "v"(vRR), "v"(vCMu), "v"(vPERM), "v"(vR16u), "s"(variant)
-                             : MM_SCREEN_MX_CLOBBERS);
-            }
+            int rowmax;
+            const int variant = __builtin_amdgcn_readfirstlane((wave + a) & 3);   // this wave's quarter of row tile 16
+            const unsigned vCMb = vCM + pb * MX_N * 4, vR16b = vR16 + pb * 32 * 4;
+            asm volatile(MM_SCREEN_MX_ASM
+                         : "=v"(rowmax)
+                         : "v"(vB), "v"(vA), "v"(vA16), "v"(vRW), "v"(vRR), "v"(vCMb), "v"(vPERM), "v"(vR16b), "s"(variant)
+                         : MM_SCREEN_MX_CLOBBERS);
 
             __syncthreads();  // S2: all column minima and the row minima of tile 16 are in LDS
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                if (u >= nc) break;
-                int m = rowmax[u];
-                for (int j = tid; j < nb; j += 256) {
-                    const int v = s_colmin[u * MX_N + j];
-                    m = v > m ? v : m;
-                }
-                if (tid < 32) { const int v = s_row16[u * 32 + tid]; m = v > m ? v : m; }
-#pragma unroll
-                for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_xor(m, sh, 64); m = o > m ? o : m; }
-                if (lane == 0) atomicMax(&s_red[u], m);
+            // fold: every thread its rows' maximum and its share of the column minima; one DPP reduction per wave; the
+            // last wave to arrive writes the candidate's value -- no third barrier, the others go on to the next candidate
+            int m = rowmax;
+            for (int j = tid; j < nb; j += 256) {
+                const int v = s_colmin[pb * MX_N + j];
+                m = v > m ? v : m;
             }
-            __syncthreads();  // S3
-            if (tid < nc) out_sq[pd.out_off + a0 + tid] = __int_as_float(s_red[tid]) * inv_s2;
+            if (tid < 32) { const int v = s_row16[pb * 32 + tid]; m = v > m ? v : m; }
+            m = wave_max_i32_dpp(m);
+            if (lane == 0) {
+                atomicMax(&s_red[pb], m);
+                __threadfence_block();
+                if (atomicAdd(&s_cnt[pb], 1) == 3) {
+                    __threadfence_block();
+                    out_sq[pd.out_off + a] = __int_as_float(atomicMax(&s_red[pb], 0)) * inv_s2;
+                }
+            }
         }
     }
 }
 
-template <int NB>
-static size_t lds_bytes_mx_nb()
+size_t lds_bytes_mx()
 {
-    return (size_t)MX_T * 64 * 16 + (size_t)NB * MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + (size_t)NB * MX_N * 4 + NB * 32 * 4 + 16;
-}
-size_t lds_bytes_mx() { return lds_bytes_mx_nb<1>(); }
-
-template <int NB>
-static hipError_t launch_screen_mx_nb(const BatchDev& b, hipStream_t s)
-{
-    const size_t lds = lds_bytes_mx_nb<NB>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_screen_mx<NB>, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y, b.cos32,
-                       b.sin32, b.sq32);
-    return hipGetLastError();
+    return (size_t)MX_T * 64 * 16 + (size_t)MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + (size_t)2 * MX_N * 4 + 2 * 32 * 4 + 16 + 64;
 }
 
 hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s)
 {
-    // one candidate per barrier round and three workgroups per CU; two per round (their column fragments resident
-    // together, fewer barriers, two workgroups per CU) measured 4 % slower: MM_MX_NB=2 (tuning knob, tools only)
-    static const int nb = std::getenv("MM_MX_NB") ? std::atoi(std::getenv("MM_MX_NB")) : 1;
-    return nb == 2 ? launch_screen_mx_nb<2>(b, s) : launch_screen_mx_nb<1>(b, s);
+    const size_t lds = lds_bytes_mx();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_screen_mx, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y, b.cos32,
+                       b.sin32, b.sq32);
+    return hipGetLastError();
 }
 int mx_min_points() { return 449; }
 int mx_max_points() { return MX_N; }

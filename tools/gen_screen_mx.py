@@ -4,8 +4,8 @@ fixed registers, so that the order is exactly the software pipeline we want -- t
 the matrix pipe) issued ahead of the 32 v_min3_i32 that fold the PREVIOUS two tiles on the vector pipe.  The compiler's
 scheduler does not produce this order (tools/ubench_mfma16*.hip: 46 ns per tile compiler-scheduled, 34 ns hand-ordered).
 
-One wave, one candidate: its four full row tiles (17 column tiles each) and its share of the 17th row tile (4 or 5 column
-tiles, chosen by the scalar operand `variant`), so that the four waves of a workgroup carry 72 or 73 tiles each.
+One wave, one candidate: its share of the 17th row tile (4 or 5 column tiles, chosen by the scalar operand `variant`) and
+its four full row tiles (17 column tiles each), so that the four waves of a workgroup carry 72 or 73 tiles each.
 The cross-lane reduction of a row tile's minima (LDS transpose: write, read back a row per lane, fold, meet the other
 half through ds_bpermute) is spread over the phases of the NEXT row tile, one LDS round trip per phase, each behind a
 wait the pipeline has anyway.
@@ -108,28 +108,40 @@ def red_final(shared):
 
 # stage s of the reduction of the PREVIOUS row tile, issued in phase s of the current one (after that phase's wait)
 RED_STAGES = {
-    0: lambda: red_write(),
-    1: lambda: red_read(0),
-    2: lambda: (red_fold(0), red_read(1)),
-    3: lambda: (red_fold(1), red_read(2)),
-    4: lambda: (red_fold(2), red_read(3)),
-    5: lambda: (red_fold(3), red_perm()),
-    6: lambda: red_final(False),
+    0: lambda shared: red_write(),
+    1: lambda shared: red_read(0),
+    2: lambda shared: (red_fold(0), red_read(1)),
+    3: lambda shared: (red_fold(1), red_read(2)),
+    4: lambda shared: (red_fold(2), red_read(3)),
+    5: lambda shared: (red_fold(3), red_perm()),
+    6: lambda shared: red_final(shared),
 }
 
 
 def reduction_blocking(shared):
+    """The last row tile of the candidate: nothing left to hide it behind.  All 16 values of a row are read back at once
+    (the result tiles are free: D2 as the landing zone), three LDS round trips in all."""
+    t = D[2]
     red_write()
-    for c in range(4):
-        red_read(c)
-        emit("s_waitcnt lgkmcnt(0)")
-        red_fold(c)
+    emit("s_waitcnt lgkmcnt(0)")
+    for q in range(8):
+        emit(f"ds_read_b64 v[{t + 2 * q}:{t + 2 * q + 1}], %5 offset:{8 * q}")
+    emit("s_waitcnt lgkmcnt(0)")
+    u = D[3]
+    emit(f"v_min3_i32 v{u}, v{t}, v{t + 1}, v{t + 2}")
+    emit(f"v_min3_i32 v{u + 1}, v{t + 3}, v{t + 4}, v{t + 5}")
+    emit(f"v_min3_i32 v{u + 2}, v{t + 6}, v{t + 7}, v{t + 8}")
+    emit(f"v_min3_i32 v{u + 3}, v{t + 9}, v{t + 10}, v{t + 11}")
+    emit(f"v_min3_i32 v{u + 4}, v{t + 12}, v{t + 13}, v{t + 14}")
+    emit(f"v_min3_i32 v{u}, v{u}, v{u + 1}, v{u + 2}")
+    emit(f"v_min3_i32 v{u + 3}, v{u + 3}, v{u + 4}, v{t + 15}")
+    emit(f"v_min_i32 v{ACC}, v{u}, v{u + 3}")
     red_perm()
     emit("s_waitcnt lgkmcnt(0)")
     red_final(shared)
 
 
-def row_tile(a, tiles, previous, a_next=None):
+def row_tile(a, tiles, previous, a_next=None, previous_shared=False):
     """All column tiles `tiles` against the row fragment in v[a:a+3].  Pairs of tiles go through D0/D1 and D2/D3 in
     turn: the two MFMAs of a pair are issued, then the 32 minima of the pair before; an odd last tile is folded alone.
     previous: None, 'staged' (the row tile before is reduced along the way, needs 8 pairs) or 'blocking'.
@@ -157,9 +169,9 @@ def row_tile(a, tiles, previous, a_next=None):
     if a_next is not None:
         emit(f"ds_read_b128 v[{a_next[0]}:{a_next[0] + 3}], {a_next[1]} offset:{a_next[2]}")
     if previous == "staged":
-        RED_STAGES[0]()
+        RED_STAGES[0](previous_shared)
     elif previous == "blocking":
-        reduction_blocking(False)
+        reduction_blocking(previous_shared)
     for p in range(1, npairs):
         # one MFMA, half of the previous pair's minima, the other MFMA, the other half: a wave never queues a second
         # MFMA behind its own first one (the matrix pipe takes 32 cycles per MFMA, 16 minima take 64)
@@ -175,7 +187,7 @@ def row_tile(a, tiles, previous, a_next=None):
         mfma(y, a, BSET[p & 1] + 4)
         prefetch(p + 1)
         if previous == "staged" and p in RED_STAGES:
-            RED_STAGES[p]()
+            RED_STAGES[p](previous_shared)
         for line in m[16:]:
             emit(line)
     lx, ly = bufs(npairs - 1)
@@ -194,24 +206,25 @@ def row_tile(a, tiles, previous, a_next=None):
         mins_single(tb, CM + tiles[n - 1])
 
 
-emit(f"ds_read_b128 v[{ASET[0]}:{ASET[0] + 3}], %2 offset:0")
+# The wave's share of row tile 16 FIRST (its reduction then rides on row tile 0's phases), then its four full row tiles;
+# only the last one's reduction has nothing to hide behind.
+emit(f"ds_read_b128 v[{ASET[0]}:{ASET[0] + 3}], %3 offset:0")
 for ct in range(NCT):
     emit(f"v_mov_b32 v{CM + ct}, {INF}")
 emit(f"v_mov_b32 v{ROWMAX}, 0")
-for k in range(4):
-    nxt = (ASET[(k + 1) & 1], "%2", 4096 * (k + 1)) if k < 3 else (ASET[0], "%3", 0)
-    row_tile(ASET[k & 1], list(range(NCT)), ("blocking" if DBG_BLOCKING else "staged") if k > 0 else None, nxt)
-# the wave's share of row tile 16 (its A fragment is in ASET[0])
 for var in range(4):
     if var < 3:
         emit(f"s_cmp_eq_u32 %9, {var}")
         emit(f"s_cbranch_scc0 {10 + var}f")
-    row_tile(ASET[0], list(range(*PART[var])), "blocking")
+    row_tile(ASET[0], list(range(*PART[var])), None, (ASET[1], "%2", 0))
     emit("s_branch 20f")
     if var < 3:
         emit(f"{10 + var}:")
 emit("20:")
-reduction_blocking(True)
+for k in range(4):
+    nxt = (ASET[k & 1], "%2", 4096 * (k + 1)) if k < 3 else None
+    row_tile(ASET[(k + 1) & 1], list(range(NCT)), "blocking" if DBG_BLOCKING else "staged", nxt, previous_shared=(k == 0))
+reduction_blocking(False)
 for ct in range(NCT):
     emit(f"ds_min_i32 %6, v{CM + ct} offset:{ct * 128}")
 emit("s_waitcnt lgkmcnt(0)")
