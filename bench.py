@@ -437,6 +437,11 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # Three or four host threads hand the interpreter lock around; with the default switch interval (5 ms) the thread that
+    # launches the next step can wait that long for a thread that is between two native calls -- longer than a whole step
+    # at N = 8.  0.2 ms keeps the hand-over far below a step.
+    sys.setswitchinterval(float(os.environ.get("MM_BENCH_SWITCH_INTERVAL", "0.0002")))
+
     import __graft_entry__ as ge
     ge.build()
     import multimoda_rs_amd as mm
