@@ -898,6 +898,10 @@ def main():
                 "valu_instr_per_tile": (pmc or {}).get("valu_instr_per_tile"),
                 "vector_issue_busy": (pmc or {}).get("vector_issue_busy"),
                 "matrix_pipe_busy": (pmc or {}).get("matrix_pipe_busy"),
+                # the MFMAs this kernel executes (289 tiles of 32 x 32 x 16 per candidate, K and the edges padded), live
+                "matrix_pipe": ({"achieved": prof["candidates"] * 289 * 32768.0 / kern_s * 1e-12, "peak": 2500.0, "unit": "TFLOP/s (f16 dense)",
+                                 "frac": prof["candidates"] * 289 * 32768.0 / kern_s * 1e-12 / 2500.0}
+                                if args.precision == "matrix" and kern_s > 0 else None),
                 "achieved_clock_ghz": (pmc or {}).get("achieved_clock_ghz"),
                 "frac_at_achieved_clock": ((achieved_tflops / peak) * 2.4 / pmc["achieved_clock_ghz"]
                                            if pmc and pmc.get("achieved_clock_ghz") else None),
