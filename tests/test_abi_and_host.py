@@ -163,3 +163,21 @@ def test_enumerations_terminate_on_steps_that_never_advance(built, mm):
         mm.search_angles(1e-300, 1.0, center=1.0, limes_deg=180.0)
     assert len(mm.search_angles(0.0001, 180.0)[0]) == 3600001                # a fine but finite grid still enumerates
     assert mm.refine_downsample_count(10, 0, 0) == 0 and mm.refine_downsample_count(0, 5, 0) == 1   # NaN / inf saturate like `as usize`
+
+
+def test_generated_asm_of_the_matrix_screen_is_current(tmp_path):
+    """csrc/mm_screen_mx_asm.inc is generated by tools/gen_screen_mx.py and committed: the committed text must be what the
+    generator writes today (an edit to one without the other would ship a kernel nobody can regenerate)."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "multimoda-rs_amd", "csrc", "mm_screen_mx_asm.inc")
+    committed = open(inc).read()
+    work = tmp_path / "repo"
+    (work / "tools").mkdir(parents=True)
+    (work / "multimoda-rs_amd" / "csrc").mkdir(parents=True)
+    shutil.copy(os.path.join(root, "tools", "gen_screen_mx.py"), work / "tools" / "gen_screen_mx.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MX_DBG")}
+    subprocess.check_call([sys.executable, str(work / "tools" / "gen_screen_mx.py")], env=env, stdout=subprocess.DEVNULL)
+    assert open(work / "multimoda-rs_amd" / "csrc" / "mm_screen_mx_asm.inc").read() == committed
