@@ -7,7 +7,7 @@ timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_prope
 rc=$?; echo "tests rc=$rc" >> gpurun_out/r3b_tests.txt; tail -3 gpurun_out/r3b_tests.txt
 [ $rc -eq 0 ] || exit $rc
 for i in 1 2 3; do
-  for v in old new; do
+  for v in new v3; do
     MM_LIB_PATH=$GRAFT_REPO_ROOT/ab/$v.so timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > gpurun_out/r3b_ab_${v}_$i.json 2> gpurun_out/r3b_ab_${v}_$i.err || exit 1
     python - <<PY
 import json

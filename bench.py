@@ -224,11 +224,21 @@ def committed_pmc(workload, precision):
             out["achieved_clock_ghz"] = cycles / dur["GRBM_GUI_ACTIVE"]
         if "SQ_INSTS_MFMA" in val and val["SQ_INSTS_MFMA"] > 0:
             # matrix-pipe screen: one MFMA per 32 x 32 tile; the vector pipe folds it with 16 minima at best.  An MFMA holds
-            # the SIMD's vector issue for 8 of its 32 cycles (MI355X_MICROARCH.md), a vector instruction for 4.
-            out["mfma_per_launch"] = val["SQ_INSTS_MFMA"]
-            out["valu_instr_per_tile"] = val["SQ_INSTS_VALU"] / val["SQ_INSTS_MFMA"]
-            out["vector_issue_busy"] = (4.0 * val["SQ_INSTS_VALU"] + 8.0 * val["SQ_INSTS_MFMA"]) / 1024.0 / cycles
-            out["matrix_pipe_busy"] = 32.0 * val["SQ_INSTS_MFMA"] / 1024.0 / cycles
+            # the SIMD's vector issue for 8 of its 32 cycles (MI355X_MICROARCH.md), a vector instruction for 4: two issue
+            # slots against one.  SQ_INSTS_VALU counts the MFMAs as well (the kernel's instruction count from its ISA --
+            # tests/test_screen_mx_asm.py for the asm block -- matches the counter only that way).
+            mf = val["SQ_INSTS_MFMA"]
+            vec = val["SQ_INSTS_VALU"] - mf
+            out["mfma_per_launch"] = mf
+            out["valu_instr_per_tile"] = vec / mf
+            out["vector_issue_busy"] = (4.0 * vec + 8.0 * mf) / 1024.0 / cycles
+            out["matrix_pipe_busy"] = 32.0 * mf / 1024.0 / cycles
+            if dur.get("GRBM_GUI_ACTIVE"):
+                # wall time per issue slot per SIMD; a stream of nothing but v_min3_i32 on every SIMD of the chip runs at
+                # 2.20 ns (3 waves per SIMD) / 2.38 ns (2 waves) per instruction: profiles/r3_ubench_mfma16c.txt
+                out["issue_slot_ns"] = dur["GRBM_GUI_ACTIVE"] / ((vec + 2.0 * mf) / 1024.0)
+                out["issue_slot_ns_min3_stream"] = {"waves_per_simd_2": 38.11 / 16.0, "waves_per_simd_3": 35.21 / 16.0,
+                                                    "source": "profiles/r3_ubench_mfma16c.txt"}
     return out
 
 
@@ -898,6 +908,8 @@ def main():
                 "valu_instr_per_tile": (pmc or {}).get("valu_instr_per_tile"),
                 "vector_issue_busy": (pmc or {}).get("vector_issue_busy"),
                 "matrix_pipe_busy": (pmc or {}).get("matrix_pipe_busy"),
+                "issue_slot_ns": (pmc or {}).get("issue_slot_ns"),
+                "issue_slot_ns_min3_stream": (pmc or {}).get("issue_slot_ns_min3_stream"),
                 # the MFMAs this kernel executes (289 tiles of 32 x 32 x 16 per candidate, K and the edges padded), live
                 "matrix_pipe": ({"achieved": prof["candidates"] * 289 * 32768.0 / kern_s * 1e-12, "peak": 2500.0, "unit": "TFLOP/s (f16 dense)",
                                  "frac": prof["candidates"] * 289 * 32768.0 / kern_s * 1e-12 / 2500.0}
@@ -914,9 +926,12 @@ def main():
                 "note": ("MATRIX-PIPE SCREEN: d^2 = |a|^2 + |b|^2 - 2 a.b as one v_mfma_f32_32x32x16_f16 per 32 x 32 tile (f16 hi + lo "
                          "pieces, fp32 accumulate), the vector pipe keeps the minima (16 v_min3_i32 per tile at best).  `frac` is "
                          "SURVEY 8(d)'s algorithmic FLOP against the fp32 VECTOR peak and exceeds 1 because the distance arithmetic no "
-                         "longer runs there; what bounds the kernel is vector issue: vector_issue_busy = (4 clk x vector "
-                         "instructions + 8 clk x MFMAs) / cycles per SIMD, valu_instr_per_tile against the floor of 16; "
-                         "matrix_pipe_busy = 32 clk x MFMAs / cycles.  " if args.precision == "matrix" else "") +
+                         "longer runs there; what bounds the kernel is vector issue: valu_instr_per_tile = vector instructions other "
+                         "than the MFMA per tile, against the floor of 16; an MFMA takes two issue slots; issue_slot_ns = the big "
+                         "launch's wall time per issue slot per SIMD, against issue_slot_ns_min3_stream, what a stream of nothing "
+                         "but v_min3_i32 on every SIMD of the chip achieves (tools/ubench_mfma16c.hip) -- the kernel issues at the "
+                         "rate the chip sustains for its instruction; vector_issue_busy = (4 clk x vector instructions + 8 clk x "
+                         "MFMAs) / cycles per SIMD with the cycles of GRBM_GUI_ACTIVE; matrix_pipe_busy = 32 clk x MFMAs / cycles.  " if args.precision == "matrix" else "") +
                         "point-set min/max metric: bounded by VALU issue (SURVEY 8(d)), not HBM/MFMA; achieved = ALGORITHMIC "
                         "rate: pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every launch on "
                         "the kernel's stream); executed_op_frac = the same launches priced by the lane-operations the kernel "

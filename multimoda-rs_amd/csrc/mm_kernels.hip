@@ -541,9 +541,10 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 // 8 more take the elementwise row minima of two tiles at once.  tools/ubench_mfma16c.hip: hand-ordered, the MFMA
 // runs entirely beside the 16 minima (34 ns per tile per SIMD against 82 for the packed-FMA form); the compiler's
 // own schedule does not (46 ns), so the main phase is one generated asm block (tools/gen_screen_mx.py).
-// Wave w of the workgroup owns row tiles w, w + 4, w + 8, w + 12 and, for candidate c, wave c & 3 the 17th.
-// Row minima cross the 32 column lanes through a wave-private LDS transpose; column minima cross the waves through
-// ds_min_i32.  Error of the screened value: PairDesc::e2 = 128 u (rho_a + rho_b)^2 (mm_engine.cpp).
+// The workgroup shares the pair's row fragments; below that every WAVE takes candidates of its own (a0 + wave, + 4, ...)
+// and computes all 17 x 17 tiles of each: column fragments in a wave-private LDS copy, column minima in registers for the
+// whole candidate, row minima across the 32 column lanes through a wave-private LDS transpose -- no barrier and no shared
+// accumulator in the candidate loop.  Error of the screened value: PairDesc::e2 = 128 u (rho_a + rho_b)^2 (mm_engine.cpp).
 // Sets of 449 .. 544 points (15 - 17 tiles a side are computed as 17); anything else takes k_screen_fast.
 // -------------------------------------------------------------------------------------
 #include "mm_screen_mx_asm.inc"
@@ -627,33 +628,28 @@ static __device__ __forceinline__ int wave_max_i32_dpp(int v)
     return a > c ? a : c;
 }
 
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, 2)
 k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
             const float* __restrict__ ptx, const float* __restrict__ pty,
             const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [17][64] row fragments
-    h4v* s_bf = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [17][64] column fragments of the candidate, 8 bytes each
-    int* s_redx = reinterpret_cast<int*>(s_bf + MX_T * 64);          // [4][MX_RED] row-reduction scratch, one per wave
-    int* s_colmin = s_redx + 4 * MX_RED;                             // [2][544]   (double-buffered by candidate parity: the
-    int* s_row16 = s_colmin + 2 * MX_N;                              // [2][32]     fold of candidate c runs beside the
-    int* s_red = s_row16 + 2 * 32;                                   // [2]         fragment construction of c + 1)
-    int* s_cnt = s_red + 2;                                          // [2] waves that have folded their share
-    float* s_cs = reinterpret_cast<float*>(s_cnt + 2);               // [8][2] cos, sin of the work item's candidates
+    h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [17][64] row fragments of the pair (all waves)
+    h4v* s_bw = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [4][17][64] column fragments, 8 bytes each: a wave's
+                                                                      //            own copy, for the candidate it is on
+    int* s_redx = reinterpret_cast<int*>(s_bw + 4 * MX_T * 64);      // [4][MX_RED] row-reduction scratch, one per wave
+    float* s_cs = reinterpret_cast<float*>(s_redx + 4 * MX_RED);     // [8][2] cos, sin of the work item's candidates
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
+    h4v* s_b = s_bw + wave * MX_T * 64;
     // LDS byte addresses of this lane's slots (generator docstring); a generic pointer's low 32 bits are its LDS offset
     const unsigned lds0 = (unsigned)(size_t)smem;
-    const unsigned vB = lds0 + (unsigned)((size_t)s_bf - (size_t)smem) + lane * 8;
-    const unsigned vA = lds0 + (unsigned)((size_t)s_a - (size_t)smem) + (wave * 64 + lane) * 16;
-    const unsigned vA16 = lds0 + (unsigned)((size_t)s_a - (size_t)smem) + (16 * 64 + lane) * 16;
+    const unsigned vB = lds0 + (unsigned)((size_t)s_b - (size_t)smem) + lane * 8;
+    const unsigned vA = lds0 + (unsigned)((size_t)s_a - (size_t)smem) + lane * 16;
     const unsigned red_w = lds0 + (unsigned)((size_t)s_redx - (size_t)smem) + wave * MX_RED * 4;
     const unsigned vRW = red_w + (hi * 16) * MM_SCREEN_MX_RED_STRIDE + l32 * 4;
     const int rh = (l32 >> 2) & 1, rv = (l32 & 3) + 4 * (l32 >> 3);        // row l32 of a tile lives at (half rh, element rv)
     const unsigned vRR = red_w + (rh * 16 + rv) * MM_SCREEN_MX_RED_STRIDE + hi * 64;
-    const unsigned vCM = lds0 + (unsigned)((size_t)s_colmin - (size_t)smem) + l32 * 4;
-    const unsigned vR16 = lds0 + (unsigned)((size_t)s_row16 - (size_t)smem) + l32 * 4;
     const unsigned vPERM = (unsigned)((lane ^ 32) * 4);
 
     for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
@@ -671,72 +667,48 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
             const int rc = row < na ? row : na - 1;      // padding rows duplicate the last reference point
             s_a[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], l >> 5);
         }
-        // this thread's columns (their unrotated, scaled coordinates stay in registers for all candidates)
-        float tx[3], ty[3];
+        // this lane's columns -- every wave holds all of them: lane + 64 q -- unrotated, scaled, in registers for all the
+        // wave's candidates
+        float tx[9], ty[9];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int j = tid + 256 * q;
+        for (int q = 0; q < 9; ++q) {
+            const int j = lane + 64 * q;
             const int jc = j < nb ? j : nb - 1;          // padding columns duplicate the last point (see k_screen_fast)
             tx[q] = S * ptx[pd.tgt_off + jc]; ty[q] = S * pty[pd.tgt_off + jc];
         }
         __syncthreads();
 
-        for (int a = w.a0; a < w.a0 + w.cnt; ++a) {
-            const int pb = (a - w.a0) & 1;                                   // buffer of this candidate
-            // (no barrier here: every reader of s_bf is past S2 of the previous candidate; buffer pb of the minima was
-            // last read by the fold of the candidate before that one, which every wave finished before its S1 since)
+        // one wave, one candidate: no barrier and nothing shared below this line
+        for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
             const float c = s_cs[2 * (a - w.a0)], s = s_cs[2 * (a - w.a0) + 1];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int j = tid + 256 * q;
+            for (int q = 0; q < 9; ++q) {
+                const int j = lane + 64 * q;
                 if (j < MX_N) {
                     const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
                     const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
                     h4v f0, f1;
                     mx_col_fragments(bx, by, f0, f1);
                     const int slot = (j >> 5) * 64 + (j & 31);
-                    s_bf[slot] = f0;
-                    s_bf[slot + 32] = f1;
-                    s_colmin[pb * MX_N + j] = 0x7f800000;
+                    s_b[slot] = f0;
+                    s_b[slot + 32] = f1;
                 }
             }
-            if (tid < 32) s_row16[pb * 32 + tid] = 0x7f800000;
-            if (tid == 0) { s_red[pb] = 0; s_cnt[pb] = 0; }
-            __syncthreads();  // S1
-
-            int rowmax;
-            const int variant = __builtin_amdgcn_readfirstlane((wave + a) & 3);   // this wave's quarter of row tile 16
-            const unsigned vCMb = vCM + pb * MX_N * 4, vR16b = vR16 + pb * 32 * 4;
+            // (LDS operations of one wave execute in order: the block's reads below see these writes)
+            int m, counter;
             asm volatile(MM_SCREEN_MX_ASM
-                         : "=v"(rowmax)
-                         : "v"(vB), "v"(vA), "v"(vA16), "v"(vRW), "v"(vRR), "v"(vCMb), "v"(vPERM), "v"(vR16b), "s"(variant)
+                         : "=&v"(m), "=&s"(counter)
+                         : "v"(vB), "v"(vA), "v"(vRW), "v"(vRR), "v"(vPERM)
                          : MM_SCREEN_MX_CLOBBERS);
-
-            __syncthreads();  // S2: all column minima and the row minima of tile 16 are in LDS
-            // fold: every thread its rows' maximum and its share of the column minima; one DPP reduction per wave; the
-            // last wave to arrive writes the candidate's value -- no third barrier, the others go on to the next candidate
-            int m = rowmax;
-            for (int j = tid; j < nb; j += 256) {
-                const int v = s_colmin[pb * MX_N + j];
-                m = v > m ? v : m;
-            }
-            if (tid < 32) { const int v = s_row16[pb * 32 + tid]; m = v > m ? v : m; }
             m = wave_max_i32_dpp(m);
-            if (lane == 0) {
-                atomicMax(&s_red[pb], m);
-                __threadfence_block();
-                if (atomicAdd(&s_cnt[pb], 1) == 3) {
-                    __threadfence_block();
-                    out_sq[pd.out_off + a] = __int_as_float(atomicMax(&s_red[pb], 0)) * inv_s2;
-                }
-            }
+            if (lane == 0) out_sq[pd.out_off + a] = __int_as_float(m) * inv_s2;
         }
     }
 }
 
 size_t lds_bytes_mx()
 {
-    return (size_t)MX_T * 64 * 16 + (size_t)MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + (size_t)2 * MX_N * 4 + 2 * 32 * 4 + 16 + 64;
+    return (size_t)MX_T * 64 * 16 + (size_t)4 * MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + 64;
 }
 
 hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s)
