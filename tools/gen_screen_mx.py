@@ -41,6 +41,9 @@ import os
 INF = "0x7f800000"
 P, Q, R, S, X = 100, 116, 132, 148, [164, 180]
 ROWMAX, CM, ASET, T, ACC, AADDR, BSET = 36, 40, [60, 64], 68, 72, 73, [80, 88]
+if os.environ.get("MX_COMPACT") == "1":      # experiment: everything below v168
+    P, Q, R, S, X = 72, 88, 104, 120, [136, 152]
+    ROWMAX, CM, ASET, T, ACC, AADDR, BSET = 24, 25, [48, 52], 42, 46, 47, [56, 64]
 NCT = 17
 NRT = 17
 RED_STRIDE = 136          # bytes between rows of the reduction scratch (34 dwords: 8-byte aligned reads, 2-way conflicts)
@@ -328,9 +331,10 @@ s.ins(f"v_max_i32 %0, v{c[0]}, v{ROWMAX}", reads=[c[0], ROWMAX])
 s.wait()                                       # (the unused B and A requests of the last steps)
 
 out = s.out
-regs = sorted(set(range(36, 37)) | set(range(40, 57)) | set(range(60, 74)) | set(range(80, 96)) | set(range(100, 196)))
+regs = sorted({ROWMAX} | set(range(CM, CM + NCT)) | set(range(ASET[0], ASET[0] + 8)) | set(range(T, T + 4)) | {ACC, AADDR}
+              | set(range(BSET[0], BSET[0] + 16)) | set(range(P, P + 64)) | set(range(X[0], X[0] + 32)))
 here = os.path.dirname(os.path.abspath(__file__))
-dst = os.path.join(here, "..", "multimoda-rs_amd", "csrc", "mm_screen_mx_asm.inc")
+dst = os.environ.get("MX_OUT") or os.path.join(here, "..", "multimoda-rs_amd", "csrc", "mm_screen_mx_asm.inc")
 with open(dst, "w") as f:
     f.write("// GENERATED by tools/gen_screen_mx.py -- do not edit.  Main phase of k_screen_mx: see the generator's docstring.\n")
     f.write(f"// {len(out)} instructions\n")
