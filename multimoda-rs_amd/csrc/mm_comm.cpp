@@ -42,7 +42,9 @@ static const RcclApi& rccl()
     std::call_once(g_rccl_once, [] {
         RcclApi& a = g_rccl;
         const char* env = std::getenv("MM_RCCL_LIB");
-        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // a library named by MM_RCCL_LIB is the only one tried: an override that silently fell back would hide a typo
+        const bool named = env && *env;
+        const char* names[] = {named ? env : "librccl.so.1", named ? nullptr : "librccl.so", named ? nullptr : "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (!n || !*n) continue;
             a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

@@ -81,11 +81,26 @@ def native_comm(group=None) -> "N.Comm":
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", torch.cuda.current_device())
     on_dev = dist.get_backend(group) == "nccl"
-    uid = N.Comm.unique_id() if rank == 0 else bytes(N.Comm.ID_BYTES)
-    t = torch.frombuffer(bytearray(uid), dtype=torch.uint8)
+    # Every step up to the collective join is decided by ALL ranks together: a rank that cannot load RCCL, or a rank 0
+    # that cannot make the id, must not leave the others waiting in the broadcast.
+    ok = torch.tensor([1 if N.lib().mm_comm_version() >= 0 else 0], dtype=torch.int32)
+    ok = ok.to(dev) if on_dev else ok
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        raise RuntimeError("RCCL cannot be loaded on at least one rank (mm_comm_version() < 0)")
+    uid, err = bytes(N.Comm.ID_BYTES), 0
+    if rank == 0:
+        try:
+            uid = N.Comm.unique_id()
+        except Exception:
+            err = 1
+    t = torch.frombuffer(bytearray(bytes([err]) + uid), dtype=torch.uint8)
     t = t.to(dev) if on_dev else t.clone()
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    c = N.Comm(bytes(t.cpu().numpy().tobytes()), rank, world, dev.index)
+    raw = bytes(t.cpu().numpy().tobytes())
+    if raw[0]:
+        raise RuntimeError("rank 0 could not make the communicator id (mm_comm_unique_id)")
+    c = N.Comm(raw[1:], rank, world, dev.index)
     _native_comms[key] = c
     return c
 

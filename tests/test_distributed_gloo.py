@@ -24,6 +24,24 @@ def test_candidate_axis_sharding_gloo(world):
     assert "GLOO_SHARD_OK" in r.stdout
 
 
+def test_native_comm_setup_is_decided_by_all_ranks():
+    """A rank that cannot load RCCL sends EVERY rank to the error, before anybody waits in a collective of the setup
+    (bench.py then falls back to torch's all-reduces on all ranks together)."""
+    import __graft_entry__ as ge
+    ge.build()
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["OMP_NUM_THREADS"] = "1"
+    env.pop("MM_RCCL_LIB", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29800 + (os.getpid() % 150)),
+           os.path.join(ROOT, "tests", "_gloo_comm_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0: COMM_SETUP_REFUSED RCCL cannot be loaded on at least one rank" in r.stdout, r.stdout[-2000:]
+    assert "rank 1: COMM_SETUP_REFUSED RCCL cannot be loaded on at least one rank" in r.stdout, r.stdout[-2000:]
+
+
 def test_merge_shards_single_rank_is_identity(mm):
     from multimoda_rs_amd import distributed as D
     cost = np.array([[0.5, np.inf, 0.1]])
