@@ -326,9 +326,11 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // Matrix-pipe screen: every non-trivial pair's sets within the kernel's fixed 17 x 17 tiling, a scale exponent that
     // puts the larger radius into [256, 512) (f16 pieces, their doubles and |x|^2 / 256 stay in range), and the wider
     // error bound of its squared values: e2 = 128 u (rho_a + rho_b)^2 -- f16 hi + lo split of both points (<= 2^-22 rho
-    // per coordinate, 2^-13 absolute if a lo piece were flushed), the norms' f32 rounding and split, twelve fp32
-    // accumulations of unknown rounding mode (2 u each at the magnitude of (rho_a + rho_b)^2).  Anything else: the
-    // packed-FMA screen.
+    // per coordinate, 2^-13 absolute if a lo piece were flushed: 11 u), the norms' f32 rounding and split (6 u), the
+    // target norm taken from the UNROTATED point (the f32 rotation keeps |b|^2 to 9 u rho_b^2, the split of the rotated
+    // point moves it by another 11 u: 27 u with the norm's own rounding and split), twelve fp32 accumulations of unknown
+    // rounding mode (2 u each at the magnitude of (rho_a + rho_b)^2: 24 u) -- 70 u in all.  Anything else: the packed-FMA
+    // screen.
     use_mx = false;
     if (precision == MM_PRECISION_F32_MATRIX && use_fast && A > 0) {
         use_mx = true;

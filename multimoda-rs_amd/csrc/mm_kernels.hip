@@ -532,9 +532,10 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 //     d^2 = |a|^2 + |b|^2 - 2 a.b   as ONE v_mfma_f32_32x32x16_f16 per 32 x 32 tile (1024 distances),
 // every coordinate split into f16 hi + lo pieces (22 significant bits), fp32 accumulation.  K slots of a
 // fragment (lane l: row or column l & 31, slots 8 * (l >> 5) .. + 7):
-//     rows    A:  [-2x1, -2x1, -2y1, -2y1, -2x2, -2x2, -2y2, -2y2 | n2h, n2l, 256, 1,   0, 0,   0,   0]
-//     columns B:  [  x1,   x2,   y1,   y2,   x1,   x2,   y1,   y2 | 256,   1, n2h, n2l, 256, 1, n2h, n2l]
-// (a column fragment's slots 4..7 repeat its slots 0..3, so it is stored as 8 bytes and read twice)
+//     rows    A:  [-2x1, -2y1, -2x1, -2y1, -2x2, -2y2, -2x2, -2y2 | n2h, n2l, 256, 1,   0, 0,   0,   0]
+//     columns B:  [  x1,   y1,   x2,   y2,   x1,   y1,   x2,   y2 | 256,   1, n2h, n2l, 256, 1, n2h, n2l]
+// (a column fragment's slots 4..7 repeat its slots 0..3, so it is stored as 8 bytes and read twice; its coordinate half
+// is the packed hi pieces followed by the packed lo pieces of (x, y): two conversions, no shuffle)
 // with x = S * (coordinate), S = 2^e chosen per pair so that the larger set radius lands in [256, 512) (all pieces,
 // their doubles and n2 / 256 stay inside f16's range), n2 = |x~|^2 of the split point, n2 = 256 * n2h + n2l.
 // The vector pipe is left with the minima: per tile 8 v_min3_i32 fold its 16 values into the column minimum and
@@ -579,9 +580,9 @@ static __device__ __forceinline__ h8v mx_fragment(float X, float Y, int hi)
     if (hi == 0) {
         if (ROWS) {
             const _Float16 m = (_Float16)-2.0f;
-            f = h8v{m * x1, m * x1, m * y1, m * y1, m * x2, m * x2, m * y2, m * y2};
+            f = h8v{m * x1, m * y1, m * x1, m * y1, m * x2, m * y2, m * x2, m * y2};
         } else {
-            f = h8v{x1, x2, y1, y2, x1, x2, y1, y2};
+            f = h8v{x1, y1, x2, y2, x1, y1, x2, y2};
         }
     } else {
         const float xs = (float)x1 + (float)x2, ys = (float)y1 + (float)y2;          // the split point, exact in f32
@@ -598,18 +599,31 @@ static __device__ __forceinline__ h8v mx_fragment(float X, float Y, int hi)
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
 
-// both (8-byte) fragments of one column -- the coordinate half and the norm half -- from the rotated, scaled point
-static __device__ __forceinline__ void mx_col_fragments(float X, float Y, h4v& f0, h4v& f1)
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// coordinate half (8 bytes) of one column's fragment from the rotated, scaled point: (x1, y1, x2, y2) -- the hi pieces of
+// both coordinates in one packed conversion, their residuals in another.  X, Y and the hi pieces are opaque to the
+// optimiser for the reason given at mx_split.
+static __device__ __forceinline__ h4v mx_col_coords(float X, float Y)
 {
-    _Float16 x1, x2, y1, y2;
-    mx_split(X, x1, x2);
-    mx_split(Y, y1, y2);
-    f0 = h4v{x1, x2, y1, y2};
-    const float xs = (float)x1 + (float)x2, ys = (float)y1 + (float)y2;
-    const float n2 = __builtin_fmaf(xs, xs, ys * ys);
+    asm volatile("" : "+v"(X), "+v"(Y));
+    h2v h = __builtin_convertvector(f2v{X, Y}, h2v);
+    unsigned hb = __builtin_bit_cast(unsigned, h);
+    asm volatile("" : "+v"(hb));
+    h = __builtin_bit_cast(h2v, hb);
+    const h2v l = __builtin_convertvector(f2v{X - (float)h.x, Y - (float)h.y}, h2v);
+    return h4v{h.x, h.y, l.x, l.y};
+}
+
+// norm half (8 bytes) of a column's fragment: (256, 1, n2h, n2l), n2 = |point|^2 of the scaled, UNROTATED point -- a
+// rotation keeps it (to the few units of rounding that PairDesc::e2 budgets for), so it is built once per work item
+static __device__ __forceinline__ h4v mx_col_norm(float X, float Y)
+{
+    const float n2 = __builtin_fmaf(X, X, Y * Y);
     const _Float16 nh = (_Float16)(n2 * 0.00390625f);
     const _Float16 nl = (_Float16)__builtin_fmaf(-256.0f, (float)nh, n2);
-    f1 = h4v{(_Float16)256.0f, (_Float16)1.0f, nh, nl};
+    return h4v{(_Float16)256.0f, (_Float16)1.0f, nh, nl};
 }
 
 template <int CTRL>
@@ -675,6 +689,8 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
             const int j = lane + 64 * q;
             const int jc = j < nb ? j : nb - 1;          // padding columns duplicate the last point (see k_screen_fast)
             tx[q] = S * ptx[pd.tgt_off + jc]; ty[q] = S * pty[pd.tgt_off + jc];
+            // the norm half of the column's fragment does not depend on the candidate: written here, read by all of them
+            if (j < MX_N) s_b[(j >> 5) * 64 + (j & 31) + 32] = mx_col_norm(tx[q], ty[q]);
         }
         __syncthreads();
 
@@ -687,11 +703,7 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
                 if (j < MX_N) {
                     const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
                     const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
-                    h4v f0, f1;
-                    mx_col_fragments(bx, by, f0, f1);
-                    const int slot = (j >> 5) * 64 + (j & 31);
-                    s_b[slot] = f0;
-                    s_b[slot + 32] = f1;
+                    s_b[(j >> 5) * 64 + (j & 31)] = mx_col_coords(bx, by);
                 }
             }
             // (LDS operations of one wave execute in order: the block's reads below see these writes)
