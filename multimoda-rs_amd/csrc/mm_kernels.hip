@@ -537,7 +537,8 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 // (a column fragment's slots 4..7 repeat its slots 0..3, so it is stored as 8 bytes and read twice; its coordinate half
 // is the packed hi pieces followed by the packed lo pieces of (x, y): two conversions, no shuffle)
 // with x = S * (coordinate), S = 2^e chosen per pair so that the larger set radius lands in [256, 512) (all pieces,
-// their doubles and n2 / 256 stay inside f16's range), n2 = |x~|^2 of the split point, n2 = 256 * n2h + n2l.
+// their doubles and n2 / 256 stay inside f16's range), n2 = 256 * n2h + n2l the squared norm -- rows: of the split
+// point; columns: of the scaled point before the rotation (once per work item).
 // The vector pipe is left with the minima: per tile 8 v_min3_i32 fold its 16 values into the column minimum and
 // 8 more take the elementwise row minima of two tiles at once.  tools/ubench_mfma16c.hip: hand-ordered, the MFMA
 // runs entirely beside the 16 minima (34 ns per tile per SIMD against 82 for the packed-FMA form); the compiler's
