@@ -233,12 +233,12 @@ def committed_pmc(workload, precision):
             out["valu_instr_per_tile"] = vec / mf
             out["vector_issue_busy"] = (4.0 * vec + 8.0 * mf) / 1024.0 / cycles
             out["matrix_pipe_busy"] = 32.0 * mf / 1024.0 / cycles
-            if dur.get("GRBM_GUI_ACTIVE"):
-                # wall time per issue slot per SIMD; a stream of nothing but v_min3_i32 on every SIMD of the chip runs at
-                # 2.20 ns (3 waves per SIMD) / 2.38 ns (2 waves) per instruction: profiles/r3_ubench_mfma16c.txt
-                out["issue_slot_ns"] = dur["GRBM_GUI_ACTIVE"] / ((vec + 2.0 * mf) / 1024.0)
-                out["issue_slot_ns_min3_stream"] = {"waves_per_simd_2": 38.11 / 16.0, "waves_per_simd_3": 35.21 / 16.0,
-                                                    "source": "profiles/r3_ubench_mfma16c.txt"}
+            # issue slots of the launch per SIMD (an instruction count: the same in every run); bench.py divides the launch
+            # time it measures live by it.  A stream of nothing but v_min3_i32 on every SIMD of the chip runs at 2.20 ns
+            # (3 waves per SIMD) / 2.38 ns (2 waves) per instruction: profiles/r3_ubench_mfma16c.txt
+            out["issue_slots_per_simd"] = (vec + 2.0 * mf) / 1024.0
+            out["issue_slot_ns_min3_stream"] = {"waves_per_simd_2": 38.11 / 16.0, "waves_per_simd_3": 35.21 / 16.0,
+                                                "source": "profiles/r3_ubench_mfma16c.txt"}
     return out
 
 
@@ -908,7 +908,8 @@ def main():
                 "valu_instr_per_tile": (pmc or {}).get("valu_instr_per_tile"),
                 "vector_issue_busy": (pmc or {}).get("vector_issue_busy"),
                 "matrix_pipe_busy": (pmc or {}).get("matrix_pipe_busy"),
-                "issue_slot_ns": (pmc or {}).get("issue_slot_ns"),
+                "issue_slot_ns": (dominant_launch(launch_ms, launch_pe, peak)["avg_ms"] * 1e6 / pmc["issue_slots_per_simd"]
+                                  if pmc and pmc.get("issue_slots_per_simd") and len(launch_ms) else None),
                 "issue_slot_ns_min3_stream": (pmc or {}).get("issue_slot_ns_min3_stream"),
                 # the MFMAs this kernel executes (289 tiles of 32 x 32 x 16 per candidate, K and the edges padded), live
                 "matrix_pipe": ({"achieved": prof["candidates"] * 289 * 32768.0 / kern_s * 1e-12, "peak": 2500.0, "unit": "TFLOP/s (f16 dense)",
@@ -928,7 +929,7 @@ def main():
                          "SURVEY 8(d)'s algorithmic FLOP against the fp32 VECTOR peak and exceeds 1 because the distance arithmetic no "
                          "longer runs there; what bounds the kernel is vector issue: valu_instr_per_tile = vector instructions other "
                          "than the MFMA per tile, against the floor of 16; an MFMA takes two issue slots; issue_slot_ns = the big "
-                         "launch's wall time per issue slot per SIMD, against issue_slot_ns_min3_stream, what a stream of nothing "
+                         "launch's wall time (measured here) per issue slot per SIMD, against issue_slot_ns_min3_stream, what a stream of nothing "
                          "but v_min3_i32 on every SIMD of the chip achieves (tools/ubench_mfma16c.hip) -- the kernel issues at the "
                          "rate the chip sustains for its instruction; vector_issue_busy = (4 clk x vector instructions + 8 clk x "
                          "MFMAs) / cycles per SIMD with the cycles of GRBM_GUI_ACTIVE; matrix_pipe_busy = 32 clk x MFMAs / cycles.  " if args.precision == "matrix" else "") +
