@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -48,7 +49,12 @@ public:
 private:
     WorkerPool()
     {
-        const unsigned hw = std::thread::hardware_concurrency();
+        unsigned hw = std::thread::hardware_concurrency();
+        // one process per GPU (torchrun exports LOCAL_WORLD_SIZE): the ranks of a node share its cores
+        if (const char* lws = std::getenv("LOCAL_WORLD_SIZE")) {
+            const int k = std::atoi(lws);
+            if (k > 1 && hw) hw = std::max(2u, hw / (unsigned)k);
+        }
         const int nw = (int)std::max(1u, std::min(16u, hw ? hw : 1u)) - 1;   // a GPU box's CPU share is 16 cores
         for (int i = 0; i < nw; ++i) threads_.emplace_back([this] { loop(); });
     }
