@@ -18,6 +18,7 @@
 #include "../../include/mm_build.h"
 #include "mm_engine.h"
 #include "mm_pool.h"
+#include "mm_trace.h"
 #include "mm_sort.h"
 
 namespace mm {
@@ -646,6 +647,7 @@ extern "C" {
 
 int mm_frames_from_flat(const mm_flat_geometry* in, mm_frames** out)
 {
+    TraceTimer tt_api("frames: from_flat");
     if (!in || !out) return set_error(MM_ERR_INVALID, "mm_frames_from_flat: NULL");
     *out = nullptr;
     const mm_geometry& g = in->g;
@@ -737,6 +739,7 @@ int mm_frames_dims(const mm_frames* h, int32_t* n_frames, int64_t* n_lumen, int6
 
 int mm_frames_export(const mm_frames* h, mm_flat_geometry* out)
 {
+    TraceTimer tt_api("frames: export");
     const Frames* F = reinterpret_cast<const Frames*>(h);
     if (!F || !out) return set_error(MM_ERR_INVALID, "mm_frames_export: NULL");
     int32_t nf; int64_t nl, nc, ne, nw;
@@ -802,6 +805,7 @@ void mm_frames_destroy(mm_frames* h) { delete reinterpret_cast<Frames*>(h); }
 // puts the reference point to the right, aortic flags, wall contours, smoothing
 int mm_frames_finish_within(mm_frames* h, int64_t ref_idx, int smooth, int* anomalous_out)
 {
+    TraceTimer tt_api("frames: finish_within");
     Frames* F = reinterpret_cast<Frames*>(h);
     if (!F) return set_error(MM_ERR_INVALID, "mm_frames_finish_within: NULL");
     std::vector<FFrame>& fr = F->f;
@@ -824,6 +828,7 @@ int mm_frames_finish_within(mm_frames* h, int64_t ref_idx, int smooth, int* anom
 
 int mm_frames_postprocess_pair(mm_frames* a, mm_frames* b, double tolerance, int anomalous)
 {
+    TraceTimer tt_api("frames: postprocess_pair");
     Frames *A = reinterpret_cast<Frames*>(a), *B = reinterpret_cast<Frames*>(b);
     if (!A || !B) return set_error(MM_ERR_INVALID, "mm_frames_postprocess_pair: NULL");
     return postprocess_pair(A->f, B->f, tolerance, anomalous != 0);
