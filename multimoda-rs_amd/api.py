@@ -489,6 +489,27 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
     return (*out, tuple(logs))
 
 
+def retain_heap(mmap_threshold: int = 32 << 20, trim_threshold: int = 1 << 30, top_pad: int = 64 << 20) -> bool:
+    """Opt-in allocator policy for processes that call the entry points repeatedly (glibc only; returns False elsewhere).
+
+    One `from_array_full` on 4 x 512 frames returns ~100 MB of arrays and builds ~50 MB of intermediates.  With glibc's
+    defaults every array above 128 KB is its own mmap: freeing the previous call's results unmaps them (3-5 ms on the
+    config3 shape) and the next call page-faults the same memory in again.  This sets M_MMAP_THRESHOLD (blocks up to
+    32 MB come from the heap), M_TRIM_THRESHOLD and M_TOP_PAD (the heap is not handed back between calls), process-wide:
+    the memory of freed results stays with the process.  Nothing in the library depends on it."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        mallopt = libc.mallopt
+    except (OSError, AttributeError):
+        return False
+    M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD = -1, -2, -3
+    ok = mallopt(M_MMAP_THRESHOLD, int(mmap_threshold)) == 1
+    ok = (mallopt(M_TRIM_THRESHOLD, int(trim_threshold)) == 1) and ok
+    ok = (mallopt(M_TOP_PAD, int(top_pad)) == 1) and ok
+    return bool(ok)
+
+
 _POOL = None
 
 

@@ -39,7 +39,10 @@ def main():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--stages", action="store_true", help="per-stage wall times of one call (MM_API_TRACE)")
+    ap.add_argument("--retain-heap", action="store_true", help="call mm.retain_heap() first (see its docstring)")
     a = ap.parse_args()
+    if a.retain_heap:
+        print("retain_heap:", mm.retain_heap(), file=sys.stderr)
     base = mm.synthetic_case(a.frames, 501)
     data = [input_data(g, lab, dia) for g, lab, dia in zip(base, ("rest", "rest", "stress", "stress"), (True, False, True, False))]
     eng = mm.Engine()
