@@ -470,10 +470,29 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
     # interpreter lock: AB and CD are post-processed on pool threads WHILE the second batch of between alignments runs
     # (a and b are final after the first batch; c and d move again, so pair CD works on snapshots taken -- in parallel
     # -- before the second batch starts).
-    snap_c, snap_d = pool.map(lambda g: g.copy(), (c, d))
     pair_ab = _make_pair(keep(a), keep(b))
-    pair_cd = _make_pair(snap_c, snap_d)
-    early = [pool.submit(post, pr) for pr in (pair_ab, pair_cd)] if postprocessing else None
+    if share:
+        # the native post-processing starts by copying the pair into the library's frame lists: done HERE for C and D, that
+        # copy is the snapshot of their state before the second batch moves them again
+        from . import native_frames as NF
+
+        def post_staged(staged, label):
+            try:
+                return GeometryPair(*NF.postprocess_staged(*staged, TOLERANCE, anomalous), label)
+            except RuntimeError as e:
+                raise RuntimeError(f"Failed postprocessing of {label}: {e}") from e
+
+        import copy
+        views = [copy.copy(g) for g in (c, d)]          # shallow: the arrays are shared, attribute updates are not
+        for v, g in zip(views, (c, d)):
+            v.meta = dict(g.meta)
+        view_cd = _make_pair(*views)
+        staged_cd = NF.stage_pair(view_cd.geom_a, view_cd.geom_b)
+        early = [pool.submit(post, pair_ab), pool.submit(post_staged, staged_cd, view_cd.label)]
+    else:
+        snap_c, snap_d = pool.map(lambda g: g.copy(), (c, d))
+        pair_cd = _make_pair(snap_c, snap_d)
+        early = [pool.submit(post, pr) for pr in (pair_ab, pair_cd)] if postprocessing else None
     _mark("snapshot of C, D; post-processing of AB, CD started")
     G.align_between(eng, [(a, c), (b, d)], rng, step, sample_size)                 # entry.rs:243-277
     _mark("between AC | BD")

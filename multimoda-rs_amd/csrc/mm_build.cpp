@@ -106,31 +106,39 @@ void set_frame_z(BFrame& f, double z)   // every z of the frame: points, extras,
 // HashMap<u32, Vec<ContourPoint>> of build_contour_with_mapping (contour.rs:164-167): rows of one frame in input order
 void group_rows(const double* rows4, int64_t n, const uint8_t* flags, std::map<uint32_t, BContour>& out)
 {
-    // rows of a frame are usually adjacent: one map lookup per run of equal frame indices (map nodes do not move);
-    // a counting pass first, so that every contour is allocated once
-    BContour* cur = nullptr;
-    uint32_t last = 0;
+    // rows of a frame are usually adjacent: one pass finds the runs of equal frame indices and counts every frame's rows
+    // (one map lookup per run; map nodes do not move), every contour is sized once, and the runs are copied over the
+    // worker pool -- each to the offset the runs of its frame before it have left, so a frame's rows keep their input order
+    struct Run { BContour* c; int64_t at, start, len; };
+    std::vector<Run> runs;
     {
         std::map<uint32_t, int64_t> count;
         int64_t* cc = nullptr;
+        uint32_t last = 0;
         for (int64_t i = 0; i < n; ++i) {
             const uint32_t f = (uint32_t)rows4[4 * i];
-            if (!cc || f != last) { cc = &count[f]; last = f; }
-            ++*cc;
+            if (!cc || f != last) {
+                cc = &count[f]; last = f;
+                runs.push_back(Run{&out[f], *cc, i, 0});
+            }
+            ++*cc; ++runs.back().len;
         }
         for (const auto& kv : count) {
             BContour& c = out[kv.first];
-            c.xyz.reserve((size_t)kv.second * 3);
-            if (flags) c.aortic.reserve((size_t)kv.second);
+            c.xyz.resize((size_t)kv.second * 3);
+            if (flags) c.aortic.resize((size_t)kv.second);
         }
     }
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t f = (uint32_t)rows4[4 * i];
-        if (!cur || f != last) { cur = &out[f]; last = f; }
-        BContour& c = *cur;
-        c.xyz.insert(c.xyz.end(), rows4 + 4 * i + 1, rows4 + 4 * i + 4);
-        if (flags) c.aortic.push_back(flags[i]);
-    }
+    const int nr = (int)runs.size();
+    parallel_for((nr + 15) / 16, [&](int blk) {
+        for (int r = blk * 16; r < std::min(nr, blk * 16 + 16); ++r) {
+            const Run& u = runs[(size_t)r];
+            double* d = u.c->xyz.data() + 3 * u.at;
+            const double* src = rows4 + 4 * u.start;
+            for (int64_t k = 0; k < u.len; ++k) { d[3 * k] = src[4 * k + 1]; d[3 * k + 1] = src[4 * k + 2]; d[3 * k + 2] = src[4 * k + 3]; }
+            if (flags) std::memcpy(u.c->aortic.data() + u.at, flags + u.start, (size_t)u.len);
+        }
+    });
 }
 
 }  // namespace

@@ -436,8 +436,7 @@ int smooth_frames(std::vector<FFrame>& fr)
             const int64_t m = cur.lumen.n();
             auto smooth = [&](const FContour& c, const FContour& p, const FContour& q, FContour& o) {
                 if (c.n() < m || p.n() < m || q.n() < m) return false;   // the reference indexes 0..point_count
-                o = c;
-                o.truncate(m);
+                o.truncate(m);                                           // (o is f's copy of c already: f = cur below)
                 for (int64_t j = 0; j < m; ++j) {
                     o.p[3 * j] = (p.p[3 * j] + c.p[3 * j] + q.p[3 * j]) / 3.0;
                     o.p[3 * j + 1] = (p.p[3 * j + 1] + c.p[3 * j + 1] + q.p[3 * j + 1]) / 3.0;
@@ -810,18 +809,18 @@ int mm_frames_finish_within(mm_frames* h, int64_t ref_idx, int smooth, int* anom
     if (!F) return set_error(MM_ERR_INVALID, "mm_frames_finish_within: NULL");
     std::vector<FFrame>& fr = F->f;
     int rc;
-    if ((rc = fill_holes(fr))) return rc;                                         // :136
+    { TraceTimer t("finish: fill_holes"); if ((rc = fill_holes(fr))) return rc; }  // :136
     if (ref_idx < 0 || ref_idx >= (int64_t)fr.size()) return set_error(MM_ERR_REF_INDEX, "reference frame index out of range");
     const FFrame& rf = fr[(size_t)ref_idx];
     if (rf.lumen.n() <= 2) return set_error(MM_ERR_INVALID, "Need at least 3 points");
     const bool anomalous = elliptic_ratio(rf.lumen) > 2.0 || rf.lumen.has_a || rf.lumen.has_p;   // :249-254
     double rot;
-    if ((rc = angle_ref_point_to_right(rf, anomalous, rot))) return rc;           // :139
-    rotate_geometry(fr, rot);                                                     // :141 (contour centroids stay as they are)
+    { TraceTimer t("finish: ref point angle"); if ((rc = angle_ref_point_to_right(rf, anomalous, rot))) return rc; }   // :139
+    { TraceTimer t("finish: rotate"); rotate_geometry(fr, rot); }                 // :141 (contour centroids stay as they are)
     if (anomalous)                                                                // :143-147 assign_aortic
         for (FFrame& f : fr) { const int64_t n = f.lumen.n(), half = n / 2; for (int64_t i = 0; i < n; ++i) f.lumen.aortic[(size_t)i] = i >= half; }
-    if ((rc = create_walls(fr, anomalous))) return rc;                            // :149-153
-    if (smooth && (rc = smooth_frames(fr))) return rc;                            // :155-157
+    { TraceTimer t("finish: walls"); if ((rc = create_walls(fr, anomalous))) return rc; }      // :149-153
+    { TraceTimer t("finish: smooth"); if (smooth && (rc = smooth_frames(fr))) return rc; }     // :155-157
     if (anomalous_out) *anomalous_out = anomalous ? 1 : 0;
     return MM_OK;
 }

@@ -70,12 +70,12 @@ class NativeFrames:
         N.check(L.mm_frames_dims(self._h, C.byref(F), C.byref(nl), C.byref(nc), C.byref(ne), C.byref(nw)), "mm_frames_dims")
         F, nl, nc, ne, nw = F.value, nl.value, nc.value, ne.value, nw.value
         g = FlatGeometry(ids=np.zeros(F, np.uint32), lumen_ids=np.zeros(F, np.uint32), orig_frames=np.zeros(F, np.uint32),
-                         centroids=np.zeros((F, 3)), lumen_off=np.zeros(F + 1, np.int64), lumen=np.zeros((nl, 3)),
+                         centroids=np.zeros((F, 3)), lumen_off=np.zeros(F + 1, np.int64), lumen=np.empty((nl, 3)),
                          has_ref=np.zeros(F, np.uint8), ref=np.zeros((F, 3)), label=self.label)
         if nc:
-            g.cath_off, g.cath = np.zeros(F + 1, np.int64), np.zeros((nc, 3))
+            g.cath_off, g.cath = np.zeros(F + 1, np.int64), np.empty((nc, 3))    # (the point arrays are written in full)
         if ne:
-            g.extra_off, g.extra = np.zeros(F + 1, np.int64), np.zeros((ne, 3))
+            g.extra_off, g.extra = np.zeros(F + 1, np.int64), np.empty((ne, 3))
         ec = np.zeros((F, 4), dtype=np.int64)
         has_lc, lc = np.zeros(F, np.uint8), np.zeros((F, 3))
         a_th, p_th, has_a, has_p = np.zeros(F), np.zeros(F), np.zeros(F, np.uint8), np.zeros(F, np.uint8)
@@ -130,11 +130,26 @@ def finish_within(g: FlatGeometry, ref_idx: int, smooth: bool) -> Tuple[FlatGeom
         nf.close()
 
 
-def postprocess_pair(a: FlatGeometry, b: FlatGeometry, tol: float, anomalous: bool) -> Tuple[FlatGeometry, FlatGeometry]:
-    """postprocess_geom_pair (postprocessing.rs:12-87) on two FlatGeometry objects."""
-    fa, fb = NativeFrames(a), NativeFrames(b)
+def stage_pair(a: FlatGeometry, b: FlatGeometry) -> Tuple[NativeFrames, NativeFrames]:
+    """The library's own copies of two geometries (mm_frames_from_flat): from here on the FlatGeometry objects may change
+    without the pair noticing -- a snapshot that costs nothing extra, because the post-processing starts with this copy."""
+    fa = NativeFrames(a)
+    try:
+        return fa, NativeFrames(b)
+    except BaseException:
+        fa.close()
+        raise
+
+
+def postprocess_staged(fa: NativeFrames, fb: NativeFrames, tol: float, anomalous: bool) -> Tuple[FlatGeometry, FlatGeometry]:
+    """postprocess_geom_pair (postprocessing.rs:12-87) on a staged pair; closes the handles."""
     try:
         fa.postprocess_pair(fb, tol, anomalous)
         return fa.to_flat(), fb.to_flat()
     finally:
         fa.close(); fb.close()
+
+
+def postprocess_pair(a: FlatGeometry, b: FlatGeometry, tol: float, anomalous: bool) -> Tuple[FlatGeometry, FlatGeometry]:
+    """postprocess_geom_pair (postprocessing.rs:12-87) on two FlatGeometry objects."""
+    return postprocess_staged(*stage_pair(a, b), tol, anomalous)
