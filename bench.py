@@ -47,6 +47,9 @@ WORKLOADS = {
     "config3ext": dict(frames=512, points=501, step_deg=0.5, range_deg=180.0, sample_size=501, shift=(-50, 49)),
 }
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (vector)
+# What bounds every screen of this path is vector ISSUE: a SIMD takes one vector wave-instruction per 4 clocks (an MFMA holds
+# the issue port for 8: two slots).  256 CUs x 4 SIMDs x 2.4 GHz / 4 clk = 614.4 G issue slots per second.
+VALU_ISSUE_PEAK_GSLOTS = 256 * 4 * 2.4 / 4.0
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md, HBM3E peak
 FLOPS_PER_PAIR_EVAL = 6.0         # 2 sub, 2 mul, 1 add, 1 min
 BYTES_PER_POSE_EVAL = lambda na, nb: (na + nb) * 2 * 4 + 8   # SURVEY 8(d) no-reuse model
@@ -192,6 +195,29 @@ def run_steps(ks, search, finish, pipelined, stage=None, lookahead=2, begin=None
     return [out[k] for k in ks]
 
 
+# candidates of the big launch of the committed --pmc passes (config3: 4 pullbacks x 511 frame pairs x 721 rotations)
+PMC_CANDIDATES = {"config3": 4 * 511 * 721}
+
+
+def issue_roofline(pmc, ms, pair_evals, na, nb):
+    """The roofline of the dominant kernel on the scale that binds it: vector issue slots per second.
+    achieved = issue slots of one big launch -- an INSTRUCTION COUNT from the committed rocprofv3 --pmc pass
+    (SQ_INSTS_VALU + SQ_INSTS_MFMA: every vector instruction one slot, an MFMA two), scaled by the candidates of the live
+    launch where the workload differs from the profiled one (same kernel, same set size: same slots per candidate) --
+    divided by the big launch's mean duration measured live (hipEvents on the kernel's stream);
+    peak = 1024 SIMDs x 2.4 GHz / 4 clk.  None where no --pmc pass of the kernel is committed."""
+    if not pmc or not pmc.get("issue_slots_per_launch") or not pmc.get("candidates_per_launch") or len(ms) == 0:
+        return None
+    big = pair_evals >= 0.5 * pair_evals.max()
+    t_ms = float(ms[big].mean())
+    cand = float(pair_evals[big].mean()) / (2.0 * na * nb)
+    slots = pmc["issue_slots_per_launch"] * cand / pmc["candidates_per_launch"]
+    ach = slots / (t_ms * 1e-3) * 1e-9
+    return {"achieved": ach, "frac": ach / VALU_ISSUE_PEAK_GSLOTS, "issue_slots_per_launch": slots,
+            "issue_slots_per_candidate": pmc["issue_slots_per_launch"] / pmc["candidates_per_launch"],
+            "candidates_per_launch": cand, "launch_ms": t_ms}
+
+
 def committed_pmc(workload, precision):
     """Figures of the dominant kernel's big launch from the committed rocprofv3 --pmc passes (profiles/, tools/gpu_pmc.sh;
     bench.py cannot run the profiler itself): HBM bytes per launch (FETCH_SIZE + WRITE_SIZE in KiB, raw -- on gfx950
@@ -200,6 +226,13 @@ def committed_pmc(workload, precision):
     names = {("config3", "fast"): ["r3_config3_fast_pmc_summary.csv", "r2_config3_fast_pmc_summary.csv"],
              ("config3", "matrix"): ["r3_config3_matrix_pmc_summary.csv"],
              ("config3", "f32"): ["r1_config3_pmc_summary.csv"]}.get((workload, precision), [])
+    if not names and workload != "config3":
+        # same kernel, same set size (N = 521), other frame / candidate counts: the per-candidate figures carry over
+        out = committed_pmc("config3", precision)
+        if out:
+            out["source"] += " (config3's launch; per-candidate figures)"
+            out.pop("traffic", None)
+        return out
     path = next((os.path.join(ROOT, "profiles", n) for n in names if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if not path:
         return None
@@ -239,6 +272,10 @@ def committed_pmc(workload, precision):
             out["issue_slots_per_simd"] = (vec + 2.0 * mf) / 1024.0
             out["issue_slot_ns_min3_stream"] = {"waves_per_simd_2": 38.11 / 16.0, "waves_per_simd_3": 35.21 / 16.0,
                                                 "source": "profiles/r3_ubench_mfma16c.txt"}
+        # issue slots of the launch (an instruction count, the same in every run): SQ_INSTS_VALU counts every vector
+        # instruction including the MFMAs, an MFMA takes a second slot
+        out["issue_slots_per_launch"] = val["SQ_INSTS_VALU"] + val.get("SQ_INSTS_MFMA", 0.0)
+        out["candidates_per_launch"] = PMC_CANDIDATES.get(workload)
     return out
 
 
@@ -655,10 +692,13 @@ def main():
                 srs.close()
                 if name == "bruteforce":
                     tf = pr["pair_evals"] * FLOPS_PER_PAIR_EVAL / (pr["ms"] * 1e-3) * 1e-12 if pr["ms"] > 0 else 0.0
+                    eiss = issue_roofline(committed_pmc("config3", args.precision), lms, lpe, ecfg["sample_size"] + 20, ecfg["sample_size"] + 20)
                     out.update({"value": srs.pose_evals / dt_, "unit": "pose-evals/s", "ms_per_step": dt_ * 1e3, "steps": 1,
                                 "pose_evals_per_step": srs.pose_evals, "pairs": int(srs.meta.shape[0]), "candidates_per_pair": len(srs.angles),
-                                "roofline": {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                             "frac": tf / FP32_VECTOR_PEAK_TFLOPS,
+                                "roofline": {"bound": "valu-issue", "unit": "G issue-slots/s", "peak": VALU_ISSUE_PEAK_GSLOTS,
+                                             **{k_: (eiss or {}).get(k_) for k_ in ("achieved", "frac", "issue_slots_per_launch")},
+                                             "algorithmic_tflops_vs_fp32_vector": {"achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                                                                                   "ratio": tf / FP32_VECTOR_PEAK_TFLOPS},
                                              "kernel": "mm::k_screen_mx" if args.precision == "matrix" else "mm::k_screen_fast<33, false>",
                                              "launches": pr["launches"],
                                              "avg_launch_ms": pr["ms"] / max(pr["launches"], 1)}})
@@ -777,6 +817,9 @@ def main():
                 extra["fast_screen"] = {"value": leg["evals"] / leg["dt"], "unit": "pose-evals/s", "ms_per_step": leg["dt"] / args.steps * 1e3,
                                         "steps": args.steps, "identical_to_headline_result": same_result(leg),
                                         "kernel": "mm::k_screen_fast<33, false>", "dominant_launch": dominant_launch(lms, lpe),
+                                        # the same scale as the headline's `roofline`: issue slots per second against 614.4 G
+                                        "issue": issue_roofline(committed_pmc(args.workload, "fast"), lms, lpe,
+                                                                cfg["sample_size"] + 20, cfg["sample_size"] + 20),
                                         "note": "expanded-form f32 screen on the vector pipe alone: 2.5 instructions per distance, "
                                                 "issue-saturated (4.02 clk per wave-instruction, profiles/r3_config3_fast_pmc_summary.csv)"}
             except Exception as ex:
@@ -841,6 +884,7 @@ def main():
         algo_gbs = prof["candidates"] * BYTES_PER_POSE_EVAL(na, nb) / kern_s * 1e-9 if kern_s > 0 else 0.0
         f64_main = args.precision == "f64"
         pmc = committed_pmc(args.workload, args.precision)
+        iss = issue_roofline(pmc, launch_ms, launch_pe, na, nb)
         peak = FP64_VECTOR_PEAK_TFLOPS if f64_main else FP32_VECTOR_PEAK_TFLOPS
         # executed VALU lane-operations per squared distance the reference counts twice (2 x 6 = 12 algorithmic FLOP):
         # fast screen 4 packed-FMA lanes (8 FLOP) + 1 add + 2 min -> 7 issue slots; direct form 8; f64 kernel 7
@@ -897,8 +941,16 @@ def main():
                                             "(mm_engine_wait_search), so the device does not idle across the hand-over" if world == 1 else "")
                                          ) if pipelined else "sequential"},
             "roofline": {
-                "bound": "valu", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved_tflops / peak,
+                # the scale that binds the kernel: vector issue slots (one per vector instruction, two per MFMA) per second
+                # against 1024 SIMDs x 2.4 GHz / 4 clk; slots = committed instruction count, time = measured live
+                "bound": "valu-issue", "achieved": (iss or {}).get("achieved"), "peak": VALU_ISSUE_PEAK_GSLOTS,
+                "unit": "G issue-slots/s", "frac": (iss or {}).get("frac"),
+                "issue": iss,
+                # SURVEY 8(d)'s ALGORITHMIC count (6 FLOP for each of the reference's 2 Na Nb pair-distances) against the fp32
+                # (fp64 for --precision f64) VECTOR peak: not a fraction of a pipe for the matrix-pipe screen -- its distance
+                # arithmetic does not run there and every distance is computed once, not twice -- kept as the survey defines it
+                "algorithmic_tflops_vs_fp32_vector": {"achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
+                                                      "ratio": achieved_tflops / peak},
                 "executed_op_frac": (achieved_tflops / peak) * exec_per_12 / 12.0 if exec_per_12 else None,
                 "traffic": (pmc or {}).get("traffic"),
                 # what saturates (committed --pmc passes of the same launch): a SIMD issues one VALU wave-instruction
@@ -916,33 +968,36 @@ def main():
                                  "frac": prof["candidates"] * 289 * 32768.0 / kern_s * 1e-12 / 2500.0}
                                 if args.precision == "matrix" and kern_s > 0 else None),
                 "achieved_clock_ghz": (pmc or {}).get("achieved_clock_ghz"),
-                "frac_at_achieved_clock": ((achieved_tflops / peak) * 2.4 / pmc["achieved_clock_ghz"]
-                                           if pmc and pmc.get("achieved_clock_ghz") else None),
+                # frac with the peak at the clock the --pmc pass ran at instead of 2.4 GHz (that pass's own duration)
+                "frac_at_achieved_clock": (iss["frac"] * 2.4 / pmc["achieved_clock_ghz"]
+                                           if iss and pmc.get("achieved_clock_ghz") else None),
                 "pmc_source": (pmc or {}).get("source"),
                 "kernel": {"matrix": "mm::k_screen_mx", "f32": "mm::k_search<float,33,16,false,false>", "fast": "mm::k_screen_fast<33, false>",
                            "bounded": "mm::k_screen_lb<5, false>",
                            "f64": "mm::k_search<double,11,16,true,true,3>"}[args.precision], "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "dominant_launch": dominant_launch(launch_ms, launch_pe, peak),
-                "note": ("MATRIX-PIPE SCREEN: d^2 = |a|^2 + |b|^2 - 2 a.b as one v_mfma_f32_32x32x16_f16 per 32 x 32 tile (f16 hi + lo "
-                         "pieces, fp32 accumulate), the vector pipe keeps the minima (16 v_min3_i32 per tile at best).  `frac` is "
-                         "SURVEY 8(d)'s algorithmic FLOP against the fp32 VECTOR peak and exceeds 1 because the distance arithmetic no "
-                         "longer runs there; what bounds the kernel is vector issue: valu_instr_per_tile = vector instructions other "
-                         "than the MFMA per tile, against the floor of 16; an MFMA takes two issue slots; issue_slot_ns = the big "
-                         "launch's wall time (measured here) per issue slot per SIMD, against issue_slot_ns_min3_stream, what a stream of nothing "
-                         "but v_min3_i32 on every SIMD of the chip achieves (tools/ubench_mfma16c.hip) -- the kernel issues at the "
-                         "rate the chip sustains for its instruction; vector_issue_busy = (4 clk x vector instructions + 8 clk x "
-                         "MFMAs) / cycles per SIMD with the cycles of GRBM_GUI_ACTIVE; matrix_pipe_busy = 32 clk x MFMAs / cycles.  " if args.precision == "matrix" else "") +
-                        "point-set min/max metric: bounded by VALU issue (SURVEY 8(d)), not HBM/MFMA; achieved = ALGORITHMIC "
-                        "rate: pose-evals x 2*Na*Nb pair-distances x 6 FLOP / kernel time (hipEvents around every launch on "
-                        "the kernel's stream); executed_op_frac = the same launches priced by the lane-operations the kernel "
-                        "executes (each squared distance is computed once and serves both directed terms: 7 issue slots "
-                        "against 12 algorithmic FLOP); traffic = HBM bytes per launch of the big launch (FETCH_SIZE+WRITE_SIZE, "
-                        "committed rocprofv3 --pmc passes in profiles/); valu_clk_per_instr = (GRBM_GUI_ACTIVE / 8 XCDs) / "
-                        "(SQ_INSTS_VALU / 1024 SIMDs) of that launch: 4.0 is back-to-back VALU issue, the kernel's real ceiling; "
-                        "achieved_clock_ghz = those cycles / the launch's duration in the same pass; frac_at_achieved_clock = frac "
-                        "re-priced with the peak at that clock instead of 2.4 GHz (> 1 is possible: 12 algorithmic FLOP per 7 "
-                        "executed lane-operations)",
+                "note": ("bound = valu-issue: a point-set min/max metric is bounded by vector ISSUE (SURVEY 8(d): 'VALU instr per pair-eval vs "
+                         "16 384 lanes x clock'), not by HBM and not by the matrix pipe.  achieved = issue slots of the big launch / its "
+                         "duration measured in this run (hipEvents around every launch on the kernel's stream); the slots are an "
+                         "instruction count taken from the committed rocprofv3 --pmc pass named in pmc_source (SQ_INSTS_VALU + "
+                         "SQ_INSTS_MFMA: a vector instruction holds a SIMD's issue port for 4 clocks, an MFMA for 8); peak = 1024 SIMDs "
+                         "x 2.4 GHz / 4 clk = 614.4 G slots/s.  frac therefore folds in both the slots the kernel spends above its "
+                         "floor and the clock the box actually runs (2.0 - 2.2 GHz under this load, achieved_clock_ghz).  " +
+                         ("MATRIX-PIPE SCREEN: d^2 = |a|^2 + |b|^2 - 2 a.b as one v_mfma_f32_32x32x16_f16 per 32 x 32 tile (f16 hi + lo "
+                          "pieces, fp32 accumulate), the vector pipe keeps the minima (16 v_min3_i32 per tile at best): "
+                          "valu_instr_per_tile = vector instructions other than the MFMA per tile against that floor; issue_slot_ns = "
+                          "the big launch's time per issue slot per SIMD against issue_slot_ns_min3_stream, what a stream of nothing but "
+                          "v_min3_i32 on every SIMD of the chip sustains (tools/ubench_mfma16c.hip); vector_issue_busy = (4 clk x vector "
+                          "instructions + 8 clk x MFMAs) / GRBM_GUI_ACTIVE cycles per SIMD (the same fraction at the clock of the --pmc "
+                          "pass); matrix_pipe_busy = 32 clk x MFMAs / cycles; matrix_pipe = executed f16 MFMA FLOP against the 2.5 PF "
+                          "dense peak.  " if args.precision == "matrix" else "") +
+                         "algorithmic_tflops_vs_fp32_vector = SURVEY 8(d)'s count, pose-evals x 2 Na Nb pair-distances x 6 FLOP / kernel "
+                         "time, against the fp32 vector peak (a ratio, not a fraction of a pipe: above 1 for the matrix-pipe screen); "
+                         "executed_op_frac = the same launches priced by the lane-operations the packed-FMA kernels execute (7 per 12 "
+                         "algorithmic FLOP); traffic = HBM bytes of the big launch (FETCH_SIZE + WRITE_SIZE, same --pmc passes); "
+                         "valu_clk_per_instr = (GRBM_GUI_ACTIVE / 8 XCDs) / (SQ_INSTS_VALU / 1024 SIMDs): 4.0 is back-to-back issue; "
+                         "achieved_clock_ghz = those cycles / the launch's duration in that pass"),
                 "hbm": {"bound": "hbm", "achieved": algo_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_gbs / HBM_PEAK_GBS,
                         "note": "algorithmic no-reuse bytes ((Na+Nb)*8+8 per pose-eval) / kernel time"},

@@ -33,9 +33,15 @@ def test_bench_contract_on_a_small_workload():
     assert d["config"]["pose_evals_per_step"] > 4 * 127 * 361         # within stage + the between stage's coarse->fine evaluations
     assert d["config"]["staged_cases_in_timed_region"] == 3          # K stagings inside the timed region
     r = d["roofline"]
-    assert r["unit"] == "TFLOP/s" and 0 < r["frac"] < 2.5 and r["kernel"] == "mm::k_screen_mx"      # (matrix-pipe screen: > 1 is possible)
+    # the roofline is a fraction of the pipe that binds the kernel: vector issue slots per second against 1024 SIMDs x 2.4 GHz / 4
+    assert r["bound"] == "valu-issue" and r["unit"] == "G issue-slots/s" and abs(r["peak"] - 614.4) < 1e-9
+    assert 0 < r["frac"] <= 1.0 and r["kernel"] == "mm::k_screen_mx"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["issue"]["issue_slots_per_launch"] / (r["issue"]["launch_ms"] * 1e-3) * 1e-9) < 1e-6 * r["achieved"]
+    assert r["algorithmic_tflops_vs_fp32_vector"]["ratio"] > 0       # SURVEY 8(d)'s count: a ratio (> 1 possible), not `frac`
     fs = d["fast_screen"]                                           # the packed-FMA screen on the same steps
     assert fs["identical_to_headline_result"] is True and 0 < fs["dominant_launch"]["frac"] <= 1.0
+    assert 0 < fs["issue"]["frac"] <= 1.0
     assert r["dominant_launch"]["launches"] == 3
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["bounded_search"]["identical_to_bruteforce_result"] is True
