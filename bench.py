@@ -363,6 +363,8 @@ class Runner:
                                       self.bruteforce, cfg["sample_size"], precision=self.prec,
                                       shard=(self.rank, *self.grid) if self.world > 1 else
                                       ((0, *self.grid) if self.rehearse > 1 else None))
+        if self.rehearse > 1 and self.comm is not None:
+            self.plans[k].set_timing_rehearsal(True)     # a world = 1 communicator serves rank 0 of a larger job: timing only
         self.stage_s += time.perf_counter() - t0
         self.staged += 1
 
@@ -517,7 +519,6 @@ def main():
         if world != 1:
             raise SystemExit("MM_BENCH_REHEARSE_WORLD is a single-process rehearsal")
         if os.environ.get("MM_EXCHANGE", "rccl") == "rccl":
-            os.environ["MM_SHARD_REHEARSAL"] = "1"      # the library lets a world = 1 communicator serve a rank of a larger job
             rehearse_comm = mm.Comm(mm.Comm.unique_id(), 0, 1, local_rank)   # the library's own communicator
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -742,7 +743,9 @@ def main():
             logs_, ev_, un_ = pl.walk()
             pl.close()
             return [list(l) for l in logs_], ev_, un_
-        chosen = os.environ.get("MM_EXCHANGE", "") or D.exchange_mode()
+        # the library's default is torch's all-reduces (`device`); this run opts into the library's own RCCL communicator on an
+        # nccl group BECAUSE it cross-checks the three exchanges right here, before anything is timed
+        chosen = os.environ.get("MM_EXCHANGE", "") or ("rccl" if backend == "nccl" else "device")
         modes = ["gather", "device"] + (["rccl"] if chosen == "rccl" else [])
         got = {}
         for m in modes:

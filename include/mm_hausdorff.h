@@ -372,6 +372,11 @@ int  mm_within_plan_create_grid(mm_engine* e, int n_geoms, mm_geometry** geoms,
                                 double step_deg, double range_deg, int bruteforce, int64_t sample_size,
                                 int precision, int rank, int pair_blocks, int cand_slices, mm_within_plan** out);
 int  mm_within_plan_set_shard_grid(mm_within_plan* p, int rank, int pair_blocks, int cand_slices);
+/* TIMING ONLY (bench.py's single-process rehearsal of a rank of a larger job): with `on` != 0 the sharded entry points accept
+ * a world = 1 communicator for a plan whose (rank, world) is a tile of a larger grid.  The reduced records then hold this
+ * tile alone -- the result is NOT an alignment, and mm_within_plan_walk / _run_sharded report n_unresolved = -1 to say so.
+ * Off by default; there is no environment variable behind it. */
+int  mm_within_plan_set_timing_rehearsal(mm_within_plan* p, int on);
 
 /* The communicator: RCCL (librccl.so.1, loaded at run time; MM_RCCL_LIB overrides the path; a process that already
  * holds a copy -- torch ships one -- shares it).  One process per GPU:

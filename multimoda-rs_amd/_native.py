@@ -42,7 +42,7 @@ EXPORTS = [
     "mm_shard_grid", "mm_within_plan_create_grid", "mm_within_plan_set_shard_grid", "mm_comm_unique_id", "mm_comm_init_rank",
     "mm_comm_destroy", "mm_comm_rank", "mm_comm_world", "mm_comm_version", "mm_comm_all_reduce_min_f64",
     "mm_comm_all_reduce_min_i64", "mm_within_plan_search_sharded", "mm_within_plan_run_sharded",
-    "mm_within_plan_search_sharded_begin", "mm_engine_wait_exchange",
+    "mm_within_plan_search_sharded_begin", "mm_engine_wait_exchange", "mm_within_plan_set_timing_rehearsal",
 ]
 # include/mm_centerline.h
 EXPORTS_CENTERLINE = [
@@ -263,6 +263,8 @@ def lib():
     L.mm_within_plan_create_grid.argtypes = [P, I, P, D, D, I, I64, I, I, I, I, C.POINTER(P)]
     L.mm_within_plan_set_shard_grid.restype = I
     L.mm_within_plan_set_shard_grid.argtypes = [P, I, I, I]
+    L.mm_within_plan_set_timing_rehearsal.restype = I
+    L.mm_within_plan_set_timing_rehearsal.argtypes = [P, I]
     L.mm_comm_unique_id.restype = I
     L.mm_comm_unique_id.argtypes = [P]
     L.mm_comm_init_rank.restype = I

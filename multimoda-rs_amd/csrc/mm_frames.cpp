@@ -590,26 +590,42 @@ int postprocess_pair(std::vector<FFrame>& A, std::vector<FFrame>& B, double tol,
     for (size_t i = 0; i < B.size(); ++i) orig_zb[i] = B[i].c[2];
     std::vector<FFrame> ra, rb;
     // (A and B are replaced at the end and nothing below reads them again -- the original z values are saved above --
-    // so a geometry that is only re-spaced is MOVED into its result: no deep copy of 512 frames x 3 contours)
+    // so a geometry that is only re-spaced is MOVED into its result: no deep copy of 512 frames x 3 contours.)
+    // Every fallible step comes BEFORE the first move, so that an error leaves the caller's handles as they were: the
+    // interpolated geometry is built from a const source, and the reference index of a geometry that is only re-spaced is
+    // read off the source in the order resample_by_diff will leave it in (rotated to start at the first minimum of z).
+    bool move_a = true, move_b = true;
+    double diff_a = 0.0, diff_b = 0.0;
     if (same) {
-        const double mean = (da + db) / 2.0;
-        ra = std::move(A); rb = std::move(B);
-        resample_by_diff(ra, mean); resample_by_diff(rb, mean);
+        diff_a = diff_b = (da + db) / 2.0;
     } else if (da < db) {
         double lo, hi;
         span(B, lo, hi);
         if ((rc = new_frames_by_sample_rate(B, predict_z_positions(ref_z_b, lo, hi, da), rb))) return rc;
-        ra = std::move(A); resample_by_diff(ra, da);
+        move_b = false; diff_a = da;
     } else {
         double lo, hi;
         span(A, lo, hi);
         if ((rc = new_frames_by_sample_rate(A, predict_z_positions(ref_z_a, lo, hi, db), ra))) return rc;
-        rb = std::move(B); resample_by_diff(rb, db);
+        move_a = false; diff_b = db;
     }
+    auto ref_idx_as_resampled = [](const std::vector<FFrame>& fr, int64_t& idx) -> int {
+        size_t k = 0;
+        for (size_t i = 1; i < fr.size(); ++i) if (fr[i].c[2] < fr[k].c[2]) k = i;
+        for (size_t q = 0; q < fr.size(); ++q) {
+            const FFrame& f = fr[(k + q) % fr.size()];
+            if (f.has_ref) { idx = (int64_t)f.id; return MM_OK; }
+        }
+        return set_error(MM_ERR_INVALID, "No reference point found in any frame");
+    };
     // :70-76 -- the reference indexes the ORIGINAL pair with the resampled geometries' reference indices
     int64_t ja, jb;
-    if ((rc = find_ref_frame_idx(ra, ja)) || (rc = find_ref_frame_idx(rb, jb))) return rc;
+    if ((rc = move_a ? ref_idx_as_resampled(A, ja) : find_ref_frame_idx(ra, ja)) ||
+        (rc = move_b ? ref_idx_as_resampled(B, jb) : find_ref_frame_idx(rb, jb)))
+        return rc;
     if (ja >= (int64_t)orig_za.size() || jb >= (int64_t)orig_zb.size()) return set_error(MM_ERR_REF_INDEX, "index out of bounds");
+    if (move_a) { ra = std::move(A); resample_by_diff(ra, diff_a); }
+    if (move_b) { rb = std::move(B); resample_by_diff(rb, diff_b); }
     const double translation = orig_za[(size_t)ja] - orig_zb[(size_t)jb];
     {
         const int n = (int)ra.size();
@@ -631,7 +647,12 @@ int postprocess_pair(std::vector<FFrame>& A, std::vector<FFrame>& B, double tol,
                 la.has_a = lb.has_a = true; la.a_th = lb.a_th = th;
             }
         }
-        if ((rc = create_walls(ra, true)) || (rc = create_walls(rb, true))) return rc;
+        if ((rc = create_walls(ra, true)) || (rc = create_walls(rb, true))) {
+            // the one failure after the moves (a degenerate contour in the wall synthesis): hand the frames back rather than
+            // leave the caller's handles empty -- they hold the re-spaced, trimmed pair without its new walls
+            A.swap(ra); B.swap(rb);
+            return rc;
+        }
     }
     A.swap(ra); B.swap(rb);
     return MM_OK;

@@ -321,6 +321,7 @@ struct WithinPlan {
     int level_commit_records(size_t l);
     int exchange_enqueue(Comm* c, size_t l);
     bool xchg_pending = false;        // search_sharded_begin has enqueued level 0's exchange
+    bool rehearsal = false;           // mm_within_plan_set_timing_rehearsal: timing only, the result is not an alignment
     void build_level_pairs(size_t l, const std::vector<double>& centres, const std::vector<uint8_t>& take,
                            std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out);
     int search();
@@ -743,9 +744,9 @@ int comm_world(const Comm* c);
 
 int WithinPlan::exchange_enqueue(Comm* c, size_t l)
 {
-    // MM_SHARD_REHEARSAL=1 (timing only, bench.py's MM_BENCH_REHEARSE_WORLD): one process plays a rank of a larger job on
-    // a world = 1 communicator -- the reduced records then hold this rank's tile alone, the result is not an alignment
-    static const bool rehearsal = std::getenv("MM_SHARD_REHEARSAL") != nullptr;
+    // mm_within_plan_set_timing_rehearsal (timing only, bench.py's MM_BENCH_REHEARSE_WORLD): one process plays a rank of a
+    // larger job on a world = 1 communicator -- the reduced records then hold this rank's tile alone, the result is not an
+    // alignment and walk() says so (n_unresolved = -1)
     if ((comm_world(c) != world || comm_rank(c) != rank) && !(rehearsal && comm_world(c) == 1))
         return set_error(MM_ERR_INVALID, "search_sharded: the plan's (rank, world) is not the communicator's");
     const int J = (int)job_geom.size();
@@ -1400,7 +1401,9 @@ int mm_within_plan_run_sharded(mm_within_plan* h, mm_comm* ch, mm_alignlog** log
     if (n_unresolved) *n_unresolved = 0;
     if (int drc = select_device(wp->e)) return drc;
     if (int rc = wp->search_sharded(reinterpret_cast<Comm*>(ch))) return rc;
-    return wp->walk(logs, pose_evals, n_unresolved);
+    const int rc = wp->walk(logs, pose_evals, n_unresolved);
+    if (wp->rehearsal && n_unresolved) *n_unresolved = -1;
+    return rc;
 }
 
 int mm_within_plan_walk(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
@@ -1410,7 +1413,17 @@ int mm_within_plan_walk(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_eva
     if (pose_evals) *pose_evals = 0;
     if (n_unresolved) *n_unresolved = 0;
     if (int drc = select_device(wp->e)) return drc;   // unresolved steps search on the chain state
-    return wp->walk(logs, pose_evals, n_unresolved);
+    const int rc = wp->walk(logs, pose_evals, n_unresolved);
+    if (wp->rehearsal && n_unresolved) *n_unresolved = -1;    // not an alignment: the records held one tile of a larger job
+    return rc;
+}
+
+int mm_within_plan_set_timing_rehearsal(mm_within_plan* h, int on)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
+    wp->rehearsal = on != 0;
+    return MM_OK;
 }
 
 // Merge per-shard results of `world` ranks (arrays are [world][n], rank-major).  For job j

@@ -43,13 +43,14 @@ def shard_bounds(n: int, rank: int, world: int):
 
 
 def exchange_mode(group=None) -> str:
-    """MM_EXCHANGE = rccl | device | gather; default: rccl on an nccl process group, device otherwise (the library's
-    communicator needs one GPU per rank, which a gloo rehearsal of several ranks on one GPU does not have)."""
-    m = os.environ.get("MM_EXCHANGE", "")
-    if m == "":
-        import torch.distributed as dist
-        nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
-        m = "rccl" if nccl else "device"
+    """MM_EXCHANGE = rccl | device | gather; default: ``device`` (torch's all-reduces on the device records).
+
+    ``rccl`` -- the library's own communicator, ``mm_within_plan_search_sharded`` -- is OPT-IN: it has run at world = 1, in
+    lock-step in-process emulation and over gloo, never at world > 1 on hardware, so its parity there is UNPINNED
+    (ADVICE r3).  ``bench.py`` opts in on an nccl group after running one case through all three exchanges and comparing
+    them.  With ``rccl`` a non-OK return of ``search_sharded*`` on ANY rank means the job must be torn down: the peers of a
+    rank that failed between the two collectives are blocked inside RCCL."""
+    m = os.environ.get("MM_EXCHANGE", "") or "device"
     if m not in ("rccl", "device", "gather"):
         raise ValueError("MM_EXCHANGE must be 'rccl', 'device' or 'gather'")
     return m

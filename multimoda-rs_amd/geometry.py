@@ -290,6 +290,11 @@ class WithinPlan:
                 "mm_within_plan_set_shard_grid")
         self.shard = (int(rank), int(pair_blocks), int(cand_slices))
 
+    def set_timing_rehearsal(self, on: bool = True):
+        """TIMING ONLY (``mm_within_plan_set_timing_rehearsal``): let a world = 1 communicator serve this plan's tile of a
+        larger grid; the result is then not an alignment and ``walk`` reports ``n_unresolved == -1``."""
+        N.check(N.lib().mm_within_plan_set_timing_rehearsal(self._h, int(bool(on))), "mm_within_plan_set_timing_rehearsal")
+
     def search_sharded_begin(self, comm: "N.Comm"):
         """Level 0 of the sharded search enqueued up to the copy of the reduced records, nothing waited for
         (``mm_within_plan_search_sharded_begin``); ``search_sharded`` collects."""

@@ -154,3 +154,42 @@ def test_native_errors_carry_the_reference_messages(built, mm):
         NF.finish_within(g, 0, True)
     with pytest.raises(RuntimeError, match="No reference point found in any frame"):
         NF.postprocess_pair(g, g, 0.03, False)
+
+
+def test_failed_postprocess_pair_leaves_both_handles_as_they_were(built, mm):
+    """every fallible step of mm_frames_postprocess_pair comes before the first move.  A is four times sparser
+    than B and carries its reference point on the last frame: re-sampled to B's spacing that frame's index lies beyond A's
+    original length -> the reference's `index out of bounds` (postprocessing.rs:70-76), which used to arrive AFTER B had
+    been moved out of its handle.  A C / Rust host that inspects or retries must still find 8 and 40 frames."""
+    from multimoda_rs_amd import native_frames as NF
+    from multimoda_rs_amd.centerline import with_lumen_centroids
+
+    def geom(n, dz, ref_at):
+        g = mm.synthetic_pullback(n, 64)
+        g.meta["extra_counts"] = {k: np.zeros(n, dtype=np.int64) for k in ("eem", "calcification", "sidebranch", "wall")}
+        g.meta["aortic_thickness"] = [None] * n
+        g.meta["pulmonary_thickness"] = [None] * n
+        z = np.arange(n) * dz
+        g.centroids[:, 2] = z
+        for i in range(n):
+            g.lumen[g.lumen_off[i]:g.lumen_off[i + 1], 2] = z[i]
+            if g.cath_off is not None:
+                g.cath[g.cath_off[i]:g.cath_off[i + 1], 2] = z[i]
+        g.has_ref[:] = 0
+        g.has_ref[ref_at] = 1
+        g.ref[ref_at] = (g.centroids[ref_at, 0] + 1.0, g.centroids[ref_at, 1], z[ref_at])
+        with_lumen_centroids(g)
+        return g
+
+    a, b = geom(8, 1.0, 7), geom(40, 0.25, 3)
+    fa, fb = NF.stage_pair(a, b)
+    try:
+        before = (fa.to_flat(), fb.to_flat())
+        with pytest.raises(RuntimeError, match="index out of bounds"):
+            fa.postprocess_pair(fb, 0.03, False)
+        after = (fa.to_flat(), fb.to_flat())
+        for x, y in zip(before, after):
+            assert x.n_frames == y.n_frames and x.n_frames in (40, 8)
+            assert np.array_equal(x.lumen, y.lumen) and np.array_equal(x.centroids, y.centroids) and np.array_equal(x.ids, y.ids)
+    finally:
+        fa.close(); fb.close()
