@@ -125,6 +125,13 @@ int  mm_engine_profile_launches(mm_engine* e, int64_t cap, float* ms, double* pa
  * out[3] in the third (decisive-point) round, out[4] candidates that went through the full f32
  * screen (the two per-pair picks not counted). */
 int  mm_engine_bound_stats(mm_engine* e, int64_t out[5]);
+/* Which kernel screened how many candidates since the engine was created (brute-force levels; the bounded search's
+ * rounds are in mm_engine_bound_stats): out[0] direct-form f32, out[1] packed-FMA (expanded form), out[2] matrix pipe with
+ * the whole target set per wave (64 .. 544 points), out[3] matrix pipe with the target set in column blocks (545 .. 2048
+ * points), out[4] every candidate in exact f64 (MM_PRECISION_F64, or a level whose coordinates no f32 screen can hold).
+ * MM_PRECISION_F32_MATRIX chooses per PAIR: only pairs with a set of fewer than 64 or more than 2048 points (or a radius
+ * beyond 1e+-30) show up under out[0] / out[1]. */
+int  mm_engine_screen_stats(mm_engine* e, int64_t out[5]);
 /* MM_PRECISION_F32_BOUNDED runs its bound rounds only on batches of at least n candidates (default
  * 16384): a dozen dependent launches cost more than screening a small batch outright. 0 = always. */
 int  mm_engine_set_bound_min_candidates(mm_engine* e, int64_t n);

@@ -28,7 +28,7 @@ MM_SEARCH_SKIP_ZERO = 1
 EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
     "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream", "mm_engine_wait_search",
-    "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches", "mm_engine_bound_stats",
+    "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches", "mm_engine_bound_stats", "mm_engine_screen_stats",
     "mm_engine_set_bound_min_candidates",
     "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
     "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
@@ -203,6 +203,8 @@ def lib():
     L.mm_engine_profile_launches.argtypes = [P, I64, P, P, C.POINTER(I64)]
     L.mm_engine_bound_stats.restype = I
     L.mm_engine_bound_stats.argtypes = [P, P]
+    L.mm_engine_screen_stats.restype = I
+    L.mm_engine_screen_stats.argtypes = [P, P]
     L.mm_parse_contour_table.restype = I64
     L.mm_parse_contour_table.argtypes = [C.c_char_p, I64, C.c_char, P, I64]
     L.mm_engine_set_bound_min_candidates.restype = I
@@ -634,6 +636,13 @@ class Engine:
     def set_bound_min_candidates(self, n: int):
         """MM_PRECISION_F32_BOUNDED uses its bound rounds only on batches of at least n candidates (default 16384)."""
         check(lib().mm_engine_set_bound_min_candidates(self._h, int(n)), "mm_engine_set_bound_min_candidates")
+
+    def screen_stats(self):
+        """Candidates screened since the engine was created, by kernel (``mm_engine_screen_stats``)."""
+        out = np.zeros(5, dtype=np.int64)
+        check(lib().mm_engine_screen_stats(self._h, _ptr(out)), "mm_engine_screen_stats")
+        return {"direct_f32": int(out[0]), "packed_fma": int(out[1]), "matrix": int(out[2]), "matrix_blocks": int(out[3]),
+                "exact_f64": int(out[4])}
 
     def bound_stats(self):
         """MM_PRECISION_F32_BOUNDED since profile(True): candidates offered, lower-bounded in rounds 1-3 and fully

@@ -89,9 +89,12 @@ struct BatchDev {
 // Launchers (mm_kernels.hip).  All asynchronous on `s`.
 hipError_t launch_screen_f32(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
 hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStream_t s);
-// matrix-pipe screen (MM_PRECISION_F32_MATRIX): every pair's sets must have mx_min_points() .. mx_max_points() points and
-// PairDesc::pad0 must hold the pair's scale exponent (k_screen_mx)
-hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s);
+// matrix-pipe screen (MM_PRECISION_F32_MATRIX) over the work items [work_begin, work_begin + n_work) of b.work: every one
+// of their pairs must have sets of mx_min_points() .. mx_max_points() points, a target set whose variant (mx_variant) is
+// (nct, multi), a reference set of at most a_cap row tiles of 32, and PairDesc::pad0 = the pair's scale exponent
+hipError_t launch_screen_mx(const BatchDev& b, int work_begin, int n_work, int nct, int multi, int a_cap, hipStream_t s);
+void       mx_variant(int n_tgt, int* nct, int* multi);
+size_t     lds_bytes_mx(int nct, bool multi, int a_cap);
 int        mx_min_points();
 int        mx_max_points();
 int        max_rows_fast();

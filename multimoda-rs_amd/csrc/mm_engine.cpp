@@ -323,34 +323,39 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     use_fast = expanded && max_na <= max_rows_fast() && max_nbp <= max_target_points_fast();
     if (expanded && !use_fast)
         for (PairDesc& d : host_pairs) d.e2 = 0.0;
-    // Matrix-pipe screen: every non-trivial pair's sets within the kernel's fixed 17 x 17 tiling, a scale exponent that
-    // puts the larger radius into [256, 512) (f16 pieces, their doubles and |x|^2 / 256 stay in range), and the wider
-    // error bound of its squared values: e2 = 128 u (rho_a + rho_b)^2 -- f16 hi + lo split of both points (<= 2^-22 rho
-    // per coordinate, 2^-13 absolute if a lo piece were flushed: 11 u), the norms' f32 rounding and split (6 u), the
-    // target norm taken from the UNROTATED point (the f32 rotation keeps |b|^2 to 9 u rho_b^2, the split of the rotated
-    // point moves it by another 11 u: 27 u with the norm's own rounding and split), twelve fp32 accumulations of unknown
-    // rounding mode (2 u each at the magnitude of (rho_a + rho_b)^2: 24 u) -- 70 u in all.  Anything else: the packed-FMA
-    // screen.
+    // Matrix-pipe screen, chosen PER PAIR: sets of mx_min_points() .. mx_max_points() points (the kernel is instantiated
+    // per column-tile count, its row-tile count is a run-time operand, larger target sets are cut into column blocks), a
+    // scale exponent that puts the larger radius into [256, 512) (f16 pieces, their doubles and |x|^2 / 256 stay in range),
+    // and the wider error bound of its squared values: e2 = 128 u (rho_a + rho_b)^2 -- f16 hi + lo split of both points
+    // (<= 2^-22 rho per coordinate, 2^-13 absolute if a lo piece were flushed: 11 u), the norms' f32 rounding and split
+    // (6 u), the target norm taken from the UNROTATED point (the f32 rotation keeps |b|^2 to 9 u rho_b^2, the split of the
+    // rotated point moves it by another 11 u: 27 u with the norm's own rounding and split), twelve fp32 accumulations of
+    // unknown rounding mode (2 u each at the magnitude of (rho_a + rho_b)^2: 24 u) -- 70 u in all.  A pair outside that
+    // range keeps the packed-FMA screen (or, in a batch whose largest sets exceed that kernel's registers, the direct
+    // form) with that kernel's own e2; its work items form a group of their own (Plan::groups).
     use_mx = false;
-    if (precision == MM_PRECISION_F32_MATRIX && use_fast && A > 0) {
-        use_mx = true;
-        for (int p = 0; p < P && use_mx; ++p) {
+    std::vector<int> pair_key((size_t)P, 0);       // 0: direct form, 1: packed FMA, else 2 + (multi << 8 | nct) << 8 | row-tile class
+    if (precision == MM_PRECISION_F32_MATRIX && A > 0) {
+        for (int p = 0; p < P; ++p) {
             PairDesc& d = host_pairs[p];
             if (trivial[p] || d.n_ang == 0) continue;
-            const double rmax = std::max(set_rho[pairs[p].ref_set], set_rho[pairs[p].tgt_set]);
+            pair_key[(size_t)p] = use_fast ? 1 : 0;
+            const double ra = set_rho[pairs[p].ref_set], rb = set_rho[pairs[p].tgt_set], rmax = std::max(ra, rb);
             if (d.n_ref < mx_min_points() || d.n_ref > mx_max_points() || d.n_tgt < mx_min_points() || d.n_tgt > mx_max_points() ||
-                !(rmax > 1.0e-30) || !(rmax < 1.0e30)) { use_mx = false; break; }
+                !(rmax > 1.0e-30) || !(rmax < 1.0e30))
+                continue;
+            int nct = 0, multi = 0, k = 0;
+            mx_variant(d.n_tgt, &nct, &multi);
+            // LDS is sized per launch by the largest reference set of the group: up to 17 row tiles leave room for two
+            // workgroups per CU, more than that for one -- two classes, so that one long contour does not halve the
+            // occupancy of every other pair's launch
+            const int nrt = (d.n_ref + 31) / 32, cls = nrt <= 17 ? 0 : 1;
+            (void)std::frexp(rmax * (1.0 + 1e-6), &k);   // radius < 2^k
+            d.pad0 = 9 - k;
+            d.e2 = 128.0 * 5.9604644775390625e-08 * (ra + rb) * (ra + rb);
+            pair_key[(size_t)p] = 2 + ((((multi << 8) | nct) << 1 | cls) << 2);
+            use_mx = true;
         }
-        if (use_mx)
-            for (int p = 0; p < P; ++p) {
-                PairDesc& d = host_pairs[p];
-                if (trivial[p] || d.n_ang == 0) continue;
-                const double rs = set_rho[pairs[p].ref_set] + set_rho[pairs[p].tgt_set];
-                int k = 0;
-                (void)std::frexp(std::max(set_rho[pairs[p].ref_set], set_rho[pairs[p].tgt_set]) * (1.0 + 1e-6), &k);   // radius < 2^k
-                d.pad0 = 9 - k;
-                d.e2 = 128.0 * 5.9604644775390625e-08 * rs * rs;
-            }
     }
     // the bound rounds pay for themselves on sets of a few dozen points or more and on batches that keep
     // the device busy for several rounds of workgroups (a dozen dependent launches cost more than
@@ -370,28 +375,52 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // 144.6/138.2/122.3 TFLOP/s) -- many short workgroups keep the co-resident ones out of phase
     // (rotation / epilogue of one overlaps the micro-tile loop of the others) and balance the tail
     int apb = (int)std::min<int64_t>(8, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
+    // matrix-pipe screen: one WAVE per candidate, four waves per workgroup -- a workgroup of fewer than four candidates
+    // leaves waves idle for the whole item (small batches: a single search of 361 candidates)
+    if (use_mx) apb = std::max(apb, 4);
+    groups.clear();
     {
         // balanced chunks: ceil(n / apb) workgroups whose sizes differ by at most one (a 90-candidate
         // slice is 12 x 7-8 candidates, not 11 x 8 + 2: the short tail would cost a full staging).
         // 186 k items for config3: sized by a prefix sum and filled over the worker pool (one push_back at a time
-        // this was half of a case's staging time)
+        // this was half of a case's staging time).  With the matrix-pipe screen the pairs are laid out group by group
+        // (stable: pair-major inside a group, as the XCD-aware work order wants it).
+        std::vector<int> order((size_t)P);
+        for (int p = 0; p < P; ++p) order[(size_t)p] = p;
+        if (use_mx) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return pair_key[(size_t)x] < pair_key[(size_t)y]; });
         std::vector<int64_t> wstart((size_t)P + 1, 0);
-        for (int p = 0; p < P; ++p) wstart[(size_t)p + 1] = wstart[(size_t)p] + (host_pairs[p].n_ang + apb - 1) / apb;
+        for (int q = 0; q < P; ++q) wstart[(size_t)q + 1] = wstart[(size_t)q] + (host_pairs[order[(size_t)q]].n_ang + apb - 1) / apb;
         if (wstart[(size_t)P] > INT32_MAX) return set_error(MM_ERR_TOO_LARGE, "too many work items");
         host_work.resize((size_t)wstart[(size_t)P]);
         WorkItem* hw = host_work.data();
         constexpr int kBlk = 64;
         parallel_for((P + kBlk - 1) / kBlk, [&](int blk) {
-            for (int p = blk * kBlk; p < std::min(P, (blk + 1) * kBlk); ++p) {
+            for (int q = blk * kBlk; q < std::min(P, (blk + 1) * kBlk); ++q) {
+                const int p = order[(size_t)q];
                 const PairDesc& d = host_pairs[p];
-                const int nw = (int)(wstart[(size_t)p + 1] - wstart[(size_t)p]);
-                WorkItem* o = hw + wstart[(size_t)p];
+                const int nw = (int)(wstart[(size_t)q + 1] - wstart[(size_t)q]);
+                WorkItem* o = hw + wstart[(size_t)q];
                 for (int k = 0; k < nw; ++k) {
                     const int a0 = (int)((int64_t)d.n_ang * k / nw), a1 = (int)((int64_t)d.n_ang * (k + 1) / nw);
                     o[k] = WorkItem{p, a0, a1 - a0, 0};
                 }
             }
         });
+        if (use_mx)
+            for (int q = 0; q < P;) {
+                const int key = pair_key[(size_t)order[(size_t)q]];
+                int q1 = q, a_cap = 1;
+                while (q1 < P && pair_key[(size_t)order[(size_t)q1]] == key) {
+                    const PairDesc& d = host_pairs[order[(size_t)q1]];
+                    if (d.n_ang > 0 && !trivial[order[(size_t)q1]]) a_cap = std::max(a_cap, (d.n_ref + 31) / 32);
+                    ++q1;
+                }
+                const int wb = (int)wstart[(size_t)q], wc = (int)(wstart[(size_t)q1] - wstart[(size_t)q]);
+                if (wc > 0)
+                    groups.push_back(key < 2 ? ScreenGroup{key, 0, 0, 0, wb, wc}
+                                             : ScreenGroup{2, ((key - 2) >> 3) & 0xff, ((key - 2) >> 11) & 1, a_cap, wb, wc});
+                q = q1;
+            }
     }
     W = (int)host_work.size();
     host_work_lb.clear();
@@ -525,8 +554,25 @@ int Plan::run(bool screen_only)
             if (eng->profile) { eng->bound_offered += A; eng->bound_round1 += lb_sparse_total; }
         } else {
             if ((prc = eng->profile_begin(s))) return prc;
-            e = use_mx ? launch_screen_mx(dev, s)
-                       : (use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s));
+            if (use_mx) {
+                e = hipSuccess;
+                for (const ScreenGroup& g : groups) {
+                    int64_t cand = 0;
+                    for (int k = 0; k < g.work_count; ++k) cand += host_work[(size_t)(g.work_begin + k)].cnt;
+                    eng->screened[g.kind == 2 ? 2 + g.multi : g.kind] += cand;
+                    if (g.kind == 2) {
+                        e = launch_screen_mx(dev, g.work_begin, g.work_count, g.nct, g.multi, g.a_cap, s);
+                    } else {
+                        BatchDev sub = dev;              // the pairs outside the matrix kernel's range: their own work items
+                        sub.work = dev.work + g.work_begin; sub.n_work = g.work_count;
+                        e = g.kind == 1 ? launch_screen_fast(sub, max_na, max_nbp, s) : launch_screen_f32(sub, max_na, max_nbp, s);
+                    }
+                    if (e != hipSuccess) break;
+                }
+            } else {
+                eng->screened[use_fast ? 1 : 0] += A;
+                e = use_fast ? launch_screen_fast(dev, max_na, max_nbp, s) : launch_screen_f32(dev, max_na, max_nbp, s);
+            }
             if (e != hipSuccess) return hip_error(e, "screen kernel launch");
             if ((prc = eng->profile_end(s, pair_evals, A))) return prc;
         }
@@ -541,6 +587,7 @@ int Plan::run(bool screen_only)
         if (e != hipSuccess) return hip_error(e, "finalize kernel launch");
     } else {
         if ((prc = eng->profile_begin(s))) return prc;
+        eng->screened[4] += A;
         e = launch_exact_all(dev, max_na, max_nbp, s);
         if (e != hipSuccess) return hip_error(e, "exact kernel launch");
         if ((prc = eng->profile_end(s, pair_evals, A))) return prc;
@@ -1037,6 +1084,14 @@ int mm_engine_bound_stats(mm_engine* h, int64_t out[5])
     if (e->dev_stats) MM_HIP(hipMemcpy(d, e->dev_stats, 64, hipMemcpyDeviceToHost));
     out[0] = e->bound_offered; out[1] = e->bound_round1; out[2] = (int64_t)d[1]; out[3] = (int64_t)d[3];
     out[4] = (int64_t)d[2];
+    return MM_OK;
+}
+
+int mm_engine_screen_stats(mm_engine* h, int64_t out[5])
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e || !out) return set_error(MM_ERR_INVALID, "engine or out == NULL");
+    for (int k = 0; k < 5; ++k) out[k] = e->screened[k].load();
     return MM_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <string>
 #include <array>
+#include <atomic>
 #include <vector>
 
 #include "../../include/mm_hausdorff.h"
@@ -70,6 +71,10 @@ struct Engine {
     // counts), device accumulators [1] bounded in round 2, [2] fully screened
     int64_t bound_min_candidates = 16384;   // smaller batches skip the bound rounds (mm_engine_set_bound_min_candidates)
     int64_t bound_offered = 0, bound_round1 = 0;
+    // candidates screened since the engine was created, by kernel: [0] direct-form f32, [1] packed FMA, [2] matrix pipe
+    // (whole target set per wave), [3] matrix pipe (target set in column blocks), [4] exact f64 for every candidate
+    // (mm_engine_screen_stats; atomics: levels are staged from several host threads)
+    std::atomic<int64_t> screened[5] = {};
     unsigned long long* dev_stats = nullptr;
     int profile_begin(hipStream_t s);
     int profile_end(hipStream_t s, double pair_evals, int64_t candidates);
@@ -127,6 +132,11 @@ struct Plan {
     bool want_costs = false;
     bool use_fast = false;                    // expanded-form screening kernel selected
     bool use_mx = false;                      // matrix-pipe screening kernel selected (MM_PRECISION_F32_MATRIX)
+    // MM_PRECISION_F32_MATRIX: the work list is grouped by screen variant, one launch per group.  kind 2 = k_screen_mx
+    // <nct, multi> with LDS for a_cap row tiles; kind 1 / 0 = the pairs outside its range (fewer than 64 or more than 2048
+    // points, radii f16 cannot scale): packed-FMA screen / direct-form f32 screen
+    struct ScreenGroup { int kind, nct, multi, a_cap, work_begin, work_count; };
+    std::vector<ScreenGroup> groups;
     bool use_lb = false;                      // lower-bound pass in front of the screen (MM_PRECISION_F32_BOUNDED)
     int W_lb = 0, lb_stride = 0, lb_runs_cap = 0, max_nt = 1;
     double lb_pair_evals = 0.0;               // pair-distances of the first bound round

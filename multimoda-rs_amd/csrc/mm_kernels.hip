@@ -547,14 +547,18 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 // and computes all 17 x 17 tiles of each: column fragments in a wave-private LDS copy, column minima in registers for the
 // whole candidate, row minima across the 32 column lanes through a wave-private LDS transpose -- no barrier and no shared
 // accumulator in the candidate loop.  Error of the screened value: PairDesc::e2 = 128 u (rho_a + rho_b)^2 (mm_engine.cpp).
-// Sets of 449 .. 544 points (15 - 17 tiles a side are computed as 17); anything else takes k_screen_fast.
+// Set sizes: the column-tile count NCT (target set, <= 17 per block) is a template parameter -- the column minima live in
+// one register per column tile -- and the row-tile count (reference set) is a run-time operand of the asm block; a target
+// set of more than 544 points is cut into equal blocks of NCT tiles (MULTI: the row minima are carried from block to block
+// through a wave-private row store in LDS).  Sets of 64 .. 2048 points take this kernel (mx_min_points .. mx_max_points);
+// the engine groups the work items by variant, one launch per group.
 // -------------------------------------------------------------------------------------
 #include "mm_screen_mx_asm.inc"
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
-static constexpr int MX_T = 17;                 // tiles a side
-static constexpr int MX_N = MX_T * 32;          // 544 padded points
+static constexpr int MX_TMAX = MM_SCREEN_MX_NCT_MAX;          // column tiles of one block
+static constexpr int MX_ROW_TILES_MAX = 64;                     // row tiles (LDS: 1 KB of fragments per row tile)
 static constexpr int MX_RED = 32 * (MM_SCREEN_MX_RED_STRIDE / 4);   // ints of one wave's reduction scratch
 
 static __device__ __forceinline__ void mx_split(float X, _Float16& h, _Float16& l)
@@ -643,20 +647,26 @@ static __device__ __forceinline__ int wave_max_i32_dpp(int v)
     return a > c ? a : c;
 }
 
+// NCT: column tiles of one block (the whole target set when !MULTI); a_cap: row tiles the launch's LDS layout provides for
+template <int NCT, bool MULTI>
 __global__ void __launch_bounds__(256, 2)
-k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
+k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work, int a_cap,
             const float* __restrict__ ptx, const float* __restrict__ pty,
             const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
 {
+    constexpr int NB = NCT * 32;                                      // padded columns of one block
+    constexpr int NQ = (NCT + 1) / 2;                                 // columns per lane
     extern __shared__ __align__(16) unsigned char smem[];
-    h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [17][64] row fragments of the pair (all waves)
-    h4v* s_bw = reinterpret_cast<h4v*>(s_a + MX_T * 64);             // [4][17][64] column fragments, 8 bytes each: a wave's
+    h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [a_cap][64] row fragments of the pair (all waves)
+    h4v* s_bw = reinterpret_cast<h4v*>(s_a + a_cap * 64);            // [4][NCT][64] column fragments, 8 bytes each: a wave's
                                                                       //            own copy, for the candidate it is on
-    int* s_redx = reinterpret_cast<int*>(s_bw + 4 * MX_T * 64);      // [4][MX_RED] row-reduction scratch, one per wave
-    float* s_cs = reinterpret_cast<float*>(s_redx + 4 * MX_RED);     // [8][2] cos, sin of the work item's candidates
+    int* s_redx = reinterpret_cast<int*>(s_bw + 4 * NCT * 64);       // [4][MX_RED] row-reduction scratch, one per wave
+    int* s_rsx = s_redx + 4 * MX_RED;                                 // MULTI: [4][a_cap * 32] row store, one per wave
+    float* s_cs = reinterpret_cast<float*>(s_rsx + (MULTI ? 4 * a_cap * 32 : 0));   // [8][2] cos, sin of the work item's candidates
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
-    h4v* s_b = s_bw + wave * MX_T * 64;
+    h4v* s_b = s_bw + wave * NCT * 64;
+    int* s_rs = s_rsx + wave * a_cap * 32;
     // LDS byte addresses of this lane's slots (generator docstring); a generic pointer's low 32 bits are its LDS offset
     const unsigned lds0 = (unsigned)(size_t)smem;
     const unsigned vB = lds0 + (unsigned)((size_t)s_b - (size_t)smem) + lane * 8;
@@ -666,75 +676,130 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
     const int rh = (l32 >> 2) & 1, rv = (l32 & 3) + 4 * (l32 >> 3);        // row l32 of a tile lives at (half rh, element rv)
     const unsigned vRR = red_w + (rh * 16 + rv) * MM_SCREEN_MX_RED_STRIDE + hi * 64;
     const unsigned vPERM = (unsigned)((lane ^ 32) * 4);
+    const unsigned vRS = lds0 + (unsigned)((size_t)s_rs - (size_t)smem) + l32 * 4;   // MULTI: both halves hold the same value
 
     for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
          wi += gridDim.x) {
         const WorkItem w = work[wi];
         const PairDesc pd = pairs[w.pair];
         const int na = pd.n_ref, nb = pd.n_tgt;
+        const int nrt = (na + 31) >> 5;                                 // row tiles (<= a_cap: the engine sized the launch)
+        const int nloop = (nrt - 1) >> 1, tail = (nrt - 1) & 1;         // the asm block: row tile 0, nloop x 2, (tail)
         const float S = __builtin_ldexpf(1.0f, pd.pad0), inv_s2 = __builtin_ldexpf(1.0f, -2 * pd.pad0);
 
         __syncthreads();
         // the candidates' cos / sin once per work item (a global load at the top of every candidate would be exposed)
         if (tid < 16 && (tid >> 1) < w.cnt) s_cs[tid] = (tid & 1) ? sinv[pd.tab_off + w.a0 + (tid >> 1)] : cosv[pd.tab_off + w.a0 + (tid >> 1)];
-        for (int slot = tid; slot < MX_T * 64; slot += 256) {
+        for (int slot = tid; slot < nrt * 64; slot += 256) {
             const int rt = slot >> 6, l = slot & 63, row = rt * 32 + (l & 31);
             const int rc = row < na ? row : na - 1;      // padding rows duplicate the last reference point
             s_a[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], l >> 5);
         }
-        // this lane's columns -- every wave holds all of them: lane + 64 q -- unrotated, scaled, in registers for all the
-        // wave's candidates
-        float tx[9], ty[9];
+        if constexpr (!MULTI) {
+            // this lane's columns -- every wave holds all of them: lane + 64 q -- unrotated, scaled, in registers for all the
+            // wave's candidates
+            float tx[NQ], ty[NQ];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int j = lane + 64 * q;
-            const int jc = j < nb ? j : nb - 1;          // padding columns duplicate the last point (see k_screen_fast)
-            tx[q] = S * ptx[pd.tgt_off + jc]; ty[q] = S * pty[pd.tgt_off + jc];
-            // the norm half of the column's fragment does not depend on the candidate: written here, read by all of them
-            if (j < MX_N) s_b[(j >> 5) * 64 + (j & 31) + 32] = mx_col_norm(tx[q], ty[q]);
-        }
-        __syncthreads();
-
-        // one wave, one candidate: no barrier and nothing shared below this line
-        for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
-            const float c = s_cs[2 * (a - w.a0)], s = s_cs[2 * (a - w.a0) + 1];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int j = lane + 64 * q;
-                if (j < MX_N) {
-                    const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
-                    const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
-                    s_b[(j >> 5) * 64 + (j & 31)] = mx_col_coords(bx, by);
-                }
+                const int jc = j < nb ? j : nb - 1;          // padding columns duplicate the last point (see k_screen_fast)
+                tx[q] = S * ptx[pd.tgt_off + jc]; ty[q] = S * pty[pd.tgt_off + jc];
+                // the norm half of the column's fragment does not depend on the candidate: written here, read by all of them
+                if (j < NB) s_b[(j >> 5) * 64 + (j & 31) + 32] = mx_col_norm(tx[q], ty[q]);
             }
-            // (LDS operations of one wave execute in order: the block's reads below see these writes)
-            int m, counter;
-            asm volatile(MM_SCREEN_MX_ASM
-                         : "=&v"(m), "=&s"(counter)
-                         : "v"(vB), "v"(vA), "v"(vRW), "v"(vRR), "v"(vPERM)
-                         : MM_SCREEN_MX_CLOBBERS);
-            m = wave_max_i32_dpp(m);
-            if (lane == 0) out_sq[pd.out_off + a] = __int_as_float(m) * inv_s2;
+            __syncthreads();
+
+            // one wave, one candidate: no barrier and nothing shared below this line
+            for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
+                const float c = s_cs[2 * (a - w.a0)], s = s_cs[2 * (a - w.a0) + 1];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int j = lane + 64 * q;
+                    if (j < NB) {
+                        const float bx = __builtin_fmaf(tx[q], c, -(ty[q] * s));     // k_screen_fast's rotation, on scaled coordinates
+                        const float by = __builtin_fmaf(tx[q], s, ty[q] * c);
+                        s_b[(j >> 5) * 64 + (j & 31)] = mx_col_coords(bx, by);
+                    }
+                }
+                // (LDS operations of one wave execute in order: the block's reads below see these writes)
+                int m = MxMain<NCT, false>::run(vB, vA, vRW, vRR, vPERM, nloop, tail, vRS);
+                m = wave_max_i32_dpp(m);
+                if (lane == 0) out_sq[pd.out_off + a] = __int_as_float(m) * inv_s2;
+            }
+        } else {
+            __syncthreads();
+            const int nblk = (((nb + 31) >> 5) + NCT - 1) / NCT;         // equal blocks of NCT column tiles (the engine's choice)
+            for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
+                const float c = s_cs[2 * (a - w.a0)], s = s_cs[2 * (a - w.a0) + 1];
+                for (int i = lane; i < nrt * 32; i += 64) s_rs[i] = 0x7f800000;      // row store: +inf
+                int m = 0;
+                for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int j = lane + 64 * q;
+                        if (j < NB) {
+                            const int jg = blk * NB + j;
+                            const int jc = jg < nb ? jg : nb - 1;
+                            const float x = S * ptx[pd.tgt_off + jc], y = S * pty[pd.tgt_off + jc];
+                            const float bx = __builtin_fmaf(x, c, -(y * s));
+                            const float by = __builtin_fmaf(x, s, y * c);
+                            s_b[(j >> 5) * 64 + (j & 31) + 32] = mx_col_norm(x, y);
+                            s_b[(j >> 5) * 64 + (j & 31)] = mx_col_coords(bx, by);
+                        }
+                    }
+                    const int mb = MxMain<NCT, true>::run(vB, vA, vRW, vRR, vPERM, nloop, tail, vRS);   // max of the block's column minima
+                    m = mb > m ? mb : m;
+                }
+                for (int i = lane; i < nrt * 32; i += 64) { const int r = s_rs[i]; m = r > m ? r : m; }
+                m = wave_max_i32_dpp(m);
+                if (lane == 0) out_sq[pd.out_off + a] = __int_as_float(m) * inv_s2;
+            }
         }
     }
 }
 
-size_t lds_bytes_mx()
+size_t lds_bytes_mx(int nct, bool multi, int a_cap)
 {
-    return (size_t)MX_T * 64 * 16 + (size_t)4 * MX_T * 64 * 8 + (size_t)4 * MX_RED * 4 + 64;
+    return (size_t)a_cap * 64 * 16 + (size_t)4 * nct * 64 * 8 + (size_t)4 * MX_RED * 4 + (multi ? (size_t)4 * a_cap * 32 * 4 : 0) + 64;
 }
 
-hipError_t launch_screen_mx(const BatchDev& b, hipStream_t s)
+template <int NCT, bool MULTI>
+static hipError_t launch_mx_t(const BatchDev& b, const WorkItem* work, int n_work, int a_cap, hipStream_t s)
 {
-    const size_t lds = lds_bytes_mx();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = lds_bytes_mx(NCT, MULTI, a_cap);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx<NCT, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_screen_mx, dim3(b.n_work), dim3(256), lds, s, b.pairs, b.work, b.n_work, b.p32x, b.p32y, b.cos32,
+    hipLaunchKernelGGL((k_screen_mx<NCT, MULTI>), dim3(n_work), dim3(256), lds, s, b.pairs, work, n_work, a_cap, b.p32x, b.p32y, b.cos32,
                        b.sin32, b.sq32);
     return hipGetLastError();
 }
-int mx_min_points() { return 449; }
-int mx_max_points() { return MX_N; }
+
+// the variant for a target set of nb points: column tiles per block, and whether the set takes several blocks
+void mx_variant(int nb, int* nct, int* multi)
+{
+    const int nbt = (nb + 31) / 32;
+    if (nbt <= MX_TMAX) { *nct = nbt < MM_SCREEN_MX_NCT_MIN ? MM_SCREEN_MX_NCT_MIN : nbt; *multi = 0; return; }
+    const int nblk = (nbt + MX_TMAX - 1) / MX_TMAX;
+    *nct = (nbt + nblk - 1) / nblk; *multi = 1;
+}
+
+// work[0 .. n_work) of b.work + work_begin: items of pairs that all take the variant (nct, multi); a_cap >= their row tiles
+hipError_t launch_screen_mx(const BatchDev& b, int work_begin, int n_work, int nct, int multi, int a_cap, hipStream_t s)
+{
+    if (n_work <= 0) return hipSuccess;
+    if (a_cap < 1 || a_cap > MX_ROW_TILES_MAX || lds_bytes_mx(nct, multi != 0, a_cap) > 160 * 1024) return hipErrorInvalidValue;
+    const WorkItem* w = b.work + work_begin;
+#define MM_MX(N) case N: return multi ? launch_mx_t<(N < 9 ? 9 : N), true>(b, w, n_work, a_cap, s) : launch_mx_t<N, false>(b, w, n_work, a_cap, s);
+    if (multi && nct < 9) return hipErrorInvalidValue;       // (several blocks: at least 18 column tiles, 9 per block)
+    switch (nct) {
+        MM_MX(2) MM_MX(3) MM_MX(4) MM_MX(5) MM_MX(6) MM_MX(7) MM_MX(8) MM_MX(9) MM_MX(10) MM_MX(11) MM_MX(12) MM_MX(13)
+        MM_MX(14) MM_MX(15) MM_MX(16) MM_MX(17)
+        default: return hipErrorInvalidValue;
+    }
+#undef MM_MX
+}
+int mx_min_points() { return 64; }
+int mx_max_points() { return MX_ROW_TILES_MAX * 32; }
 
 // -------------------------------------------------------------------------------------
 // Bounded screen.  For subsets A' of the reference set and B' of the target set,

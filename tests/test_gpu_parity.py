@@ -786,23 +786,21 @@ def test_shift_rotation_extension_bounded_equals_full_screen(engine, mm):
 # ---------------------------------------------------------------------------------------
 # MM_PRECISION_F32_MATRIX: the screen on the f16 matrix pipe (k_screen_mx)
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("na,nb", [(521, 521), (544, 544), (449, 544), (500, 470), (543, 449)])
-@pytest.mark.parametrize("scale,offset", [(1.0, (4.5, 4.5)), (37.0, (-900.0, 120.0)), (1e-3, (0.0, 0.0)), (2.0 ** 20, (1e7, -3e6))])
-def test_matrix_screen_winner_cost_and_interval(engine, oracle, mm, na, nb, scale, offset):
-    """One search through the matrix-pipe screen at set sizes across its 15 .. 17 tile range, at coordinate scales far
-    from mm: the winner, its angle and its cost are the oracle's (exact re-score), and EVERY candidate's exact cost lies
-    in the interval the screened value promises, [sqrt(max(0, S - e2)) - delta, sqrt(S + e2) + delta] with
-    e2 = 128 * 2^-24 * (rho_a + rho_b)^2 -- observed errors stay far inside it."""
+def _matrix_search_case(engine, oracle, mm, na, nb, scale, offset, step=1.0, want_kernel="matrix"):
     rng = np.random.default_rng(na * 1000 + nb)
     ref = (blob(rng, na) - 4.5) * scale + np.array(offset)
     tgt = (blob(rng, nb) - 4.5) * scale + np.array(offset)
     c = tgt.mean(axis=0)
     centre = (float(c[0]), float(c[1]))
-    angles, _, _ = mm.search_angles(1.0, 180.0)
+    angles, _, _ = mm.search_angles(step, 180.0)
     oc = oracle.costs_over_angles(ref, tgt, angles, centre[0], centre[1])
     want = int(np.argmin(oc))
+    before = engine.screen_stats()
     bi, ba, bc, costs = engine.best_rotation(ref, tgt, angles, centre, skip_zero=True, precision=mm.MM_PRECISION_F32_MATRIX,
                                              return_costs=True)
+    after = engine.screen_stats()
+    took = {k: after[k] - before[k] for k in after}
+    assert took[want_kernel] == len(angles) and sum(took.values()) == len(angles), took     # the kernel asked for, nothing else
     assert bi == want and ba == angles[want] and bc == oc[want]
     rho = max(np.sqrt(((ref - c) ** 2).sum(1)).max(), 0.0) + np.sqrt(((tgt - c) ** 2).sum(1)).max()
     e2 = 128 * 2.0 ** -24 * rho * rho
@@ -816,16 +814,85 @@ def test_matrix_screen_winner_cost_and_interval(engine, oracle, mm, na, nb, scal
     assert err2.size and err2.max() < 0.25 * e2                   # the bound is not tight: a factor 4 in hand
 
 
-def test_matrix_screen_falls_back_outside_its_tile_range(engine, oracle, mm):
-    """Sets of fewer than 449 or more than 544 points take the packed-FMA screen; same results either way."""
+@pytest.mark.parametrize("na,nb", [(521, 521), (544, 544), (449, 544), (500, 470), (543, 449)])
+@pytest.mark.parametrize("scale,offset", [(1.0, (4.5, 4.5)), (37.0, (-900.0, 120.0)), (1e-3, (0.0, 0.0)), (2.0 ** 20, (1e7, -3e6))])
+def test_matrix_screen_winner_cost_and_interval(engine, oracle, mm, na, nb, scale, offset):
+    """One search through the matrix-pipe screen at the bench's set sizes (15 .. 17 tiles a side), at coordinate scales far
+    from mm: the winner, its angle and its cost are the oracle's (exact re-score), and EVERY candidate's exact cost lies
+    in the interval the screened value promises, [sqrt(max(0, S - e2)) - delta, sqrt(S + e2) + delta] with
+    e2 = 128 * 2^-24 * (rho_a + rho_b)^2 -- observed errors stay far inside it."""
+    _matrix_search_case(engine, oracle, mm, na, nb, scale, offset)
+
+
+# (reference set, target set): the reference's parameter space -- sample_size and n_points are user kwargs
+# (binding/functions.rs:144-167): Rust-side default 200 + 8 catheter points = 208, the OCT benchmark's 216 .. 240 -- every
+# column-tile count 2 .. 17 (one instantiation each), odd and even row-tile counts incl. a single loop-free pass (64 rows:
+# row tile 0 + the tail), ragged pairs, and above 544 target points the column blocks (600 -> 2 x 10 tiles, 1042 -> 2 x 17,
+# 1100 -> 3 x 12, 2048 -> 4 x 16) against 2 .. 64 row tiles
+MX_SIZES = [(64, 64), (208, 208), (216, 240), (240, 216), (320, 320), (448, 448), (97, 65), (65, 130), (100, 161), (521, 100),
+            (130, 200), (161, 250), (240, 290), (521, 330), (330, 360), (64, 390), (400, 420), (512, 470), (33 * 32, 500),
+            (2048, 544), (1042, 521)]
+MX_SIZES_BLOCKS = [(600, 600), (1042, 1042), (521, 1100), (64, 2048), (2048, 2048), (545, 545), (100, 577)]
+
+
+@pytest.mark.parametrize("na,nb", MX_SIZES)
+def test_matrix_screen_at_every_tile_count(engine, oracle, mm, na, nb):
+    """VERDICT r3 #2: the matrix-pipe screen covers the reference's parameter space, not the bench size alone."""
+    _matrix_search_case(engine, oracle, mm, na, nb, 1.0, (4.5, 4.5), step=2.0 if na * nb > 600000 else 1.0)
+    if (na, nb) in ((208, 208), (240, 216), (1042, 521)):
+        _matrix_search_case(engine, oracle, mm, na, nb, 2.0 ** 20, (1e7, -3e6), step=2.0)
+
+
+@pytest.mark.parametrize("na,nb", MX_SIZES_BLOCKS)
+def test_matrix_screen_with_the_target_set_in_column_blocks(engine, oracle, mm, na, nb):
+    """More than 544 target points: equal blocks of <= 17 column tiles, the row minima carried from block to block through
+    the wave's row store (the `carry` form of the asm block)."""
+    _matrix_search_case(engine, oracle, mm, na, nb, 1.0, (4.5, 4.5), step=4.0 if na * nb > 600000 else 2.0, want_kernel="matrix_blocks")
+    if (na, nb) == (600, 600):
+        _matrix_search_case(engine, oracle, mm, na, nb, 1e-3, (0.0, 0.0), step=2.0, want_kernel="matrix_blocks")
+
+
+def test_matrix_screen_chooses_per_pair(engine, oracle, mm):
+    """One batch, pairs of seven shapes: each goes to its own variant of the matrix kernel; only the pairs with a set of fewer
+    than 64 (or more than 2048) points take the packed-FMA screen -- and no pair sends the others there (VERDICT r3 #2:
+    `use_mx = false; break`).  Winners and costs are the oracle's."""
     rng = np.random.default_rng(5)
     angles, _, _ = mm.search_angles(2.0, 90.0)
-    for na, nb in ((200, 200), (448, 521), (600, 521), (521, 30)):
-        ref, tgt = blob(rng, na), blob(rng, nb)
-        c = tgt.mean(axis=0)
+    shapes = [(200, 200), (448, 521), (600, 521), (521, 30), (521, 600), (63, 64), (521, 521), (240, 216), (2049, 300), (200, 200)]
+    refs = [blob(rng, a) for a, _ in shapes]
+    tgts = [blob(rng, b) for _, b in shapes]
+    cs = [t.mean(axis=0) for t in tgts]
+    before = engine.screen_stats()
+    out = engine.best_rotation_batch(mm.Batch(refs, tgts, [angles] * len(shapes), [(float(c[0]), float(c[1])) for c in cs]),
+                                     precision=mm.MM_PRECISION_F32_MATRIX)
+    after = engine.screen_stats()
+    took = {k: after[k] - before[k] for k in after}
+    n = len(angles)
+    # (a batch with a reference set beyond the packed-FMA kernel's registers sends its small pairs to the direct form)
+    assert took == {"direct_f32": 3 * n, "packed_fma": 0, "matrix": 6 * n, "matrix_blocks": n, "exact_f64": 0}, took
+    for p in range(len(shapes)):
+        oc = oracle.costs_over_angles(refs[p], tgts[p], angles, float(cs[p][0]), float(cs[p][1]))
+        assert out["best_idx"][p] == int(np.argmin(oc)) and out["best_cost"][p] == oc[out["best_idx"][p]]
+    # without the reference sets beyond 528 points the small pairs take the packed-FMA screen
+    keep = [0, 1, 3, 4, 5, 6, 7]
+    before = engine.screen_stats()
+    engine.best_rotation_batch(mm.Batch([refs[i] for i in keep], [tgts[i] for i in keep], [angles] * len(keep),
+                                        [(float(cs[i][0]), float(cs[i][1])) for i in keep]), precision=mm.MM_PRECISION_F32_MATRIX)
+    after = engine.screen_stats()
+    took = {k: after[k] - before[k] for k in after}
+    assert took == {"direct_f32": 0, "packed_fma": 2 * n, "matrix": 4 * n, "matrix_blocks": n, "exact_f64": 0}, took
+
+
+def test_matrix_screen_small_batches_fill_the_workgroup(engine, oracle, mm):
+    """ADVICE r3: a single search of 361 candidates used to get one candidate per 256-thread workgroup (three of four waves
+    idle); now at least four.  Same result at 1, 3, 4, 5 and 361 candidates."""
+    rng = np.random.default_rng(11)
+    ref, tgt = blob(rng, 521), blob(rng, 521)
+    c = tgt.mean(axis=0)
+    for n in (1, 3, 4, 5, 361):
+        angles = np.linspace(-0.4, 0.4, n)
         oc = oracle.costs_over_angles(ref, tgt, angles, float(c[0]), float(c[1]))
-        bi, ba, bc = engine.best_rotation(ref, tgt, angles, (float(c[0]), float(c[1])), skip_zero=True,
-                                          precision=mm.MM_PRECISION_F32_MATRIX)
+        bi, ba, bc = engine.best_rotation(ref, tgt, angles, (float(c[0]), float(c[1])), skip_zero=True, precision=mm.MM_PRECISION_F32_MATRIX)
         assert bi == int(np.argmin(oc)) and bc == oc[bi]
 
 

@@ -1,56 +1,69 @@
 #!/usr/bin/env python3
-"""Generates multimoda-rs_amd/csrc/mm_screen_mx_asm.inc: the main phase of k_screen_mx (mm_kernels.hip) as ONE asm block on
+"""Generates multimoda-rs_amd/csrc/mm_screen_mx_asm.inc: the main phase of k_screen_mx (mm_kernels.hip) as asm blocks on
 fixed registers, so that the order is exactly the software pipeline we want -- the MFMAs of one group of tiles (1024
 squared distances each, on the matrix pipe) issued ahead of the v_min3_i32 that fold the PREVIOUS group on the vector pipe.
 The compiler's scheduler does not produce this order (tools/ubench_mfma16*.hip: 46 ns per tile compiler-scheduled, 34 ns
 hand-ordered).
 
-One WAVE, one candidate, all 17 x 17 tiles of it: no other wave touches the candidate, so there is no barrier and no
-shared accumulator anywhere in the candidate loop.  The 289 tiles are ONE stream of groups, pipelined across the row-tile
-boundaries: row tile 0, then a loop of eight iterations over two row tiles each.
+One block per COLUMN-TILE COUNT `nct` (2 .. 17; the column minima live in one register per column tile, so the column
+loop is unrolled) in two forms; the ROW-tile count is a run-time operand (a loop over pairs of row tiles, an optional tail
+row tile):
+  plain   the wave sees every column of the candidate: the row minima are final when a row tile is done
+  carry   the candidate's columns come in several blocks of `nct` tiles: a row tile's minima are met with those of the
+          blocks before through a wave-private row store in LDS (read, min, write back); after the last block the
+          kernel takes the maximum over the store
 
-A row tile is an `init` group (column tile 16) followed by eight pairs of column tiles.  Six 16-register result buffers:
-the pairs alternate between (P, Q) and (R, S); the init tile's MFMA writes X0 or X1 (row tile parity), and that buffer
-simply BECOMES the running row minima of the row tile (no instruction) -- every pair folds into it with 16 three-operand
-minima.  Per row tile: 8 (column fold of the init tile) + 8 x 32 = 264 vector instructions for 17 tiles; the floor of two
-values per instruction, each value used twice, would be 272 -- the init tile's row half costs nothing.
+One WAVE, one candidate (or column block of it), all row tiles x nct tiles: no other wave touches it, so there is no
+barrier and no shared accumulator anywhere in the candidate loop.  The tiles are ONE stream of groups, pipelined across the
+row-tile boundaries: row tile 0, then a loop over two row tiles per iteration, then (even row-tile counts) one more.
+
+A row tile is an `init` group (the last column tile) followed by pairs of column tiles and, for an even `nct`, one single
+tile.  Six 16-register result buffers: the pairs alternate between (P, Q) and (R, S); the init tile's MFMA writes X0 or X1
+(row tile parity), and that buffer simply BECOMES the running row minima of the row tile (no instruction) -- every pair
+folds into it with 16 three-operand minima.  Per row tile at nct = 17: 8 (column fold of the init tile) + 8 x 32 = 264
+vector instructions for 17 tiles; the floor of two values per instruction, each value used twice, would be 272 -- the init
+tile's row half costs nothing.
 
 The cross-lane reduction of a row tile's minima (LDS transpose: write, read back a row per lane, fold, meet the other
-half through ds_bpermute) is spread over the steps of the NEXT row tile, one LDS round trip per step, each behind a wait
-the pipeline has anyway.  The column minima stay in registers for the whole candidate (this wave has seen every row);
-lanes l and l + 32 hold different rows of the same column, so at the end v_permlane32_swap brings the halves of two
-column tiles together, one minimum per pair, and the maximum over everything leaves in one register.
+half through ds_bpermute) is spread over the steps of the NEXT row tile, each LDS round trip behind a wait the pipeline
+has anyway where the row tile has steps enough (nct >= 14: seven stages, four values read back at a time; below that all
+16 values of a row are read back at once into a landing zone of their own, three round trips, the surplus ones behind
+waits of their own).  The column minima stay in registers for the whole candidate (this wave has seen every row); lanes l
+and l + 32 hold different rows of the same column, so at the end v_permlane32_swap brings the halves of two column tiles
+together, one minimum per pair, and the maximum over everything leaves in one register.
 
 Wait states: nothing in an asm string is padded by the assembler.  The generator tracks every MFMA's destination and
 pads (s_nop) where fewer than MFMA_STATES instructions separate it from the first instruction that touches the buffer,
-pads a vector write ahead of a v_permlane32_swap, and refuses to read a register an LDS load is still filling.
+pads a vector write ahead of a v_permlane32_swap, and refuses to read a register an LDS load is still filling.  Where two
+paths meet (zero loop iterations, the tail) the code after the join is generated from either predecessor state and
+required to be the same text.  tests/test_screen_mx_asm.py executes every block symbolically for row-tile counts 1 .. 9
+and 17.
 
 Register map (VGPR):
   v36        rowmax     max over rows of the row minima (signed-int order on f32 bits, floored at 0)
-  v[40:56]   cm[17]     running column minima per column tile (this lane's column, this lane's rows)
+  v[40:56]   cm[nct]    running column minima per column tile (this lane's column, this lane's rows)
   v[60:63], v[64:67]    A operand fragment of the even / the odd row tiles
   v[68:71], v72         reduction: four values read back, accumulator
   v73                   LDS address of the A fragments, advanced by two row tiles per loop iteration
+  v74, v75              carry: address of the row store (advanced like v73), the stored minimum read back
   v[80:87], v[88:95]    B operand fragments, two groups (double buffer)
   v[100:195]            six result buffers P, Q, R, S, X0, X1
+  v[196:211]            nct < 14: landing zone of the reduction (16 values of a row)
 Operands: %0 out: this lane's maximum; %1 =s loop counter; %2 vB (LDS byte address of this lane's B fragment in column
 tile 0, the wave's own copy); %3 vA (A fragment of row tile 0; the next ones 1024 bytes apart); %4 vRW / %5 vRR
-(row-reduction scratch: write / read address); %6 vPERM (4 * (lane ^ 32))."""
+(row-reduction scratch: write / read address); %6 vPERM (4 * (lane ^ 32)); %7 s: loop iterations = (row tiles - 1) / 2;
+%8 s: 1 if the row-tile count is even (tail row tile); %9 (carry) vRS: this lane's slot in the row store of row tile 0
+(the next ones 128 bytes apart)."""
+import copy
 import os
 
 INF = "0x7f800000"
 P, Q, R, S, X = 100, 116, 132, 148, [164, 180]
-ROWMAX, CM, ASET, T, ACC, AADDR, BSET = 36, 40, [60, 64], 68, 72, 73, [80, 88]
-if os.environ.get("MX_COMPACT") == "1":      # experiment: everything below v168
-    P, Q, R, S, X = 72, 88, 104, 120, [136, 152]
-    ROWMAX, CM, ASET, T, ACC, AADDR, BSET = 24, 25, [48, 52], 42, 46, 47, [56, 64]
-NCT = 17
-NRT = 17
+ROWMAX, CM, ASET, T, ACC, AADDR, RSADDR, TP, BSET, LAND = 36, 40, [60, 64], 68, 72, 73, 74, 75, [80, 88], 196
+NCT_MIN, NCT_MAX = 2, 17
 RED_STRIDE = 136          # bytes between rows of the reduction scratch (34 dwords: 8-byte aligned reads, 2-way conflicts)
 MFMA_STATES = 12          # instructions between an 8-pass MFMA and the first touch of its destination (11 required)
 PERMLANE_STATES = 3       # a vector write and a v_permlane32_swap reading it (2 required)
-
-DBG_NOP = int(os.environ.get("MX_DBG_NOP", "0"))           # s_nop 15 count in front of every group of minima
 
 
 class Stream:
@@ -62,6 +75,7 @@ class Stream:
         self.mfma_at = {}                       # register -> state count at which an MFMA writing it was issued
         self.valu_at = {}                       # register -> state count of the last vector write
         self.loading = set()                    # registers an LDS load is filling (cleared by s_waitcnt)
+        self.used = set()                       # every vector register named (the clobber list)
 
     def _pad(self, need):
         if need > 0:
@@ -70,6 +84,7 @@ class Stream:
 
     def ins(self, text, reads=(), writes=(), lds_load=False, mfma=False, valu=False, permlane=False):
         reads, writes = list(reads), list(writes)
+        self.used.update(reads + writes)
         need = 0
         for r in reads + writes:
             if r in self.mfma_at:
@@ -103,6 +118,9 @@ class Stream:
         self.out.append(text)
         self.n += 1
 
+    def label(self, text):
+        self.out.append(text)
+
     def mark(self):
         return len(self.out)
 
@@ -114,11 +132,11 @@ def rng(base, n):
 class Pipe:
     """The software pipeline: step(g) issues the MFMAs of group g and, beside them, the minima of the group before."""
 
-    def __init__(self, s):
-        self.s = s
+    def __init__(self, s, nct, carry):
+        self.s, self.nct, self.carry = s, nct, carry
         self.pending = None                 # group whose minima are still to be issued
         self.bpar = 0                       # B operand set of the next group
-        self.red = None                     # (buffer, next stage) of the reduction in progress
+        self.red = None                     # [buffer, list of stages still to run, row-store offset] of the reduction in progress
         self.next_b = None                  # tiles whose B fragments are in flight / loaded for the next group
         self.busy = set()                   # result buffers holding values still to be folded (bookkeeping check)
 
@@ -154,9 +172,19 @@ class Pipe:
             return lambda: s.ins(f"v_min3_i32 v{Rm + v}, v{Rm + v}, v{dA + v}, v{dB + v}",
                                  reads=[Rm + v, dA + v, dB + v], writes=[Rm + v], valu=True)
 
+        def row2(v, dA):
+            return lambda: s.ins(f"v_min_i32 v{Rm + v}, v{Rm + v}, v{dA + v}", reads=[Rm + v, dA + v], writes=[Rm + v], valu=True)
+
         if g["kind"] == "init":
             d, = g["bufs"]
             return [col(CM + g["tiles"][0], d, q) for q in range(8)]
+        if g["kind"] == "single":           # an even nct's last tile: folded alone (24 instructions instead of 16)
+            dA, = g["bufs"]
+            cA = CM + g["tiles"][0]
+            L = []
+            for q in range(8):
+                L += [col(cA, dA, q), row2(2 * q, dA), row2(2 * q + 1, dA)]
+            return L
         dA, dB = g["bufs"]
         cA, cB = CM + g["tiles"][0], CM + g["tiles"][1]
         L = []
@@ -165,35 +193,87 @@ class Pipe:
         return L
 
     # ---- the reduction of a finished row tile, in stages --------------------------------------------------------------
-    def red_stage(self):
-        if self.red is None:
-            return
+    def red_final(self, off):
+        """ACC holds this half's minimum of the row, T the other half's (ds_bpermute)."""
         s = self.s
-        buf, st = self.red
-        if st == 0:
+        if self.carry:
+            s.ins(f"v_min3_i32 v{ACC}, v{ACC}, v{T}, v{TP}", reads=[ACC, T, TP], writes=[ACC], valu=True)
+            s.ins(f"ds_write_b32 v{RSADDR}, v{ACC} offset:{off}", reads=[RSADDR, ACC])
+        else:
+            s.ins(f"v_min_i32 v{ACC}, v{ACC}, v{T}", reads=[ACC, T], writes=[ACC], valu=True)
+            s.ins(f"v_max_i32 v{ROWMAX}, v{ROWMAX}, v{ACC}", reads=[ROWMAX, ACC], writes=[ROWMAX], valu=True)
+
+    def red_prefetch(self, off):
+        if self.carry:
+            self.s.ins(f"ds_read_b32 v{TP}, v{RSADDR} offset:{off}", reads=[RSADDR], writes=[TP], lds_load=True)
+
+    def red_stages(self, buf, off, narrow):
+        """The reduction of the row minima in `buf` as a list of (needs the LDS data of the stage before, closure)."""
+        s = self.s
+
+        def write():
             for v in range(16):
                 s.ins(f"ds_write_b32 %4, v{buf + v} offset:{v * RED_STRIDE}", reads=[buf + v])
             self.busy.discard(buf)                  # the row minima are on their way to LDS: the buffer is free
-        elif st == 6:
-            s.ins(f"v_min_i32 v{ACC}, v{ACC}, v{T}", reads=[ACC, T], writes=[ACC], valu=True)
-            s.ins(f"v_max_i32 v{ROWMAX}, v{ROWMAX}, v{ACC}", reads=[ROWMAX, ACC], writes=[ROWMAX], valu=True)
-        else:
-            chunk = st - 2                          # fold what stage st - 1 read, then read the next four values
-            if chunk == 0:
-                s.ins(f"v_min3_i32 v{ACC}, v{T}, v{T + 1}, v{T + 2}", reads=rng(T, 3), writes=[ACC], valu=True)
-                s.ins(f"v_min_i32 v{ACC}, v{ACC}, v{T + 3}", reads=[ACC, T + 3], writes=[ACC], valu=True)
-            elif chunk > 0:
-                s.ins(f"v_min3_i32 v{ACC}, v{ACC}, v{T}, v{T + 1}", reads=[ACC, T, T + 1], writes=[ACC], valu=True)
-                s.ins(f"v_min3_i32 v{ACC}, v{ACC}, v{T + 2}, v{T + 3}", reads=[ACC, T + 2, T + 3], writes=[ACC], valu=True)
-            if st <= 4:
-                c = st - 1
-                s.ins(f"ds_read_b64 v[{T}:{T + 1}], %5 offset:{16 * c}", writes=rng(T, 2), lds_load=True)
-                s.ins(f"ds_read_b64 v[{T + 2}:{T + 3}], %5 offset:{16 * c + 8}", writes=rng(T + 2, 2), lds_load=True)
-            else:
-                s.ins(f"ds_bpermute_b32 v{T}, %6, v{ACC}", reads=[ACC], writes=[T], lds_load=True)
-        self.red = (buf, st + 1) if st < 6 else None
 
-    def reduce_blocking(self, buf, t, u):
+        if narrow:
+            def read(c):
+                def f():
+                    s.ins(f"ds_read_b64 v[{T}:{T + 1}], %5 offset:{16 * c}", writes=rng(T, 2), lds_load=True)
+                    s.ins(f"ds_read_b64 v[{T + 2}:{T + 3}], %5 offset:{16 * c + 8}", writes=rng(T + 2, 2), lds_load=True)
+                return f
+
+            def fold(c, then):
+                def f():
+                    if c == 0:
+                        s.ins(f"v_min3_i32 v{ACC}, v{T}, v{T + 1}, v{T + 2}", reads=rng(T, 3), writes=[ACC], valu=True)
+                        s.ins(f"v_min_i32 v{ACC}, v{ACC}, v{T + 3}", reads=[ACC, T + 3], writes=[ACC], valu=True)
+                    else:
+                        s.ins(f"v_min3_i32 v{ACC}, v{ACC}, v{T}, v{T + 1}", reads=[ACC, T, T + 1], writes=[ACC], valu=True)
+                        s.ins(f"v_min3_i32 v{ACC}, v{ACC}, v{T + 2}, v{T + 3}", reads=[ACC, T + 2, T + 3], writes=[ACC], valu=True)
+                    then()
+                return f
+
+            def bperm():
+                s.ins(f"ds_bpermute_b32 v{T}, %6, v{ACC}", reads=[ACC], writes=[T], lds_load=True)
+                self.red_prefetch(off)
+            return [(False, write), (False, read(0)), (True, fold(0, read(1))), (True, fold(1, read(2))), (True, fold(2, read(3))),
+                    (True, fold(3, bperm)), (True, lambda: self.red_final(off))]
+
+        t = LAND
+
+        def read_all():
+            for q in range(8):
+                s.ins(f"ds_read_b64 v[{t + 2 * q}:{t + 2 * q + 1}], %5 offset:{8 * q}", writes=rng(t + 2 * q, 2), lds_load=True)
+
+        def fold_all():
+            for i in range(5):
+                s.ins(f"v_min3_i32 v{t + 3 * i}, v{t + 3 * i}, v{t + 3 * i + 1}, v{t + 3 * i + 2}", reads=rng(t + 3 * i, 3), writes=[t + 3 * i], valu=True)
+            s.ins(f"v_min3_i32 v{t}, v{t}, v{t + 3}, v{t + 6}", reads=[t, t + 3, t + 6], writes=[t], valu=True)
+            s.ins(f"v_min3_i32 v{t + 9}, v{t + 9}, v{t + 12}, v{t + 15}", reads=[t + 9, t + 12, t + 15], writes=[t + 9], valu=True)
+            s.ins(f"v_min_i32 v{ACC}, v{t}, v{t + 9}", reads=[t, t + 9], writes=[ACC], valu=True)
+            s.ins(f"ds_bpermute_b32 v{T}, %6, v{ACC}", reads=[ACC], writes=[T], lds_load=True)
+            self.red_prefetch(off)
+        return [(False, write), (False, read_all), (True, fold_all), (True, lambda: self.red_final(off))]
+
+    def red_run(self, n):
+        """the next n stages of the reduction in progress; a stage that needs the data of the one before it in the same
+        call waits for it (the first stage of a call sits behind the step's own wait)"""
+        if self.red is None or n == 0:
+            return
+        first = True
+        for _ in range(n):
+            if not self.red[1]:
+                break
+            needs, f = self.red[1].pop(0)
+            if needs and not first:
+                self.s.wait()
+            f()
+            first = False
+        if not self.red[1]:
+            self.red = None
+
+    def reduce_blocking(self, buf, t, u, off):
         """The last row tile of the candidate: nothing left to hide it behind.  All 16 values of a row are read back at once
         (two free result buffers as landing zone and scratch), three LDS round trips in all."""
         s = self.s
@@ -201,6 +281,7 @@ class Pipe:
         for v in range(16):
             s.ins(f"ds_write_b32 %4, v{buf + v} offset:{v * RED_STRIDE}", reads=[buf + v])
         self.busy.discard(buf)
+        self.red_prefetch(off)
         s.wait()
         for q in range(8):
             s.ins(f"ds_read_b64 v[{t + 2 * q}:{t + 2 * q + 1}], %5 offset:{8 * q}", writes=rng(t + 2 * q, 2), lds_load=True)
@@ -212,13 +293,13 @@ class Pipe:
         s.ins(f"v_min_i32 v{ACC}, v{u}, v{u + 3}", reads=[u, u + 3], writes=[ACC], valu=True)
         s.ins(f"ds_bpermute_b32 v{T}, %6, v{ACC}", reads=[ACC], writes=[T], lds_load=True)
         s.wait()
-        s.ins(f"v_min_i32 v{ACC}, v{ACC}, v{T}", reads=[ACC, T], writes=[ACC], valu=True)
-        s.ins(f"v_max_i32 v{ROWMAX}, v{ROWMAX}, v{ACC}", reads=[ROWMAX, ACC], writes=[ROWMAX], valu=True)
+        self.red_final(off)
 
     # ---- one step -----------------------------------------------------------------------------------------------------
-    def step(self, g, nxt, extra=None):
+    def step(self, g, nxt, extra=None, red_n=0):
         """g: the group whose MFMAs are issued now (its B fragments were requested a step ago); nxt: the tiles of the group
-        after it (their B fragments are requested here); extra: a closure issued with the prefetch (A loads)."""
+        after it (their B fragments are requested here); extra: a closure issued with the prefetch (A loads); red_n: stages
+        of the reduction in progress to run in this step."""
         s = self.s
         assert self.next_b == g["tiles"]
         b = BSET[self.bpar]
@@ -229,8 +310,6 @@ class Pipe:
         half = len(m) // 2 if len(g["tiles"]) == 2 else 0
 
         self.mfma(g["bufs"][0], g["a"], b)
-        for _ in range(DBG_NOP):
-            s.raw("s_nop 15")
         for f in m[:half]:
             f()
         if len(g["tiles"]) == 2:
@@ -240,12 +319,21 @@ class Pipe:
         self.load_b(nxt)
         if extra is not None:
             extra()
-        # the reduction's write stage reads the previous row tile's minima: they are final once the last group of that row
-        # tile is folded, i.e. after this step's minima when this step opens a new row tile -- so stage 0 waits a step
-        if not (self.red is not None and self.red[1] == 0 and g["kind"] == "init"):
-            self.red_stage()
-        for f in m[half:]:
-            f()
+        if red_n <= 1:
+            self.red_run(red_n)
+            for f in m[half:]:
+                f()
+        else:
+            # a short row tile: several stages in one step, each behind a wait of its own; the minima go first so that the
+            # first of those waits has something in front of it
+            self.red_run(1)
+            for f in m[half:]:
+                f()
+            for _ in range(red_n - 1):
+                if self.red is not None:
+                    if self.red[1][0][0]:
+                        s.wait()
+                    self.red_run(1)
         if prev is not None and prev["kind"] != "init":
             for d in prev["bufs"]:
                 self.busy.discard(d)
@@ -259,89 +347,188 @@ class Pipe:
                 self.busy.discard(d)
 
 
-def row_tile(k):
-    """groups of row tile k: init on column tile 16 into X[k & 1], then pairs alternating between (P, Q) and (R, S)"""
+def row_tile(nct, k):
+    """groups of row tile k: init on the last column tile into X[k & 1], then pairs alternating between (P, Q) and (R, S),
+    then (even nct) the single tile left over"""
     a, x = ASET[k & 1], X[k & 1]
-    G = [dict(kind="init", a=a, tiles=[NCT - 1], bufs=[x], rmin=x, rt=k)]
-    for p in range(8):
+    G = [dict(kind="init", a=a, tiles=[nct - 1], bufs=[x], rmin=x, rt=k)]
+    npairs = (nct - 1) // 2
+    for p in range(npairs):
         G.append(dict(kind="pair", a=a, tiles=[2 * p, 2 * p + 1], bufs=[R, S] if p & 1 else [P, Q], rmin=x, rt=k, p=p))
+    if (nct - 1) & 1:
+        G.append(dict(kind="single", a=a, tiles=[nct - 2], bufs=[R] if npairs & 1 else [P], rmin=x, rt=k, p=npairs))
     return G
 
 
-def run_row_tile(pipe, k, a_offset_next, a_reg_next):
-    """steps of row tile k; in its first pair the A fragment of row tile k + 1 is requested (offset relative to v73)"""
-    G = row_tile(k)
+def run_row_tile(pipe, nct, k, a_offset_next, a_reg_next, red_prev, red_off):
+    """steps of row tile k; in its second step the A fragment of row tile k + 1 is requested (offset relative to v73);
+    red_prev: the row tile before is reduced beside this one (its row-store offset: red_off)"""
+    G = row_tile(nct, k)
+    slots = len(G) - 1                            # the steps after the init step: where the reduction's stages go
+    narrow = slots >= 6                           # four values at a time (7 stages); else all 16 at once (3 round trips)
     for i, g in enumerate(G):
-        nxt = G[i + 1]["tiles"] if i + 1 < len(G) else [NCT - 1]
+        nxt = G[i + 1]["tiles"] if i + 1 < len(G) else [nct - 1]
         extra = None
-        if g["kind"] == "init" and k > 0:
-            pipe.red = (X[(k - 1) & 1], 0)           # the row tile before: final after this step
-        if g["kind"] == "pair" and g["p"] == 0:
+        red_n = 0
+        if i == 0 and red_prev:
+            # the row tile before: its minima are final once its last group is folded, i.e. after this step's minima
+            pipe.red = [X[(k - 1) & 1], [], red_off]
+        if i == 1:
             extra = (lambda: pipe.load_a(a_reg_next, a_offset_next))
-        pipe.step(g, nxt, extra)
+            if pipe.red is not None:
+                st = pipe.red_stages(pipe.red[0], pipe.red[2], narrow)
+                if not (narrow and slots >= 7):
+                    # the write and the first read need no wait between them (one wave's LDS operations execute in order)
+                    st = [(False, lambda a=st[0][1], b=st[1][1]: (a(), b()))] + st[2:]
+                pipe.red[1] = st
+        if i >= 1 and pipe.red is not None:
+            left, slots_left = len(pipe.red[1]), len(G) - i
+            red_n = (left + slots_left - 1) // slots_left
+        pipe.step(g, nxt, extra, red_n)
+    assert pipe.red is None, "the reduction must be over before the next row tile starts"
 
 
-s = Stream()
-pipe = Pipe(s)
-# ---- prologue: row tile 0 -------------------------------------------------------------------------------------------
-s.ins(f"v_mov_b32 v{AADDR}, %3", writes=[AADDR], valu=True)
-s.ins(f"ds_read_b128 v[{ASET[0]}:{ASET[0] + 3}], %3 offset:0", writes=rng(ASET[0], 4), lds_load=True)
-pipe.load_b([NCT - 1])
-for ct in range(NCT):
-    s.ins(f"v_mov_b32 v{CM + ct}, {INF}", writes=[CM + ct], valu=True)
-s.ins(f"v_mov_b32 v{ROWMAX}, 0", writes=[ROWMAX], valu=True)
-run_row_tile(pipe, 0, 1024, ASET[1])
-s.raw("s_mov_b32 %1, 8")
-s.raw("1:")
-# ---- loop body: row tiles (2i + 1, 2i + 2), v73 = A address of row tile 2i; generated twice, emitted once ------------------
-bodies = []
-for it in range(2):
-    m0 = s.mark()
-    run_row_tile(pipe, 1, 2048, ASET[0])
-    run_row_tile(pipe, 2, 3072, ASET[1])         # (the last iteration requests a 18th row fragment: read, never used)
-    s.ins(f"v_add_u32 v{AADDR}, 2048, v{AADDR}", reads=[AADDR], writes=[AADDR], valu=True)
-    bodies.append(s.out[m0:])
-    if it == 0:
-        keep = s.mark()
-assert bodies[0] == bodies[1], "the loop body must leave the pipeline in the state it found it in"
-del s.out[keep:]
-s.raw("s_sub_u32 %1, %1, 1")
-s.raw("s_cmp_lg_u32 %1, 0")
-s.raw("s_cbranch_scc1 1b")
-# ---- epilogue ---------------------------------------------------------------------------------------------------------
-pipe.drain()
-assert pipe.red is None
-pipe.reduce_blocking(X[0], P, Q)
-# column minima: lanes l and l + 32 hold different rows of column l & 31.  The swap leaves the lower halves of two column
-# tiles in one register and the upper halves in the other; their minimum is complete for both tiles.
-for p in range(8):
-    a, b = CM + 2 * p, CM + 2 * p + 1
-    s.ins(f"v_permlane32_swap_b32 v{a}, v{b}", reads=[a, b], writes=[a, b], permlane=True)
-    s.ins(f"v_min_i32 v{a}, v{a}, v{b}", reads=[a, b], writes=[a], valu=True)
-a = CM + 16
-s.ins(f"v_mov_b32 v{T}, v{a}", reads=[a], writes=[T], valu=True)
-s.ins(f"v_permlane32_swap_b32 v{a}, v{T}", reads=[a, T], writes=[a, T], permlane=True)
-s.ins(f"v_min_i32 v{a}, v{a}, v{T}", reads=[a, T], writes=[a], valu=True)
-c = [CM + 2 * p for p in range(9)]
-s.ins(f"v_max3_i32 v{c[0]}, v{c[0]}, v{c[1]}, v{c[2]}", reads=c[0:3], writes=[c[0]], valu=True)
-s.ins(f"v_max3_i32 v{c[3]}, v{c[3]}, v{c[4]}, v{c[5]}", reads=c[3:6], writes=[c[3]], valu=True)
-s.ins(f"v_max3_i32 v{c[6]}, v{c[6]}, v{c[7]}, v{c[8]}", reads=c[6:9], writes=[c[6]], valu=True)
-s.ins(f"v_max3_i32 v{c[0]}, v{c[0]}, v{c[3]}, v{c[6]}", reads=[c[0], c[3], c[6]], writes=[c[0]], valu=True)
-s.ins(f"v_max_i32 %0, v{c[0]}, v{ROWMAX}", reads=[c[0], ROWMAX])
-s.wait()                                       # (the unused B and A requests of the last steps)
+def snapshot(s, pipe):
+    return copy.deepcopy((s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.bpar, pipe.red, pipe.next_b, pipe.busy))
 
-out = s.out
-regs = sorted({ROWMAX} | set(range(CM, CM + NCT)) | set(range(ASET[0], ASET[0] + 8)) | set(range(T, T + 4)) | {ACC, AADDR}
-              | set(range(BSET[0], BSET[0] + 16)) | set(range(P, P + 64)) | set(range(X[0], X[0] + 32)))
-here = os.path.dirname(os.path.abspath(__file__))
-dst = os.environ.get("MX_OUT") or os.path.join(here, "..", "multimoda-rs_amd", "csrc", "mm_screen_mx_asm.inc")
-with open(dst, "w") as f:
-    f.write("// GENERATED by tools/gen_screen_mx.py -- do not edit.  Main phase of k_screen_mx: see the generator's docstring.\n")
-    f.write(f"// {len(out)} instructions\n")
-    f.write("#define MM_SCREEN_MX_ASM \\\n")
-    for line in out:
-        f.write(f'    "{line}\\n" \\\n')
-    f.write('    ""\n')
-    f.write("#define MM_SCREEN_MX_CLOBBERS " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
-    f.write(f"#define MM_SCREEN_MX_RED_STRIDE {RED_STRIDE}\n")
-print(len(out), "instructions ->", os.path.normpath(dst))
+
+def restore(s, pipe, snap):
+    s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.bpar, pipe.red, pipe.next_b, pipe.busy = copy.deepcopy(snap)
+
+
+def column_final(s, nct):
+    """lanes l and l + 32 hold different rows of column l & 31.  The swap leaves the lower halves of two column tiles in one
+    register and the upper halves in the other; their minimum is complete for both tiles."""
+    done = []
+    for p in range(nct // 2):
+        a, b = CM + 2 * p, CM + 2 * p + 1
+        s.ins(f"v_permlane32_swap_b32 v{a}, v{b}", reads=[a, b], writes=[a, b], permlane=True)
+        s.ins(f"v_min_i32 v{a}, v{a}, v{b}", reads=[a, b], writes=[a], valu=True)
+        done.append(a)
+    if nct & 1:
+        a = CM + nct - 1
+        s.ins(f"v_mov_b32 v{T}, v{a}", reads=[a], writes=[T], valu=True)
+        s.ins(f"v_permlane32_swap_b32 v{a}, v{T}", reads=[a, T], writes=[a, T], permlane=True)
+        s.ins(f"v_min_i32 v{a}, v{a}, v{T}", reads=[a, T], writes=[a], valu=True)
+        done.append(a)
+    while len(done) > 1:
+        nxt = []
+        for i in range(0, len(done), 3):
+            c = done[i:i + 3]
+            if len(c) == 3:
+                s.ins(f"v_max3_i32 v{c[0]}, v{c[0]}, v{c[1]}, v{c[2]}", reads=c, writes=[c[0]], valu=True)
+            elif len(c) == 2:
+                s.ins(f"v_max_i32 v{c[0]}, v{c[0]}, v{c[1]}", reads=c, writes=[c[0]], valu=True)
+            nxt.append(c[0])
+        done = nxt
+    s.ins(f"v_max_i32 %0, v{done[0]}, v{ROWMAX}", reads=[done[0], ROWMAX])
+
+
+def generate(nct, carry):
+    s = Stream()
+    pipe = Pipe(s, nct, carry)
+    # ---- prologue: row tile 0 -------------------------------------------------------------------------------------------
+    s.ins(f"v_mov_b32 v{AADDR}, %3", writes=[AADDR], valu=True)
+    if carry:
+        s.ins(f"v_mov_b32 v{RSADDR}, %9", writes=[RSADDR], valu=True)
+    s.ins(f"ds_read_b128 v[{ASET[0]}:{ASET[0] + 3}], %3 offset:0", writes=rng(ASET[0], 4), lds_load=True)
+    pipe.load_b([nct - 1])
+    for ct in range(nct):
+        s.ins(f"v_mov_b32 v{CM + ct}, {INF}", writes=[CM + ct], valu=True)
+    s.ins(f"v_mov_b32 v{ROWMAX}, 0", writes=[ROWMAX], valu=True)
+    run_row_tile(pipe, nct, 0, 1024, ASET[1], False, 0)
+    s.raw("s_mov_b32 %1, %7")
+    s.raw("s_cmp_eq_u32 %1, 0")
+    s.raw("s_cbranch_scc1 2f")
+    after_prologue = snapshot(s, pipe)
+    s.label("1:")
+    # ---- loop body: row tiles (2i + 1, 2i + 2), v73 = A address of row tile 2i; generated twice, emitted once ------------------
+    bodies = []
+    for it in range(2):
+        m0 = s.mark()
+        run_row_tile(pipe, nct, 1, 2048, ASET[0], True, 0)
+        run_row_tile(pipe, nct, 2, 3072, ASET[1], True, 128)     # (the last iteration requests one fragment too many: read, never used)
+        s.ins(f"v_add_u32 v{AADDR}, 2048, v{AADDR}", reads=[AADDR], writes=[AADDR], valu=True)
+        if carry:
+            s.ins(f"v_add_u32 v{RSADDR}, 256, v{RSADDR}", reads=[RSADDR], writes=[RSADDR], valu=True)
+        s.raw("s_sub_u32 %1, %1, 1")
+        s.raw("s_cmp_lg_u32 %1, 0")
+        s.raw("s_cbranch_scc1 1b")
+        bodies.append(s.out[m0:])
+        if it == 0:
+            keep = s.mark()
+            after_body = snapshot(s, pipe)
+    assert bodies[0] == bodies[1], "the loop body must leave the pipeline in the state it found it in"
+    del s.out[keep:]
+    s.label("2:")
+
+    # ---- after the loop: odd row-tile count -> epilogue; even -> one more row tile, then the epilogue -----------------------------
+    def tail_and_epilogue(entry):
+        restore(s, pipe, entry)
+        m0 = s.mark()
+        s.raw("s_cmp_lg_u32 %8, 0")
+        s.raw("s_cbranch_scc1 3f")
+        at_branch = snapshot(s, pipe)
+        pipe.drain()
+        assert pipe.red is None
+        pipe.reduce_blocking(X[0], P, Q, 0)
+        s.raw("s_branch 4f")
+        s.label("3:")
+        restore(s, pipe, at_branch)
+        run_row_tile(pipe, nct, 1, 2048, ASET[0], True, 0)
+        pipe.drain()
+        pipe.reduce_blocking(X[1], P, Q, 128)
+        s.label("4:")
+        # both paths end behind the final instructions of reduce_blocking: the same distances to every hazard below
+        column_final(s, nct)
+        s.wait()                                       # (the unused B and A requests of the last steps)
+        text = s.out[m0:]
+        del s.out[m0:]
+        return text
+
+    t_a, t_b = tail_and_epilogue(after_prologue), tail_and_epilogue(after_body)
+    assert t_a == t_b, "the code behind the loop must not depend on whether the loop ran"
+    s.out += t_a
+    return s.out, sorted(s.used)
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    dst = os.environ.get("MX_OUT") or os.path.join(here, "..", "multimoda-rs_amd", "csrc", "mm_screen_mx_asm.inc")
+    total = 0
+    with open(dst, "w") as f:
+        f.write("// GENERATED by tools/gen_screen_mx.py -- do not edit.  Main phase of k_screen_mx: see the generator's docstring.\n")
+        f.write(f"#define MM_SCREEN_MX_RED_STRIDE {RED_STRIDE}\n")
+        f.write(f"#define MM_SCREEN_MX_NCT_MIN {NCT_MIN}\n#define MM_SCREEN_MX_NCT_MAX {NCT_MAX}\n")
+        for carry in (False, True):
+            for nct in range(NCT_MIN, NCT_MAX + 1):
+                out, regs = generate(nct, carry)
+                total += len(out)
+                name = f"{nct}{'C' if carry else ''}"
+                f.write(f"// ---- nct = {nct}, {'carry' if carry else 'plain'}: {len(out)} instructions\n")
+                f.write(f"#define MM_SCREEN_MX_ASM_{name} \\\n")
+                for line in out:
+                    f.write(f'    "{line}\\n" \\\n')
+                f.write('    ""\n')
+                f.write(f"#define MM_SCREEN_MX_CLOBBERS_{name} " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
+        # the dispatch: one inline function per block, selected at compile time
+        f.write("\n#ifdef __HIPCC__\n")
+        f.write("template <int NCT, bool CARRY> struct MxMain;\n")
+        for carry in (False, True):
+            for nct in range(NCT_MIN, NCT_MAX + 1):
+                name = f"{nct}{'C' if carry else ''}"
+                f.write(f"template <> struct MxMain<{nct}, {'true' if carry else 'false'}> {{\n"
+                        "    static __device__ __forceinline__ int run(unsigned vB, unsigned vA, unsigned vRW, unsigned vRR, unsigned vPERM,\n"
+                        "                                              int nloop, int tail, unsigned vRS)\n    {\n"
+                        "        int m, counter;\n"
+                        f"        asm volatile(MM_SCREEN_MX_ASM_{name}\n"
+                        "                     : \"=&v\"(m), \"=&s\"(counter)\n"
+                        "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"v\"(vPERM), \"s\"(nloop), \"s\"(tail), \"v\"(vRS)\n"
+                        f"                     : MM_SCREEN_MX_CLOBBERS_{name});\n"
+                        "        return m;\n    }\n};\n")
+        f.write("#endif\n")
+    print(total, "instructions in", 2 * (NCT_MAX - NCT_MIN + 1), "blocks ->", os.path.normpath(dst))
+
+
+if __name__ == "__main__":
+    main()
