@@ -309,6 +309,91 @@ def cpu_baseline(cfg, geoms, threads, budget_s=10.0):
                       f"({n_angles} candidates each, N={ss + 20} pts/set), {t_used:.1f} s"}
 
 
+# The reference's SECOND published benchmark (benchmarks/benchmark_cpu_scaling.py:32-80, docs/benchmark.rst:53-86):
+# `from_array_single` on its OCT example pullback -- 280 frames, step 0.01 deg, range +-6 deg (1201 candidates brute force, a
+# 135-evaluation ladder otherwise), sample_size = 200, image_center = (5, 5), n_points = 40, write_obj / smooth off.  The OCT
+# contours themselves are not in the reference checkout (examples/data/oct_single holds only oct_ref.csv: frame 280,
+# (6, 9), z = 56 -> 0.2 mm frame spacing), so the pullback is synthetic: 280 frames x 360 points around (5, 5), 1 deg
+# torsion walk -> 200 lumen + ceil(40 * 200 / 360) = 23 catheter points = 223 points per set (7 x 7 tiles).
+OCT = dict(frames=280, points=360, step_deg=0.01, range_deg=6.0, sample_size=200, image_center=(5.0, 5.0), n_points=40,
+           published_s={"bruteforce": 14.15, "optimized": 2.40, "hardware": "Xeon Gold 6234, 16 threads (docs/benchmark.rst:53-86)"})
+
+
+def oct_pullback(mm, frames=None):
+    return mm.synthetic_pullback(frames or OCT["frames"], OCT["points"], pullback_id=0, seed=4321, image_center=OCT["image_center"],
+                                 n_catheter=OCT["n_points"], torsion_sigma_deg=1.0)
+
+
+def oct_input_data(mm, g):
+    """The (N, 4) [frame, x, y, z] arrays of numpy_to_inputdata, as the reference's benchmark builds them from its CSVs."""
+    frame = np.repeat(g.orig_frames.astype(np.float64), np.diff(g.lumen_off))
+    ref_i = int(np.nonzero(g.has_ref)[0][0])
+    return mm.numpy_to_inputdata(np.concatenate([frame[:, None], g.lumen], axis=1),
+                                 np.concatenate([[float(g.orig_frames[ref_i])], g.ref[ref_i]]), True, label="oct")
+
+
+def oct_single_leg(mm, eng, precision, repeats=5, oracle_frames=64, cpu_threads=16):
+    """Both modes of that benchmark, end to end through `mm.from_array_single` (InputData arrays -> geometry builder ->
+    search -> chain walk -> post-steps) and the search alone (mm.WithinPlan on the built geometry: stage, search, walk),
+    with the kernel time of the screen (hipEvents) and the first 63 chain steps re-done by the CPU oracle."""
+    import statistics
+    g0 = oct_pullback(mm)
+    data = oct_input_data(mm, g0)
+    kw = dict(step_rotation_deg=OCT["step_deg"], range_rotation_deg=OCT["range_deg"], sample_size=OCT["sample_size"],
+              image_center=OCT["image_center"], n_points=OCT["n_points"], write_obj=False, smooth=False, engine=eng)
+    n_set = min(OCT["sample_size"], OCT["points"]) + -(-OCT["n_points"] * OCT["sample_size"] // OCT["points"])
+    out = {"workload": (f"from_array_single, synthetic OCT-like pullback: {OCT['frames']} frames x {OCT['points']} pts, step "
+                        f"{OCT['step_deg']} deg x +-{OCT['range_deg']} deg, sample_size {OCT['sample_size']}, n_points {OCT['n_points']} "
+                        f"-> {n_set} pts/set; write_obj / smooth off (benchmarks/benchmark_cpu_scaling.py:32-80)"),
+           "points_per_set": n_set,
+           "reference_published_seconds": OCT["published_s"],
+           "note": "the reference's OCT contours are not in its checkout (only oct_ref.csv): synthetic data of the published shape; "
+                   "the published seconds are another machine's and the reference's own data -- context, not a baseline"}
+    for name, brute in (("bruteforce", True), ("optimized", False)):
+        mm.from_array_single(data, bruteforce=brute, **kw)                                  # warm-up
+        ts = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            g_api, logs_api = mm.from_array_single(data, bruteforce=brute, **kw)
+            ts.append(time.perf_counter() - t0)
+        # the search alone, through the precision of the headline
+        ss, evals, kms, launches = [], 0, 0.0, 0
+        for rep in range(repeats + 1):
+            case = [g0.copy()]
+            eng.synchronize()
+            if rep:
+                eng.profile(True)
+            t0 = time.perf_counter()
+            plan = mm.WithinPlan(eng, case, OCT["step_deg"], OCT["range_deg"], brute, OCT["sample_size"], precision=precision)
+            logs, evals, unresolved = plan.run()
+            dt_ = time.perf_counter() - t0
+            plan.close()
+            if rep:
+                pr = eng.profile_read()
+                eng.profile(False)
+                ss.append(dt_); kms += pr["ms"]; launches += pr["launches"]
+        same = bool(list(logs[0]) == list(logs_api))          # (the entry point goes on to the post-steps: compare the logs)
+        out[name] = {"from_array_single_ms": 1e3 * statistics.median(ts), "search_alone_ms": 1e3 * statistics.median(ss),
+                     "pose_evals_per_call": int(evals), "pose_evals_per_s_search_alone": evals / statistics.median(ss),
+                     "screen_kernel_ms_per_call": kms / repeats, "screen_launches_per_call": launches / repeats,
+                     "chain_steps_researched_on_chain_state": int(unresolved),
+                     "search_alone_logs_identical_to_from_array_single": same,
+                     "published_s": OCT["published_s"][name]}
+        # the oracle's chain on the first 64 frames (a chain's first steps do not depend on the rest)
+        from oracle import oracle as orc
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import to_oracle  # type: ignore
+        head = oct_pullback(mm, oracle_frames)
+        same_inputs = bool(np.array_equal(head.lumen, g0.lumen[:head.lumen.shape[0]]))
+        ol = orc.align_within_chain(to_oracle(orc, head), OCT["step_deg"], OCT["range_deg"], brute, OCT["sample_size"], n_threads=cpu_threads)
+        out[name]["identical_to_oracle_first_63_chain_steps"] = bool(same_inputs and list(logs[0])[:oracle_frames - 1] == list(ol))
+    sst = eng.screen_stats()
+    out["kernel"] = "mm::k_screen_mx<7, false> (223 pts/set = 7 x 7 tiles of 32 x 32; the bounded search behind from_array_single " \
+                    "screens its survivors and small levels with the same kernel)"
+    out["screen_stats_of_this_engine"] = sst
+    return out
+
+
 def dominant_launch(ms, pair_evals, peak=FP32_VECTOR_PEAK_TFLOPS):
     """The launches that carry the work (>= half of the largest launch's pair-distances: the one
     within-stage launch of every step): their count, mean device time and algorithmic rate -- the
@@ -879,6 +964,10 @@ def main():
         if args.workload == "config3":
             extra["ladder_default"] = ladder_leg()
             extra["extension_grid"] = extension_leg()
+            try:
+                extra["oct_single"] = oct_single_leg(mm, engs[0], PREC, cpu_threads=args.cpu_threads or 16)
+            except Exception as ex:
+                extra["oct_single"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         na = nb = cfg["sample_size"] + 20

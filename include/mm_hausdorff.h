@@ -63,14 +63,16 @@ enum {
                              of the other (2/k of the distance matrix), one full evaluation per pair
                              gives an upper bound, and only candidates whose bound does not exceed it
                              are screened and re-scored.  Candidates ruled out are never the minimum.
-                             Falls back to MM_PRECISION_F32_FAST when per-candidate costs are requested,
-                             the batch is small (mm_engine_set_bound_min_candidates)
+                             Screens every candidate like MM_PRECISION_F32_MATRIX when per-candidate costs
+                             are requested, the batch is small (mm_engine_set_bound_min_candidates)
                              or a set exceeds the bound kernel's LDS budget                          */
     MM_PRECISION_F32_MATRIX = 4 /* same contract; the screen's squared distances come from the f16 matrix pipe: one
                              v_mfma_f32_32x32x16_f16 per 32 x 32 tile over coordinates split into f16 hi + lo pieces
                              (22 significant bits, fp32 accumulation; absolute error 128*2^-24*(rho_a+rho_b)^2 on the
-                             squared value -> a wider shortlist, same winners and costs after the exact re-score).  For
-                             sets of 449 .. 544 points; other levels fall back to MM_PRECISION_F32_FAST             */
+                             squared value -> a wider shortlist, same winners and costs after the exact re-score).
+                             Chosen per PAIR for sets of 64 .. 2048 points on either side (the reference's sample_size /
+                             n_points are user kwargs, binding/functions.rs:144-167); a pair outside that range takes the
+                             packed-FMA or the direct-form screen, the other pairs of its batch are not affected   */
 };
 
 /* flags of one search */

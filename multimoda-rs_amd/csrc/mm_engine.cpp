@@ -333,9 +333,18 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // unknown rounding mode (2 u each at the magnitude of (rho_a + rho_b)^2: 24 u) -- 70 u in all.  A pair outside that
     // range keeps the packed-FMA screen (or, in a batch whose largest sets exceed that kernel's registers, the direct
     // form) with that kernel's own e2; its work items form a group of their own (Plan::groups).
+    // the bound rounds pay for themselves on sets of a few dozen points or more and on batches that keep
+    // the device busy for several rounds of workgroups (a dozen dependent launches cost more than
+    // screening a small batch outright: the between stage's 2 x 722 candidates are 40 % faster without);
+    // per-candidate costs need every candidate evaluated
+    use_lb = precision == MM_PRECISION_F32_BOUNDED && use_fast && !want_costs && A > 0 && A >= e->bound_min_candidates &&
+             std::min(max_na, max_nt) >= 64 && std::max(max_na, max_nt) <= lb_max_points();
+    // A bounded search that does not run its bound rounds (small batch, per-candidate costs asked for, sets outside the
+    // bound kernel's range) screens every candidate: on the matrix pipe, like MM_PRECISION_F32_MATRIX.
+    const bool mx_wanted = precision == MM_PRECISION_F32_MATRIX || (precision == MM_PRECISION_F32_BOUNDED && !use_lb);
     use_mx = false;
-    std::vector<int> pair_key((size_t)P, 0);       // 0: direct form, 1: packed FMA, else 2 + (multi << 8 | nct) << 8 | row-tile class
-    if (precision == MM_PRECISION_F32_MATRIX && A > 0) {
+    std::vector<int> pair_key((size_t)P, 0);       // 0: direct form, 1: packed FMA, else 2 + the matrix kernel's variant
+    if (mx_wanted && A > 0) {
         for (int p = 0; p < P; ++p) {
             PairDesc& d = host_pairs[p];
             if (trivial[p] || d.n_ang == 0) continue;
@@ -357,12 +366,6 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
             use_mx = true;
         }
     }
-    // the bound rounds pay for themselves on sets of a few dozen points or more and on batches that keep
-    // the device busy for several rounds of workgroups (a dozen dependent launches cost more than
-    // screening a small batch outright: the between stage's 2 x 722 candidates are 40 % faster without);
-    // per-candidate costs need every candidate evaluated
-    use_lb = precision == MM_PRECISION_F32_BOUNDED && use_fast && !want_costs && A > 0 && A >= e->bound_min_candidates &&
-             std::min(max_na, max_nt) >= 64 && std::max(max_na, max_nt) <= lb_max_points();
     if (max_nbp > max_target_points_f64() || (precision != MM_PRECISION_F64 && max_nbp > max_target_points_f32()))
         return set_error(MM_ERR_TOO_LARGE, "target set does not fit the kernel's LDS budget (" +
                                                std::to_string(max_target_points_f64()) + " points)");

@@ -147,6 +147,47 @@ def test_default_ladder_full_size_equals_oracle(fresh_engine, oracle, mm, step, 
         assert geoms_equal(geoms[k], og[k]), f"coordinates of pullback {k} differ"
 
 
+@pytest.mark.parametrize("bruteforce", [True, False])
+@pytest.mark.parametrize("precision", ["matrix", "bounded"])
+def test_oct_single_benchmark_shape_equals_oracle(fresh_engine, oracle, mm, bruteforce, precision):
+    """The reference's SECOND published benchmark at full size (benchmarks/benchmark_cpu_scaling.py:32-80): 280 frames,
+    0.01 deg x +-6 deg (1201 candidates brute force; 1 deg / 0.1 deg / 0.01 deg ladder = 135 evaluations otherwise),
+    sample_size 200, n_points 40 -> 223 points per set (7 x 7 tiles of the matrix-pipe screen): the whole chain's logs and
+    coordinates against the oracle's sequential chain, and `mm.from_array_single` end to end on the same arrays."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    O = bench.OCT
+    g = bench.oct_pullback(mm)
+    og = to_oracle(oracle, g)
+    ologs = oracle.align_within_chain(og, O["step_deg"], O["range_deg"], bruteforce, O["sample_size"], n_threads=_threads())
+    prec = {"matrix": mm.MM_PRECISION_F32_MATRIX, "bounded": mm.MM_PRECISION_F32_BOUNDED}[precision]
+    before = fresh_engine.screen_stats()
+    plan = mm.WithinPlan(fresh_engine, [g], O["step_deg"], O["range_deg"], bruteforce, O["sample_size"], precision=prec)
+    logs, evals, unresolved = plan.run()
+    plan.close()
+    after = fresh_engine.screen_stats()
+    assert logs[0] == ologs and geoms_equal(g, og)
+    if bruteforce:
+        assert evals == 279 * 1201
+    else:
+        assert 279 * oracle.count_evals(O["step_deg"], O["range_deg"], False) <= evals <= 279 * 135
+    assert after["packed_fma"] == before["packed_fma"] and after["direct_f32"] == before["direct_f32"]
+    if precision == "matrix":
+        assert after["matrix"] - before["matrix"] == evals          # every candidate screened on the matrix pipe
+    elif not bruteforce:
+        # the bounded search: the ladder's first and last level (279 x 13 and 279 x 21 candidates) are small batches, screened
+        # outright on the matrix pipe; the middle level (279 x 101) runs the bound rounds
+        assert after["matrix"] - before["matrix"] >= 279 * 13
+    # the entry point itself: same logs
+    g_api, logs_api = mm.from_array_single(bench.oct_input_data(mm, bench.oct_pullback(mm)), step_rotation_deg=O["step_deg"],
+                                           range_rotation_deg=O["range_deg"], sample_size=O["sample_size"],
+                                           image_center=O["image_center"], n_points=O["n_points"], write_obj=False, smooth=False,
+                                           bruteforce=bruteforce, engine=fresh_engine)
+    assert list(logs_api) == ologs
+
+
 def test_bench_two_ranks_check_config2():
     """`bench.py --gpus 2 --workload config2 --check` as the driver starts it (torch.distributed.run, here two `gloo`
     ranks sharing the one GPU): the sharded step pipeline end to end, rank 0's result compared with the oracle."""
