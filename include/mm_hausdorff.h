@@ -68,7 +68,7 @@ enum {
                              or a set exceeds the bound kernel's LDS budget                          */
     MM_PRECISION_F32_MATRIX = 4 /* same contract; the screen's squared distances come from the f16 matrix pipe: one
                              v_mfma_f32_32x32x16_f16 per 32 x 32 tile over coordinates split into f16 hi + lo pieces
-                             (22 significant bits, fp32 accumulation; absolute error 128*2^-24*(rho_a+rho_b)^2 on the
+                             (22 significant bits, fp32 accumulation; absolute error 2^-24*(47 R^2 + 6 rho_a^2 + 27 rho_b^2), R = rho_a+rho_b, on the
                              squared value -> a wider shortlist, same winners and costs after the exact re-score).
                              Chosen per PAIR for sets of 64 .. 2048 points on either side (the reference's sample_size /
                              n_points are user kwargs, binding/functions.rs:144-167); a pair outside that range takes the

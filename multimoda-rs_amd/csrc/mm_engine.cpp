@@ -223,6 +223,32 @@ static inline double screen_delta(double rho_r, double rho_t, double cx, double 
     return 24.0 * u * (rho_r + rho_t) + std::ldexp(std::fabs(cx) + std::fabs(cy) + rho_r + rho_t, -49) + 1e-300;
 }
 
+// Error bound of the matrix-pipe screen's squared distances: |S~ - S| <= mx_e2(rho_a, rho_b), with rho_a (rho_b) the largest
+// distance of a reference (target) point from the rotation centre, R = rho_a + rho_b, u = 2^-24.  In the kernel's scaled
+// units (larger radius in [256, 512)) the screened value of a point pair is
+//     S~ = fl_acc( |a~|^2~ + n2(b) - 2 a~ . b~' ),   a~ = a1 + a2, b~' = b1' + b2' the f16 hi + lo splits of a and of R32(b),
+// the products exact in fp32 (11 x 11 bits), and the budget is (every term in units of u):
+//   * split of both points -- |a - a~|, |b' - b~'| <= 2^-22 |.| per coordinate (two roundings of relative size 2^-11), or
+//     2^-14 absolute where a lo piece falls into f16's subnormal range and the matrix pipe flushes it; the distance moves by
+//     2 |a - b| (|da| + |db|) <= 2 R sqrt(2) 2^-22 R = 11.3 R^2, with the absolute form 2 R 2 sqrt(2) 2^-14 = 22.6 R^2 (256 / R)
+//     <= 22.6 R^2 because the larger radius is at least 256:                                                        23 R^2
+//   * the row norm |a~|^2: two f32 roundings (2 rho_a^2), its own split n2 = 256 nh + nl (nh to 0.25, nl to 2^-6 absolute
+//     = 4 u rho^2 at rho = 256, less above):                                                                        6 rho_a^2
+//   * the column norm is taken from the UNROTATED target point, once per work item: the same 6, the f32 rotation (cos / sin
+//     tables rounded to f32: |c^2 + s^2 - 1| <= 1.5 u; two fma per coordinate: |b' - R b| <= 2 sqrt(2) u rho_b) keeps
+//     |b|^2 to 9, and the split of the rotated point moves |b'|^2 by 2 rho_b sqrt(2) 2^-22 rho_b = 11.3:               27 rho_b^2
+//   * twelve fp32 accumulations inside the MFMA, rounding mode and order unspecified: 2 u each on partial sums that stay
+//     below (|a| + |b|)^2 <= R^2:                                                                                   24 R^2
+// Sum: u (47 R^2 + 6 rho_a^2 + 27 rho_b^2) -- 55 u R^2 for equal radii.  (Rounds 3 shipped a flat 128 u R^2; the directed
+// search of tests/test_gpu_mx_error_bound.py -- coordinates on f16 ties, radii at both edges of the scale, far outliers,
+// subnormal lo pieces, tile-edge set sizes, the angles whose f32 (cos, sin) is furthest from unit norm -- found at most
+// 2.2 % of that, 5 % of this.)  min and max are 1-Lipschitz, so the bound carries over to the screened Hausdorff value.
+static double mx_e2(double rho_a, double rho_b)
+{
+    const double u = 5.9604644775390625e-08, R = rho_a + rho_b;
+    return u * (47.0 * R * R + 6.0 * rho_a * rho_a + 27.0 * rho_b * rho_b);
+}
+
 int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_t angle_begin, int32_t angle_end,
                       bool want_costs_, hipStream_t st)
 {
@@ -326,13 +352,9 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // Matrix-pipe screen, chosen PER PAIR: sets of mx_min_points() .. mx_max_points() points (the kernel is instantiated
     // per column-tile count, its row-tile count is a run-time operand, larger target sets are cut into column blocks), a
     // scale exponent that puts the larger radius into [256, 512) (f16 pieces, their doubles and |x|^2 / 256 stay in range),
-    // and the wider error bound of its squared values: e2 = 128 u (rho_a + rho_b)^2 -- f16 hi + lo split of both points
-    // (<= 2^-22 rho per coordinate, 2^-13 absolute if a lo piece were flushed: 11 u), the norms' f32 rounding and split
-    // (6 u), the target norm taken from the UNROTATED point (the f32 rotation keeps |b|^2 to 9 u rho_b^2, the split of the
-    // rotated point moves it by another 11 u: 27 u with the norm's own rounding and split), twelve fp32 accumulations of
-    // unknown rounding mode (2 u each at the magnitude of (rho_a + rho_b)^2: 24 u) -- 70 u in all.  A pair outside that
-    // range keeps the packed-FMA screen (or, in a batch whose largest sets exceed that kernel's registers, the direct
-    // form) with that kernel's own e2; its work items form a group of their own (Plan::groups).
+    // and the error bound of its squared values (mx_e2 below).  A pair outside that range keeps the packed-FMA screen (or,
+    // in a batch whose largest sets exceed that kernel's registers, the direct form) with that kernel's own e2; its work
+    // items form a group of their own (Plan::groups).
     // the bound rounds pay for themselves on sets of a few dozen points or more and on batches that keep
     // the device busy for several rounds of workgroups (a dozen dependent launches cost more than
     // screening a small batch outright: the between stage's 2 x 722 candidates are 40 % faster without);
@@ -361,7 +383,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
             const int nrt = (d.n_ref + 31) / 32, cls = nrt <= 17 ? 0 : 1;
             (void)std::frexp(rmax * (1.0 + 1e-6), &k);   // radius < 2^k
             d.pad0 = 9 - k;
-            d.e2 = 128.0 * 5.9604644775390625e-08 * (ra + rb) * (ra + rb);
+            d.e2 = mx_e2(ra, rb);
             pair_key[(size_t)p] = 2 + ((((multi << 8) | nct) << 1 | cls) << 2);
             use_mx = true;
         }

@@ -802,8 +802,9 @@ def _matrix_search_case(engine, oracle, mm, na, nb, scale, offset, step=1.0, wan
     took = {k: after[k] - before[k] for k in after}
     assert took[want_kernel] == len(angles) and sum(took.values()) == len(angles), took     # the kernel asked for, nothing else
     assert bi == want and ba == angles[want] and bc == oc[want]
-    rho = max(np.sqrt(((ref - c) ** 2).sum(1)).max(), 0.0) + np.sqrt(((tgt - c) ** 2).sum(1)).max()
-    e2 = 128 * 2.0 ** -24 * rho * rho
+    ra, rb = np.sqrt(((ref - c) ** 2).sum(1)).max(), np.sqrt(((tgt - c) ** 2).sum(1)).max()
+    rho = ra + rb
+    e2 = 2.0 ** -24 * (47 * rho * rho + 6 * ra * ra + 27 * rb * rb)      # mx_e2 (csrc/mm_engine.cpp)
     delta = 24 * 2.0 ** -24 * rho + 2.0 ** -49 * (abs(c).sum() + rho) + 1e-300
     S = np.asarray(costs) ** 2
     lo = np.sqrt(np.maximum(0.0, S - e2)) - delta
@@ -820,7 +821,7 @@ def test_matrix_screen_winner_cost_and_interval(engine, oracle, mm, na, nb, scal
     """One search through the matrix-pipe screen at the bench's set sizes (15 .. 17 tiles a side), at coordinate scales far
     from mm: the winner, its angle and its cost are the oracle's (exact re-score), and EVERY candidate's exact cost lies
     in the interval the screened value promises, [sqrt(max(0, S - e2)) - delta, sqrt(S + e2) + delta] with
-    e2 = 128 * 2^-24 * (rho_a + rho_b)^2 -- observed errors stay far inside it."""
+    e2 = 2^-24 * (47 (rho_a + rho_b)^2 + 6 rho_a^2 + 27 rho_b^2) -- observed errors stay far inside it."""
     _matrix_search_case(engine, oracle, mm, na, nb, scale, offset)
 
 
