@@ -631,6 +631,9 @@ def main():
     if LOOK < 2:
         raise SystemExit("MM_BENCH_ENGINES must be >= 2")
     engs = [mm.Engine(local_rank) for _ in range(LOOK)]
+    if os.environ.get("MM_BENCH_BOUND_MATRIX"):      # A/B: 0 = the bounded search on the packed-FMA kernels of rounds 1-3; 11/12/21/22 = variant
+        for e_ in engs:
+            e_.set_bound_matrix(int(os.environ["MM_BENCH_BOUND_MATRIX"]))
     ext = cfg.get("shift")
     pipelined = mode == 1 and ext is None and not os.environ.get("MM_BENCH_SEQUENTIAL")
     STAGER = LOOK >= 3
@@ -884,7 +887,16 @@ def main():
     # must be the same -- a race in the pipeline (three threads, three engines) would show here first
     steps_identical = all(list(r[0]) == list(res[0]) and np.array_equal(r[1], res[1]) and r[2:] == res[2:] for r in results)
     if not steps_identical:
-        raise SystemExit("the timed steps disagree with each other: identical inputs gave different alignments")
+        what = []
+        for i, r in enumerate(results):
+            d = [n for n, same in (("within logs", list(r[0]) == list(res[0])), ("between rotations", np.array_equal(r[1], res[1])),
+                                   ("pose-eval / re-search counts", r[2:] == res[2:])) if not same]
+            if d:
+                what.append(f"step {i}: {', '.join(d)}" + (f" {r[2:]} vs {res[2:]}" if "pose-eval / re-search counts" in d else ""))
+        import hashlib
+        sig = [hashlib.sha1(repr((list(r[0]), None if r[1] is None else np.asarray(r[1]).tolist(), r[2:])).encode()).hexdigest()[:8] for r in results]
+        raise SystemExit("the timed steps disagree with each other: identical inputs gave different alignments (" + "; ".join(what[:6]) +
+                         f"); result signatures per step: {sig}")
     if args.precision != "bounded":
         bound = None
 

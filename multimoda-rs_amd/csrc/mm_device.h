@@ -61,7 +61,8 @@ struct BatchDev {
     // per-candidate outputs
     float*    sq32;       // squared Hausdorff from the screening kernel
     double*   sq64;       // exact squared Hausdorff (valid where flag != 0 or in exact mode)
-    uint8_t*  flag;       // 1 = shortlisted (re-scored in f64)
+    uint8_t*  flag;       // 1 = shortlisted (re-scored in f64); before that, bounded search on the matrix pipe: 1 = needs a bound
+    int64_t   n_cand;     // candidates of the level (length of sq32 / lb32 / flag)
     // shortlist queue
     WorkItem* items;      // capacity = total candidates (bounded mode: first the survivors' runs)
     int32_t*  n_items;    // 8 device counters: [0] re-score queue; bounded mode: [1] picks, [2] queue 0 (round 2),
@@ -69,6 +70,9 @@ struct BatchDev {
     // bounded screen (MM_PRECISION_F32_BOUNDED)
     const WorkItem* work_lb;   // bound kernel's work list (more candidates per workgroup)
     int32_t   n_work_lb, lb_stride;
+    int32_t   lb_mx;       // > 0: the bounds come from the matrix pipe (k_bound_mx); value = row tiles per set of its LDS layout
+    int32_t   lb_mx_qt, lb_mx_nc;   // its variant: column tiles of queries per side (1 | 2), candidates per wave at once (1 | 2)
+    int32_t   kept_mx_nct, kept_mx_acap;   // > 0: the picks' and the survivors' screen is k_screen_mx<kept_mx_nct, false> (every pair: that variant)
     float*    lb32;        // per-candidate lower bound of the screened squared value
     int32_t*  pick_idx;    // [2 * n_pairs] per pair: candidate with the smallest bound after round 1 / round 3 (-1: none)
     WorkItem* items_pick;  // [2 * n_pairs] queue entries of the two picks
@@ -93,6 +97,7 @@ hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStr
 // of their pairs must have sets of mx_min_points() .. mx_max_points() points, a target set whose variant (mx_variant) is
 // (nct, multi), a reference set of at most a_cap row tiles of 32, and PairDesc::pad0 = the pair's scale exponent
 hipError_t launch_screen_mx(const BatchDev& b, int work_begin, int n_work, int nct, int multi, int a_cap, hipStream_t s);
+hipError_t launch_screen_none(const BatchDev& b, int work_begin, int n_work, hipStream_t s);   // screened value 0 for every candidate
 void       mx_variant(int n_tgt, int* nct, int* multi);
 size_t     lds_bytes_mx(int nct, bool multi, int a_cap);
 int        mx_min_points();
@@ -117,6 +122,7 @@ int        lb_candidate_step();
 int        lb_sparse_candidates(int n);   // candidates of a list of n the first round scores
 hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s);
 int        lb_max_query_points();   // subset size the bound kernel holds in registers
+int        lb_mx_max_points();      // largest set (either side) the matrix-pipe bound kernel stages in LDS
 int        lb_max_points();         // largest set (either side) the bound kernel stages in LDS
 // large-set Hausdorff (no LDS limit on the set sizes); pairs/work are device arrays of the kernel's
 // LargePair {a_off, na, b_off, nb, col_off, pad} / LargeWork {pair, row0} records

@@ -361,6 +361,50 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // per-candidate costs need every candidate evaluated
     use_lb = precision == MM_PRECISION_F32_BOUNDED && use_fast && !want_costs && A > 0 && A >= e->bound_min_candidates &&
              std::min(max_na, max_nt) >= 64 && std::max(max_na, max_nt) <= lb_max_points();
+    // The bound rounds on the matrix pipe (k_bound_mx) and the survivors through k_screen_mx: every non-trivial pair with
+    // sets of 64 .. lb_mx_max_points() points and a radius f16 can be scaled to; the pairs then carry the scale exponent and
+    // the matrix kernels' error bound (the larger of the two directions': pass 1 rotates reference queries against target
+    // rows, pass 2 target queries against reference rows).  The two per-pair picks stay on the packed-FMA screen (it emits
+    // the row / column minima the third round's query choice needs); its e2 is the smaller one.
+    lb_mx_tiles = 0; kept_nct = 0; kept_acap = 0;
+    if (use_lb && e->bound_matrix) {
+        bool ok = true;
+        int tiles = 1, nct0 = -1, acap = 1;
+        for (int p = 0; p < P && ok; ++p) {
+            const PairDesc& d = host_pairs[p];
+            if (trivial[p] || d.n_ang == 0) continue;
+            const double rmax = std::max(set_rho[pairs[p].ref_set], set_rho[pairs[p].tgt_set]);
+            ok = d.n_ref >= mx_min_points() && d.n_tgt >= mx_min_points() && d.n_ref <= lb_mx_max_points() &&
+                 d.n_tgt <= lb_mx_max_points() && rmax > 1.0e-30 && rmax < 1.0e30;
+            tiles = std::max(tiles, (std::max(d.n_ref, d.n_tgt) + 31) / 32);
+            int nct = 0, multi = 0;
+            mx_variant(d.n_tgt, &nct, &multi);
+            if (multi) nct = 0;
+            nct0 = nct0 < 0 ? nct : (nct0 == nct ? nct0 : 0);     // 0: the pairs do not share one variant
+            acap = std::max(acap, (d.n_ref + 31) / 32);
+        }
+        // The picks and the survivors go through k_screen_mx from device queues, which takes ONE variant per launch: every
+        // pair must have the same column-tile count (and <= 17 row tiles, two workgroups per CU).  (k_screen_mx gives a
+        // candidate to one wave, ~10 us, where the packed-FMA screen spends 2 - 3 us of a whole workgroup -- 222 against
+        // 156 us per step for config3's survivors -- but the packed-FMA kernels are not to run beside MFMA kernels:
+        // profiles/README.md, "packed-FMA kernels beside MFMA kernels".)  A batch of mixed shapes, or one with sets beyond
+        // the bound kernel's range, is screened outright on the matrix pipe instead.
+        ok = ok && nct0 > 0 && acap <= 17;
+        if (!ok) use_lb = false;
+        if (ok) {
+            lb_mx_tiles = tiles;
+            kept_nct = nct0; kept_acap = acap;
+            for (int p = 0; p < P; ++p) {
+                PairDesc& d = host_pairs[p];
+                if (trivial[p] || d.n_ang == 0) continue;
+                const double ra = set_rho[pairs[p].ref_set], rb = set_rho[pairs[p].tgt_set];
+                int k = 0;
+                (void)std::frexp(std::max(ra, rb) * (1.0 + 1e-6), &k);
+                d.pad0 = 9 - k;
+                d.e2 = std::max(mx_e2(ra, rb), mx_e2(rb, ra));
+            }
+        }
+    }
     // A bounded search that does not run its bound rounds (small batch, per-candidate costs asked for, sets outside the
     // bound kernel's range) screens every candidate: on the matrix pipe, like MM_PRECISION_F32_MATRIX.
     const bool mx_wanted = precision == MM_PRECISION_F32_MATRIX || (precision == MM_PRECISION_F32_BOUNDED && !use_lb);
@@ -371,6 +415,9 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
             PairDesc& d = host_pairs[p];
             if (trivial[p] || d.n_ang == 0) continue;
             pair_key[(size_t)p] = use_fast ? 1 : 0;
+            // a set of fewer than 64 points: no f32 screen, every candidate is scored exactly (cheap at that size, and no
+            // packed-FMA kernel runs under this precision unless a set exceeds mx_max_points())
+            if (std::min(d.n_ref, d.n_tgt) < mx_min_points() && std::max(d.n_ref, d.n_tgt) <= mx_max_points()) { pair_key[(size_t)p] = -1; use_mx = true; continue; }
             const double ra = set_rho[pairs[p].ref_set], rb = set_rho[pairs[p].tgt_set], rmax = std::max(ra, rb);
             if (d.n_ref < mx_min_points() || d.n_ref > mx_max_points() || d.n_tgt < mx_min_points() || d.n_tgt > mx_max_points() ||
                 !(rmax > 1.0e-30) || !(rmax < 1.0e30))
@@ -442,7 +489,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
                 }
                 const int wb = (int)wstart[(size_t)q], wc = (int)(wstart[(size_t)q1] - wstart[(size_t)q]);
                 if (wc > 0)
-                    groups.push_back(key < 2 ? ScreenGroup{key, 0, 0, 0, wb, wc}
+                    groups.push_back(key < 0 ? ScreenGroup{3, 0, 0, 0, wb, wc} : key < 2 ? ScreenGroup{key, 0, 0, 0, wb, wc}
                                              : ScreenGroup{2, ((key - 2) >> 3) & 0xff, ((key - 2) >> 11) & 1, a_cap, wb, wc});
                 q = q1;
             }
@@ -452,8 +499,8 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     W_lb = 0; lb_runs_cap = 0; lb_pair_evals = 0.0; lb_sparse_total = 0;
     if (use_lb) {
         // every lb_stride-th point of either set is a query; the subset has to fit the kernel's registers
-        const int qmax = lb_max_query_points();
-        lb_stride = std::max(8, (std::max(max_na, max_nt) + qmax - 1) / qmax);
+        const int qmax = lb_mx_tiles > 0 ? 32 * e->bound_matrix_qt : lb_max_query_points();
+        lb_stride = std::max(lb_mx_tiles > 0 ? 1 : 8, (std::max(max_na, max_nt) + qmax - 1) / qmax);
         // first round: every lb_candidate_step()-th candidate and the last one, 32 of them per workgroup
         // (4 waves x 8: amortises staging the reference set)
         const int apb_lb = 32, cstep = lb_candidate_step();
@@ -530,9 +577,11 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     dev.cos32 = (const float*)(B + o_c32); dev.sin32 = (const float*)(B + o_s32);
     dev.cos64 = (const double*)(B + o_c64); dev.sin64 = (const double*)(B + o_s64);
     dev.ang64 = (const double*)(B + o_a64);
-    dev.sq32 = (float*)(B + o_sq32); dev.sq64 = (double*)(B + o_sq64); dev.flag = (uint8_t*)(B + o_flag);
+    dev.sq32 = (float*)(B + o_sq32); dev.sq64 = (double*)(B + o_sq64); dev.flag = (uint8_t*)(B + o_flag); dev.n_cand = A;
     dev.items = (WorkItem*)(B + o_items); dev.n_items = (int32_t*)(B + o_nitems);
     dev.work_lb = (const WorkItem*)(B + o_work_lb); dev.n_work_lb = W_lb; dev.lb_stride = lb_stride;
+    dev.lb_mx = lb_mx_tiles; dev.kept_mx_nct = kept_nct; dev.kept_mx_acap = kept_acap;
+    dev.lb_mx_qt = e->bound_matrix_qt; dev.lb_mx_nc = e->bound_matrix_nc;
     dev.lb32 = (float*)(B + o_lb32); dev.pick_idx = (int32_t*)(B + o_pick); dev.items_pick = (WorkItem*)(B + o_items_pick);
     dev.items_lb = (WorkItem*)(B + o_items_lb); dev.emit = (float*)(B + o_emit); dev.emit_rows = emit_rows; dev.emit_cols = emit_cols;
     dev.qlist = (int32_t*)(B + o_qlist);
@@ -584,9 +633,11 @@ int Plan::run(bool screen_only)
                 for (const ScreenGroup& g : groups) {
                     int64_t cand = 0;
                     for (int k = 0; k < g.work_count; ++k) cand += host_work[(size_t)(g.work_begin + k)].cnt;
-                    eng->screened[g.kind == 2 ? 2 + g.multi : g.kind] += cand;
+                    eng->screened[g.kind == 2 ? 2 + g.multi : (g.kind == 3 ? 4 : g.kind)] += cand;
                     if (g.kind == 2) {
                         e = launch_screen_mx(dev, g.work_begin, g.work_count, g.nct, g.multi, g.a_cap, s);
+                    } else if (g.kind == 3) {
+                        e = launch_screen_none(dev, g.work_begin, g.work_count, s);
                     } else {
                         BatchDev sub = dev;              // the pairs outside the matrix kernel's range: their own work items
                         sub.work = dev.work + g.work_begin; sub.n_work = g.work_count;
@@ -1099,6 +1150,19 @@ int mm_engine_set_bound_min_candidates(mm_engine* h, int64_t n)
     return MM_OK;
 }
 
+int mm_engine_set_bound_matrix(mm_engine* h, int on)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e) return set_error(MM_ERR_INVALID, "engine == NULL");
+    e->bound_matrix = on != 0;
+    if (on > 1) {      // experiments: 10 * (query tiles per side) + (candidates per wave), e.g. 21
+        const int qt = on / 10, nc = on % 10;
+        if ((qt != 1 && qt != 2) || (nc != 1 && nc != 2)) return set_error(MM_ERR_INVALID, "mm_engine_set_bound_matrix: variant must be 11, 12, 21 or 22");
+        e->bound_matrix_qt = qt; e->bound_matrix_nc = nc;
+    }
+    return MM_OK;
+}
+
 int mm_engine_bound_stats(mm_engine* h, int64_t out[5])
 {
     Engine* e = reinterpret_cast<Engine*>(h);
@@ -1155,6 +1219,41 @@ int mm_best_rotation_batch(mm_engine* h, int n_pairs,
         if (best_angle) best_angle[p] = res.best_idx[p] >= 0 ? angles[ang_off[p] + res.best_idx[p]] : NAN;
     }
     if (all_costs) scatter_costs(plan, costs.data(), ang_off, all_costs);
+    return MM_OK;
+}
+
+// The lower bound MM_PRECISION_F32_BOUNDED's first round would give EVERY candidate of one search (it scores every 8th):
+// out_lb2[i] <= (exact cost of candidate i)^2 up to the error bound *e2 of the kernel's squared values and *delta of the
+// distance.  A test hook for the bound kernels themselves (packed-FMA: matrix == 0, matrix pipe: matrix != 0); nothing in
+// the product calls it.
+int mm_lower_bounds(mm_engine* h, const double* rx, const double* ry, int nr, const double* tx, const double* ty, int nt,
+                    double cx, double cy, const double* angles, int n_angles, int flags, int matrix, float* out_lb2,
+                    double* e2, double* delta, int* stride)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e || !out_lb2 || nr <= 0 || nt <= 0 || n_angles <= 0 || !angles) return set_error(MM_ERR_INVALID, "mm_lower_bounds: bad arguments");
+    MM_HIP(hipSetDevice(e->device));
+    std::vector<SetRef> sets{SetRef{rx, ry, nr, cx, cy}, SetRef{tx, ty, nt, cx, cy}};
+    std::vector<PairSpec> pairs{PairSpec{0, 1, cx, cy, flags, angles, n_angles, 0.0, 0.0}};
+    const int64_t keep_min = e->bound_min_candidates;
+    const bool keep_mx = e->bound_matrix;
+    e->bound_min_candidates = 0; e->bound_matrix = matrix != 0;
+    Plan plan;
+    int rc = plan.stage_sets(e, sets, true);
+    if (!rc) rc = plan.stage_level(pairs, MM_PRECISION_F32_BOUNDED, 0, INT32_MAX, false);
+    e->bound_min_candidates = keep_min; e->bound_matrix = keep_mx;
+    if (rc) return rc;
+    if (!plan.use_lb || (matrix != 0) != (plan.lb_mx_tiles > 0)) return set_error(MM_ERR_INVALID, "mm_lower_bounds: the bound kernel asked for does not take these sets");
+    BatchDev sub = plan.dev;
+    sub.work_lb = plan.dev.work; sub.n_work_lb = plan.W;      // every candidate, step 1 (WorkItem::pad == 0)
+    const int nap = (plan.max_na + 31) & ~31, nbp = (plan.max_nt + 31) & ~31;
+    hipError_t he = launch_screen_lb(sub, nap, nbp, plan.stream);
+    if (he != hipSuccess) return hip_error(he, "bound kernel launch");
+    MM_HIP(hipMemcpyAsync(out_lb2, plan.dev.lb32, (size_t)n_angles * 4, hipMemcpyDeviceToHost, plan.stream));
+    MM_HIP(hipStreamSynchronize(plan.stream));
+    if (e2) *e2 = plan.host_pairs[0].e2;
+    if (delta) *delta = plan.host_pairs[0].delta;
+    if (stride) *stride = plan.lb_stride;
     return MM_OK;
 }
 

@@ -71,6 +71,9 @@ struct Engine {
     // counts), device accumulators [1] bounded in round 2, [2] fully screened
     int64_t bound_min_candidates = 16384;   // smaller batches skip the bound rounds (mm_engine_set_bound_min_candidates)
     int64_t bound_offered = 0, bound_round1 = 0;
+    bool bound_matrix = true;          // MM_PRECISION_F32_BOUNDED: bounds and survivors on the matrix pipe (mm_engine_set_bound_matrix)
+    int bound_matrix_qt = 1, bound_matrix_nc = 1;
+    bool bound_matrix_kept = false;    // survivors through k_screen_mx (measured slower than the packed-FMA screen: off)   // k_bound_mx's variant: query tiles per side, candidates per wave
     // candidates screened since the engine was created, by kernel: [0] direct-form f32, [1] packed FMA, [2] matrix pipe
     // (whole target set per wave), [3] matrix pipe (target set in column blocks), [4] exact f64 for every candidate
     // (mm_engine_screen_stats; atomics: levels are staged from several host threads)
@@ -132,13 +135,14 @@ struct Plan {
     bool want_costs = false;
     bool use_fast = false;                    // expanded-form screening kernel selected
     bool use_mx = false;                      // matrix-pipe screening kernel selected (MM_PRECISION_F32_MATRIX)
-    // MM_PRECISION_F32_MATRIX: the work list is grouped by screen variant, one launch per group.  kind 2 = k_screen_mx
+    // MM_PRECISION_F32_MATRIX: the work list is grouped by screen variant, one launch per group.  kind 3 = no screen (a set of fewer than 64 points: every candidate scored exactly); kind 2 = k_screen_mx
     // <nct, multi> with LDS for a_cap row tiles; kind 1 / 0 = the pairs outside its range (fewer than 64 or more than 2048
     // points, radii f16 cannot scale): packed-FMA screen / direct-form f32 screen
     struct ScreenGroup { int kind, nct, multi, a_cap, work_begin, work_count; };
     std::vector<ScreenGroup> groups;
     bool use_lb = false;                      // lower-bound pass in front of the screen (MM_PRECISION_F32_BOUNDED)
     int W_lb = 0, lb_stride = 0, lb_runs_cap = 0, max_nt = 1;
+    int lb_mx_tiles = 0, kept_nct = 0, kept_acap = 0;   // bounded search on the matrix pipe (BatchDev::lb_mx, kept_mx_*)
     double lb_pair_evals = 0.0;               // pair-distances of the first bound round
     int64_t lb_sparse_total = 0;              // candidates the first bound round scores
     std::vector<WorkItem> host_work_lb;

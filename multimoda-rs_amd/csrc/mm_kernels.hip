@@ -650,8 +650,8 @@ static __device__ __forceinline__ int wave_max_i32_dpp(int v)
 // NCT: column tiles of one block (the whole target set when !MULTI); a_cap: row tiles the launch's LDS layout provides for
 template <int NCT, bool MULTI>
 __global__ void __launch_bounds__(256, 2)
-k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work, int a_cap,
-            const float* __restrict__ ptx, const float* __restrict__ pty,
+k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work_host,
+            const int* __restrict__ n_work_dev, int a_cap, const float* __restrict__ ptx, const float* __restrict__ pty,
             const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
 {
     constexpr int NB = NCT * 32;                                      // padded columns of one block
@@ -677,6 +677,7 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
     const unsigned vRR = red_w + (rh * 16 + rv) * MM_SCREEN_MX_RED_STRIDE + hi * 64;
     const unsigned vPERM = (unsigned)((lane ^ 32) * 4);
     const unsigned vRS = lds0 + (unsigned)((size_t)s_rs - (size_t)smem) + l32 * 4;   // MULTI: both halves hold the same value
+    const int n_work = n_work_dev ? *n_work_dev : n_work_host;   // device queue: a bounded grid strides over it
 
     for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
          wi += gridDim.x) {
@@ -763,14 +764,17 @@ size_t lds_bytes_mx(int nct, bool multi, int a_cap)
     return (size_t)a_cap * 64 * 16 + (size_t)4 * nct * 64 * 8 + (size_t)4 * MX_RED * 4 + (multi ? (size_t)4 * a_cap * 32 * 4 : 0) + 64;
 }
 
+// n_dev == nullptr: one workgroup per item of the host-built list; else a device queue of at most `cap` items whose length is
+// *n_dev (a bounded grid strides over it)
 template <int NCT, bool MULTI>
-static hipError_t launch_mx_t(const BatchDev& b, const WorkItem* work, int n_work, int a_cap, hipStream_t s)
+static hipError_t launch_mx_t(const BatchDev& b, const WorkItem* work, int n_work, const int* n_dev, int cap, int a_cap, hipStream_t s)
 {
     const size_t lds = lds_bytes_mx(NCT, MULTI, a_cap);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx<NCT, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_screen_mx<NCT, MULTI>), dim3(n_work), dim3(256), lds, s, b.pairs, work, n_work, a_cap, b.p32x, b.p32y, b.cos32,
-                       b.sin32, b.sq32);
+    const int grid = n_dev ? std::min(cap, 256 * 8) : n_work;
+    hipLaunchKernelGGL((k_screen_mx<NCT, MULTI>), dim3(grid), dim3(256), lds, s, b.pairs, work, n_work, n_dev, a_cap, b.p32x, b.p32y,
+                       b.cos32, b.sin32, b.sq32);
     return hipGetLastError();
 }
 
@@ -784,12 +788,12 @@ void mx_variant(int nb, int* nct, int* multi)
 }
 
 // work[0 .. n_work) of b.work + work_begin: items of pairs that all take the variant (nct, multi); a_cap >= their row tiles
-hipError_t launch_screen_mx(const BatchDev& b, int work_begin, int n_work, int nct, int multi, int a_cap, hipStream_t s)
+static hipError_t launch_mx_any(const BatchDev& b, const WorkItem* w, int n_work, const int* n_dev, int cap, int nct, int multi, int a_cap,
+                                hipStream_t s)
 {
-    if (n_work <= 0) return hipSuccess;
     if (a_cap < 1 || a_cap > MX_ROW_TILES_MAX || lds_bytes_mx(nct, multi != 0, a_cap) > 160 * 1024) return hipErrorInvalidValue;
-    const WorkItem* w = b.work + work_begin;
-#define MM_MX(N) case N: return multi ? launch_mx_t<(N < 9 ? 9 : N), true>(b, w, n_work, a_cap, s) : launch_mx_t<N, false>(b, w, n_work, a_cap, s);
+#define MM_MX(N) case N: return multi ? launch_mx_t<(N < 9 ? 9 : N), true>(b, w, n_work, n_dev, cap, a_cap, s) \
+                                      : launch_mx_t<N, false>(b, w, n_work, n_dev, cap, a_cap, s);
     if (multi && nct < 9) return hipErrorInvalidValue;       // (several blocks: at least 18 column tiles, 9 per block)
     switch (nct) {
         MM_MX(2) MM_MX(3) MM_MX(4) MM_MX(5) MM_MX(6) MM_MX(7) MM_MX(8) MM_MX(9) MM_MX(10) MM_MX(11) MM_MX(12) MM_MX(13)
@@ -797,6 +801,12 @@ hipError_t launch_screen_mx(const BatchDev& b, int work_begin, int n_work, int n
         default: return hipErrorInvalidValue;
     }
 #undef MM_MX
+}
+
+hipError_t launch_screen_mx(const BatchDev& b, int work_begin, int n_work, int nct, int multi, int a_cap, hipStream_t s)
+{
+    if (n_work <= 0) return hipSuccess;
+    return launch_mx_any(b, b.work + work_begin, n_work, nullptr, 0, nct, multi, a_cap, s);
 }
 int mx_min_points() { return 64; }
 int mx_max_points() { return MX_ROW_TILES_MAX * 32; }
@@ -975,6 +985,270 @@ k_screen_lb(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
     }
 }
 
+// -------------------------------------------------------------------------------------
+// The same bound on the matrix pipe (BatchDev::lb_mx): the queries are the COLUMNS of one or two 32-wide column tiles
+// (QT), built in registers -- a B operand's lanes 0..31 carry a query's rotated, split coordinates, lanes 32..63 its norm
+// pieces, which do not depend on the candidate -- and the large set is the ROWS, staged once per work item in k_screen_mx's
+// A-form fragments (1 KB per 32 points) and never rotated: pass 1 takes R^-1 A' against the target, pass 2 R B' against the
+// reference, as above.  Per 32 x 32 tile one v_mfma_f32_32x32x16_f16 and 8 v_min3_i32 (only the column minima are wanted:
+// a lane's 16 values all belong to ITS query), against 2.5 vector instructions per distance pair above: a candidate's
+// 2 x 17 tiles cost ~340 issue slots instead of ~1300.  No LDS traffic per candidate except the row fragments; four
+// workgroups per CU hide the MFMA latency of each other's waves (no hand-written schedule needed here: the minima of a tile
+// are 8 instructions, the dependence is on the tile before).  Values carry k_screen_mx's error bound (the engine sets
+// PairDesc::e2 to the larger of the two directions').
+// -------------------------------------------------------------------------------------
+// min over the nt row tiles at LDS address `rows` of the squared distances to this lane's query (column lane & 31) in each of
+// the NB column fragments, both halves of the wave combined; int bit patterns (signed order: rounded values can fall a few
+// units below zero).  The pass itself is a generated asm block (tools/gen_screen_mx.py, generate_bound): written in C the
+// compiler puts the minima of a tile right behind that tile's MFMA without a wait state, and the hardware does not interlock.
+template <int NB> struct MxBound;
+template <> struct MxBound<1> {
+    static __device__ __forceinline__ void run(unsigned rows, int nt, const h8v* bq, int* out)
+    {
+        int counter;
+        asm volatile(MM_BOUND_MX_ASM_1 : "=&v"(out[0]), "=&s"(counter) : "v"(rows), "s"(nt - 1), "v"(bq[0]) : MM_BOUND_MX_CLOBBERS_1);
+    }
+};
+template <> struct MxBound<2> {
+    static __device__ __forceinline__ void run(unsigned rows, int nt, const h8v* bq, int* out)
+    {
+        int counter;
+        asm volatile(MM_BOUND_MX_ASM_2 : "=&v"(out[0]), "=&v"(out[1]), "=&s"(counter) : "v"(rows), "s"(nt - 1), "v"(bq[0]), "v"(bq[1])
+                     : MM_BOUND_MX_CLOBBERS_2);
+    }
+};
+template <> struct MxBound<4> {
+    static __device__ __forceinline__ void run(unsigned rows, int nt, const h8v* bq, int* out)
+    {
+        int counter;
+        asm volatile(MM_BOUND_MX_ASM_4 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&s"(counter)
+                     : "v"(rows), "s"(nt - 1), "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]) : MM_BOUND_MX_CLOBBERS_4);
+    }
+};
+template <int NB>
+static __device__ __forceinline__ void mx_bound_pass(unsigned rows, int nt, const h8v (&bq)[NB], int (&out)[NB])
+{
+    MxBound<NB>::run(rows, nt, bq, out);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int o = __shfl_xor(out[j], 32, 64);      // lanes l and l + 32: different rows of the same column
+        out[j] = o < out[j] ? o : out[j];
+    }
+}
+
+static __device__ __forceinline__ h8v mx_query_fragment(float X, float Y, h4v norm, int hi)
+{
+    const h4v c = mx_col_coords(X, Y);
+    const h4v h = hi ? norm : c;
+    return h8v{h.x, h.y, h.z, h.w, h.x, h.y, h.z, h.w};
+}
+
+// QT: column tiles of queries per side (32 QT queries); NC: candidates a wave scores at once (every row fragment read from
+// LDS feeds QT x NC MFMAs); LIST: the queries are qlist[pair * 2 nq_list + (0 .. nq_list - 1 reference, nq_list .. target)]
+// and the result is merged into out_lb by maximum.  a_cap: row tiles per set the launch's LDS layout provides for.
+template <int QT, int NC, bool LIST>
+__global__ void __launch_bounds__(256, (QT * NC >= 4 ? 2 : 3))
+k_bound_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work_host,
+           const int* __restrict__ n_work_dev, int stride, const int32_t* __restrict__ qlist, int nq_list, int a_cap,
+           const float* __restrict__ ptx, const float* __restrict__ pty,
+           const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_lb)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    h8v* s_r = reinterpret_cast<h8v*>(smem);          // [a_cap][64] reference points as row fragments
+    h8v* s_t = s_r + a_cap * 64;                      // [a_cap][64] target points as row fragments (as staged, never rotated)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
+    const int n_work = n_work_dev ? *n_work_dev : n_work_host;
+    // LDS byte addresses of this lane's fragment in row tile 0 of either set (a generic pointer's low 32 bits are its LDS offset)
+    const unsigned vR = (unsigned)(size_t)smem + lane * 16, vT = vR + (unsigned)a_cap * 1024u;
+
+    for (int wi = (int)gridDim.x == n_work ? xcd_work_index(blockIdx.x, n_work) : (int)blockIdx.x; wi < n_work;
+         wi += gridDim.x) {
+        const WorkItem w = work[wi];
+        const PairDesc pd = pairs[w.pair];
+        const int na = pd.n_ref, nb = pd.n_tgt;
+        const int nrt = (na + 31) >> 5, ntt = (nb + 31) >> 5;
+        const float S = __builtin_ldexpf(1.0f, pd.pad0), inv_s2 = __builtin_ldexpf(1.0f, -2 * pd.pad0);
+        const int qa = LIST ? nq_list : (na + stride - 1) / stride;      // <= 32 QT (host)
+        const int qb = LIST ? nq_list : (nb + stride - 1) / stride;
+        const int32_t* ql = LIST ? qlist + (size_t)w.pair * (2 * nq_list) : nullptr;
+
+        __syncthreads();   // the previous item's readers are done
+        for (int slot = tid; slot < nrt * 64; slot += 256) {
+            const int row = (slot >> 6) * 32 + (slot & 31), rc = row < na ? row : na - 1;   // padding rows duplicate the last point
+            s_r[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], (slot & 63) >> 5);
+        }
+        for (int slot = tid; slot < ntt * 64; slot += 256) {
+            const int row = (slot >> 6) * 32 + (slot & 31), rc = row < nb ? row : nb - 1;
+            s_t[slot] = mx_fragment<true>(S * ptx[pd.tgt_off + rc], S * pty[pd.tgt_off + rc], (slot & 63) >> 5);
+        }
+        // this lane's queries, unrotated and scaled, and their norm pieces (candidate-independent); columns past the subset
+        // repeat its last query (no effect on the maximum over the subset)
+        float ax[QT], ay[QT], bx[QT], by[QT];
+        h4v an[QT], bn[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int col = t * 32 + l32;
+            const int ia = LIST ? ql[col < qa ? col : qa - 1] : (col < qa ? col : qa - 1) * stride;
+            const int ib = LIST ? ql[nq_list + (col < qb ? col : qb - 1)] : (col < qb ? col : qb - 1) * stride;
+            ax[t] = S * ptx[pd.ref_off + ia]; ay[t] = S * pty[pd.ref_off + ia];
+            bx[t] = S * ptx[pd.tgt_off + ib]; by[t] = S * pty[pd.tgt_off + ib];
+            an[t] = mx_col_norm(ax[t], ay[t]); bn[t] = mx_col_norm(bx[t], by[t]);
+        }
+        const int step = w.pad > 0 ? w.pad : 1;
+        float tab_c = 1.0f, tab_s = 0.0f;
+        if (wave + 4 * lane < w.cnt) {
+            const int al = min(w.a0 + (wave + 4 * lane) * step, pd.n_ang - 1);
+            tab_c = cosv[pd.tab_off + al];
+            tab_s = sinv[pd.tab_off + al];
+        }
+        __syncthreads();
+
+        for (int i = 0, k = wave; k < w.cnt; i += NC, k += 4 * NC) {
+            // this wave's candidates k, k + 4, ... (NC of them; past the item's end the last one is scored again, not stored)
+            float c[NC], sn[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int ij = (k + 4 * j < w.cnt) ? i + j : i;
+                c[j] = __shfl(tab_c, ij, 64); sn[j] = __shfl(tab_s, ij, 64);
+            }
+            h8v bq[QT * NC];
+            int m1[QT * NC], m2[QT * NC];
+            // pass 1: R^-1 A' against the target as staged.  x' = x c + y s, y' = y c - x s
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    bq[j * QT + t] = mx_query_fragment(__builtin_fmaf(ax[t], c[j], ay[t] * sn[j]), __builtin_fmaf(ay[t], c[j], -(ax[t] * sn[j])), an[t], hi);
+            mx_bound_pass<QT * NC>(vT, ntt, bq, m1);
+            // pass 2: R B' (the full screen's rotation) against the reference
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    bq[j * QT + t] = mx_query_fragment(__builtin_fmaf(bx[t], c[j], -(by[t] * sn[j])), __builtin_fmaf(bx[t], sn[j], by[t] * c[j]), bn[t], hi);
+            mx_bound_pass<QT * NC>(vR, nrt, bq, m2);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                int m = 0;
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    m = m1[j * QT + t] > m ? m1[j * QT + t] : m;
+                    m = m2[j * QT + t] > m ? m2[j * QT + t] : m;
+                }
+                m = wave_max_i32_dpp(m);
+                if (lane == 0 && k + 4 * j < w.cnt) {
+                    const int a = min(w.a0 + (k + 4 * j) * step, pd.n_ang - 1);
+                    float v = __int_as_float(m) * inv_s2;
+                    if (LIST) { const float o = out_lb[pd.out_off + a]; v = o > v ? o : v; }   // +inf (ruled out) stays
+                    out_lb[pd.out_off + a] = v;
+                }
+            }
+        }
+    }
+}
+
+// The later rounds bound the candidates the rounds before could not rule out: a few per cent of a pair's list, scattered.
+// As queue items (runs inside aligned groups of 8) every run of one to seven candidates staged both sets again -- 34 KB of
+// row fragments for a few hundred MFMAs.  Here a workgroup takes one pair (one `split`-th of its candidate list), collects
+// the flagged candidates (flags[], written by k_lb_spread / k_lb_keep) with their cos / sin into an LDS list, stages the sets
+// ONCE -- and not at all where nothing is flagged -- and its four waves work the list off.
+static constexpr int kScanChunk = 1024;      // candidates collected per pass over the list (LDS: 12 KB)
+
+template <int QT, bool LIST>
+__global__ void __launch_bounds__(256, 3)
+k_bound_mx_scan(const PairDesc* __restrict__ pairs, int n_pairs, int split, const uint8_t* __restrict__ flags, int stride,
+                const int32_t* __restrict__ qlist, int nq_list, int a_cap, const float* __restrict__ ptx,
+                const float* __restrict__ pty, const float* __restrict__ cosv, const float* __restrict__ sinv,
+                float* __restrict__ out_lb, unsigned long long* __restrict__ stats, int stat_slot)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    h8v* s_r = reinterpret_cast<h8v*>(smem);
+    h8v* s_t = s_r + a_cap * 64;
+    int* s_list = reinterpret_cast<int*>(s_t + a_cap * 64);          // [kScanChunk] candidate indices
+    float* s_c = reinterpret_cast<float*>(s_list + kScanChunk);        // their cos
+    float* s_s = s_c + kScanChunk;                                     // and sin
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
+    const unsigned vR = (unsigned)(size_t)smem + lane * 16, vT = vR + (unsigned)a_cap * 1024u;
+
+    for (int wi = blockIdx.x; wi < n_pairs * split; wi += gridDim.x) {
+        const int p = wi / split, part = wi - p * split;
+        const PairDesc pd = pairs[p];
+        if (pd.n_ang <= 0) continue;
+        const int lo = (int)((long long)pd.n_ang * part / split), hi_a = (int)((long long)pd.n_ang * (part + 1) / split);
+        const int na = pd.n_ref, nb = pd.n_tgt;
+        const int nrt = (na + 31) >> 5, ntt = (nb + 31) >> 5;
+        const float S = __builtin_ldexpf(1.0f, pd.pad0), inv_s2 = __builtin_ldexpf(1.0f, -2 * pd.pad0);
+        bool staged = false;
+        float ax[QT], ay[QT], bx[QT], by[QT];
+        h4v an[QT], bn[QT];
+        for (int base = lo; base < hi_a; base += kScanChunk) {
+            __syncthreads();       // the list's readers of the chunk (or pair) before are done
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            for (int a = base + tid; a < min(base + kScanChunk, hi_a); a += 256)
+                if (flags[pd.out_off + a]) {
+                    const int k = atomicAdd(&s_cnt, 1);
+                    s_list[k] = a; s_c[k] = cosv[pd.tab_off + a]; s_s[k] = sinv[pd.tab_off + a];
+                }
+            __syncthreads();
+            const int n = s_cnt;
+            if (n == 0) continue;
+            if (stats && tid == 0) atomicAdd(&stats[stat_slot], (unsigned long long)n);
+            if (!staged) {
+                staged = true;
+                for (int slot = tid; slot < nrt * 64; slot += 256) {
+                    const int row = (slot >> 6) * 32 + (slot & 31), rc = row < na ? row : na - 1;
+                    s_r[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], (slot & 63) >> 5);
+                }
+                for (int slot = tid; slot < ntt * 64; slot += 256) {
+                    const int row = (slot >> 6) * 32 + (slot & 31), rc = row < nb ? row : nb - 1;
+                    s_t[slot] = mx_fragment<true>(S * ptx[pd.tgt_off + rc], S * pty[pd.tgt_off + rc], (slot & 63) >> 5);
+                }
+                const int qa = LIST ? nq_list : (na + stride - 1) / stride;
+                const int qb = LIST ? nq_list : (nb + stride - 1) / stride;
+                const int32_t* ql = LIST ? qlist + (size_t)p * (2 * nq_list) : nullptr;
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const int col = t * 32 + l32;
+                    const int ia = LIST ? ql[col < qa ? col : qa - 1] : (col < qa ? col : qa - 1) * stride;
+                    const int ib = LIST ? ql[nq_list + (col < qb ? col : qb - 1)] : (col < qb ? col : qb - 1) * stride;
+                    ax[t] = S * ptx[pd.ref_off + ia]; ay[t] = S * pty[pd.ref_off + ia];
+                    bx[t] = S * ptx[pd.tgt_off + ib]; by[t] = S * pty[pd.tgt_off + ib];
+                    an[t] = mx_col_norm(ax[t], ay[t]); bn[t] = mx_col_norm(bx[t], by[t]);
+                }
+                __syncthreads();
+            }
+            for (int k = wave; k < n; k += 4) {
+                const int a = s_list[k];
+                const float c = s_c[k], sn = s_s[k];
+                h8v bq[QT];
+                int m1[QT], m2[QT];
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    bq[t] = mx_query_fragment(__builtin_fmaf(ax[t], c, ay[t] * sn), __builtin_fmaf(ay[t], c, -(ax[t] * sn)), an[t], hi);
+                mx_bound_pass<QT>(vT, ntt, bq, m1);
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    bq[t] = mx_query_fragment(__builtin_fmaf(bx[t], c, -(by[t] * sn)), __builtin_fmaf(bx[t], sn, by[t] * c), bn[t], hi);
+                mx_bound_pass<QT>(vR, nrt, bq, m2);
+                int m = 0;
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    m = m1[t] > m ? m1[t] : m;
+                    m = m2[t] > m ? m2[t] : m;
+                }
+                m = wave_max_i32_dpp(m);
+                if (lane == 0) {
+                    float v = __int_as_float(m) * inv_s2;
+                    if (LIST) { const float o = out_lb[pd.out_off + a]; v = o > v ? o : v; }   // +inf (ruled out) stays
+                    out_lb[pd.out_off + a] = v;
+                }
+            }
+        }
+    }
+}
+
 static constexpr int kLbCandStep = 8;   // first round: every 8th candidate (and the last) gets a bound
 
 // number of candidates the sparse first round scores for a list of n: 0, 8, 16, ... and n - 1
@@ -1019,7 +1293,8 @@ k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, in
 __global__ void __launch_bounds__(256)
 k_lb_spread(const PairDesc* __restrict__ pairs, float* __restrict__ lb32, const float* __restrict__ sq32,
             const int32_t* __restrict__ pick_idx, const double* __restrict__ cos64, const double* __restrict__ sin64,
-            WorkItem* __restrict__ items, int* __restrict__ n_items, unsigned long long* __restrict__ stats)
+            WorkItem* __restrict__ items, int* __restrict__ n_items, unsigned long long* __restrict__ stats,
+            uint8_t* __restrict__ flags)
 {
     const int p = blockIdx.x, tid = threadIdx.x;
     const PairDesc pd = pairs[p];
@@ -1040,10 +1315,10 @@ k_lb_spread(const PairDesc* __restrict__ pairs, float* __restrict__ lb32, const 
             // 4e-8: the cancellation floor of 2 - 2 cos D in f64 (sqrt of two ulps of 2)
             const double chL = pd.rho_t * (sqrt(dL > 0.0 ? dL : 0.0) + 4e-8), chR = pd.rho_t * (sqrt(dR > 0.0 ? dR : 0.0) + 4e-8);
             const double inherited = fmax(hL - chL, hR - chR);
-            if (inherited <= ub) { if (first < 0) first = a; lastp = a; }
+            if (inherited <= ub) { if (first < 0) first = a; lastp = a; if (flags) flags[pd.out_off + a] = 1; }
             else lb32[pd.out_off + a] = __int_as_float(0x7f800000);
         }
-        if (first >= 0) {
+        if (first >= 0 && !flags) {      // (flags: k_bound_mx_scan collects the candidates itself)
             const int slot = atomicAdd(n_items, 1);
             WorkItem w; w.pair = p; w.a0 = first; w.cnt = lastp - first + 1; w.pad = 1;
             items[slot] = w;
@@ -1063,7 +1338,7 @@ template <bool FINAL>
 __global__ void __launch_bounds__(256)
 k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, float* __restrict__ sq32,
           const int32_t* __restrict__ pick_idx, const int32_t* __restrict__ pick2, WorkItem* __restrict__ items,
-          int* __restrict__ n_items, unsigned long long* __restrict__ stats)
+          int* __restrict__ n_items, unsigned long long* __restrict__ stats, uint8_t* __restrict__ flags)
 {
     const int p = blockIdx.x, tid = threadIdx.x;
     const PairDesc pd = pairs[p];
@@ -1077,8 +1352,11 @@ k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, fl
         int first = -1, last = -1;
         for (int a = lo; a < hi; ++a) {
             const double sv = (double)lb32[pd.out_off + a] - pd.e2;
-            if (a == c1 || a == c2 || sqrt(sv > 0.0 ? sv : 0.0) <= ub) { if (first < 0) first = a; last = a; }
+            const bool stays = a == c1 || a == c2 || sqrt(sv > 0.0 ? sv : 0.0) <= ub;
+            if (stays) { if (first < 0) first = a; last = a; }
+            if (!FINAL && flags) flags[pd.out_off + a] = stays ? 1 : 0;     // every candidate of the pair: no stale flag survives
         }
+        if (!FINAL && flags) continue;   // (k_bound_mx_scan collects the flagged candidates itself and counts them)
         if (FINAL)
             for (int a = lo; a < hi; ++a)
                 if (a < first || a > last) sq32[pd.out_off + a] = __int_as_float(0x7f800000);
@@ -1504,10 +1782,38 @@ int lb_max_query_points() { return 8 * kLbRP; }
 int lb_max_points() { return 4096; }
 size_t lds_bytes_lb(int nap, int nbp) { return ((size_t)nap + (size_t)nbp) * 16; }
 
+int lb_mx_max_points() { return 1024; }     // 32 row tiles per set: 64 KB of row fragments
+
+// b.lb_mx_qt column tiles of queries per side (32 queries each), b.lb_mx_nc candidates per wave at once
+template <int QT, int NC, bool LIST>
+static hipError_t launch_lb_mx_v(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap, hipStream_t s)
+{
+    auto kern = k_bound_mx<QT, NC, LIST>;
+    const size_t lds = (size_t)2 * b.lb_mx * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int grid = n_dev ? std::min(cap, 256 * 16) : n_host;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, work, n_host, n_dev, b.lb_stride, b.qlist, kLbListQ, b.lb_mx,
+                       b.p32x, b.p32y, b.cos32, b.sin32, b.lb32);
+    return hipGetLastError();
+}
+
+template <bool LIST>
+static hipError_t launch_lb_mx_t(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap, hipStream_t s)
+{
+    const int v = b.lb_mx_qt * 10 + b.lb_mx_nc;
+    if (v == 11) return launch_lb_mx_v<1, 1, LIST>(b, work, n_host, n_dev, cap, s);
+    if (v == 12) return launch_lb_mx_v<1, 2, LIST>(b, work, n_host, n_dev, cap, s);
+    if (v == 21) return launch_lb_mx_v<2, 1, LIST>(b, work, n_host, n_dev, cap, s);
+    if (v == 22) return launch_lb_mx_v<2, 2, LIST>(b, work, n_host, n_dev, cap, s);
+    return hipErrorInvalidValue;
+}
+
 template <int RP, bool LIST>
 static hipError_t launch_lb_t(const BatchDev& b, const WorkItem* work, int n_host, const int* n_dev, int cap,
                               int max_nap, int max_nbp, hipStream_t s)
 {
+    if (b.lb_mx > 0) return launch_lb_mx_t<LIST>(b, work, n_host, n_dev, cap, s);
     auto kern = k_screen_lb<RP, LIST>;
     const size_t lds = lds_bytes_lb(max_nap, max_nbp);
     if (lds > 48 * 1024) {
@@ -1532,10 +1838,27 @@ hipError_t launch_screen_lb(const BatchDev& b, int max_nap, int max_nbp, hipStre
     return launch_lb_t<kLbRP, false>(b, b.work_lb, b.n_work_lb, nullptr, 0, max_nap, max_nbp, s);
 }
 
-// round 2: the candidates k_lb_spread could not rule out (queue 0, counter [2])
+template <bool LIST>
+static hipError_t launch_lb_mx_scan(const BatchDev& b, int stat_slot, hipStream_t s)
+{
+    const size_t lds = (size_t)2 * b.lb_mx * 1024 + (size_t)kScanChunk * 12;
+    // two workgroups per pair (halves of its candidate list): 4 000 workgroups for config3, and a pair's staging twice at most
+    const int split = 2, grid = std::min(b.n_pairs * split, 256 * 24);
+#define MM_SCAN(QT) { auto kern = k_bound_mx_scan<QT, LIST>; \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e; \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b.pairs, b.n_pairs, split, b.flag, b.lb_stride, b.qlist, kLbListQ, b.lb_mx, \
+                           b.p32x, b.p32y, b.cos32, b.sin32, b.lb32, b.stats, stat_slot); }
+    if (b.lb_mx_qt == 2) MM_SCAN(2) else MM_SCAN(1)
+#undef MM_SCAN
+    return hipGetLastError();
+}
+
+// round 2: the candidates k_lb_spread could not rule out (queue 0, counter [2]; matrix pipe: the flagged ones)
 hipError_t launch_screen_lb_queued(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s)
 {
     if (cap <= 0) return hipSuccess;
+    if (b.lb_mx > 0) return launch_lb_mx_scan<false>(b, 1, s);
     return launch_lb_t<kLbRP, false>(b, b.items_lb, 0, b.n_items + 2, cap, max_nap, max_nbp, s);
 }
 
@@ -1543,6 +1866,7 @@ hipError_t launch_screen_lb_queued(const BatchDev& b, int max_nap, int max_nbp, 
 hipError_t launch_screen_lb_list(const BatchDev& b, int max_nap, int max_nbp, int cap, hipStream_t s)
 {
     if (cap <= 0) return hipSuccess;
+    if (b.lb_mx > 0) return launch_lb_mx_scan<true>(b, 3, s);
     return launch_lb_t<kLbListRP, true>(b, b.items_lb + cap, 0, b.n_items + 3, cap, max_nap, max_nbp, s);
 }
 
@@ -1562,8 +1886,39 @@ hipError_t launch_lb_pick(const BatchDev& b, int round, hipStream_t s)
 hipError_t launch_screen_picks(const BatchDev& b, int round, int max_na, int max_nbp, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
+    if (b.kept_mx_nct > 0) {
+        // bounded search on the matrix pipe: the pick's VALUE (the pair's upper bound) comes from k_screen_mx.  The
+        // packed-FMA screen still runs for the first pick, but only for what it EMITS -- the row / column minima from which
+        // k_lb_topk chooses the third round's queries, a heuristic: whatever it leaves there, the bounds stay valid -- and
+        // k_screen_mx then overwrites its value.  (Why: profiles/README.md, "packed-FMA kernels beside MFMA kernels".)
+        if (round == 0) {
+            hipError_t e = launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, true, s);
+            if (e != hipSuccess) return e;
+            return launch_mx_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, b.kept_mx_nct, 0, b.kept_mx_acap, s);
+        }
+        return launch_mx_any(b, b.items_pick + b.n_pairs, 0, b.n_items + 4, b.n_pairs, b.kept_mx_nct, 0, b.kept_mx_acap, s);
+    }
     if (round == 0) return launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, true, s);
     return launch_fast_any(b, b.items_pick + b.n_pairs, 0, b.n_items + 4, b.n_pairs, max_na, max_nbp, false, s);
+}
+
+// MM_PRECISION_F32_MATRIX, pairs with a set of fewer than 64 points: no screen at all -- every candidate gets the screened
+// value 0, so that the shortlist keeps all of them and the exact f64 kernel scores them (tiny sets: cheap)
+__global__ void __launch_bounds__(256) k_screen_none(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work,
+                                                      float* __restrict__ out_sq)
+{
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const WorkItem w = work[wi];
+        const PairDesc pd = pairs[w.pair];
+        for (int k = threadIdx.x; k < w.cnt; k += 256) out_sq[pd.out_off + w.a0 + k] = 0.0f;
+    }
+}
+
+hipError_t launch_screen_none(const BatchDev& b, int work_begin, int n_work, hipStream_t s)
+{
+    if (n_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_screen_none, dim3(std::min(n_work, 4096)), dim3(256), 0, s, b.pairs, b.work + work_begin, n_work, b.sq32);
+    return hipGetLastError();
 }
 
 hipError_t launch_lb_topk(const BatchDev& b, int max_n, hipStream_t s)
@@ -1577,8 +1932,13 @@ hipError_t launch_lb_topk(const BatchDev& b, int max_n, hipStream_t s)
 hipError_t launch_lb_spread(const BatchDev& b, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
+    uint8_t* flags = b.lb_mx > 0 ? b.flag : nullptr;
+    if (flags) {       // the candidates that need a bound of their own are flagged (k_bound_mx_scan), not queued
+        hipError_t e = hipMemsetAsync(flags, 0, (size_t)b.n_cand, s);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_lb_spread, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx, b.cos64,
-                       b.sin64, b.items_lb, b.n_items + 2, b.stats);
+                       b.sin64, b.items_lb, b.n_items + 2, b.stats, flags);
     return hipGetLastError();
 }
 
@@ -1588,16 +1948,20 @@ hipError_t launch_lb_keep(const BatchDev& b, int final, int cap, hipStream_t s)
     if (b.n_pairs <= 0) return hipSuccess;
     if (!final)
         hipLaunchKernelGGL(k_lb_keep<false>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx,
-                           (const int32_t*)nullptr, b.items_lb + cap, b.n_items + 3, b.stats);
+                           (const int32_t*)nullptr, b.items_lb + cap, b.n_items + 3, b.stats, b.lb_mx > 0 ? b.flag : (uint8_t*)nullptr);
     else
         hipLaunchKernelGGL(k_lb_keep<true>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx,
-                           (const int32_t*)(b.pick_idx + b.n_pairs), b.items_lb + 2 * (size_t)cap, b.n_items + 5, b.stats);
+                           (const int32_t*)(b.pick_idx + b.n_pairs), b.items_lb + 2 * (size_t)cap, b.n_items + 5, b.stats,
+                           (uint8_t*)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s)
 {
     if (cap <= 0) return hipSuccess;
+    // every pair of the batch takes the same variant of the matrix-pipe screen: the survivors go through it (runs of <= 8
+    // candidates from the device queue, one wave per candidate)
+    if (b.kept_mx_nct > 0) return launch_mx_any(b, b.items_lb + 2 * (size_t)cap, 0, b.n_items + 5, cap, b.kept_mx_nct, 0, b.kept_mx_acap, s);
     return launch_fast_any(b, b.items_lb + 2 * (size_t)cap, 0, b.n_items + 5, cap, max_na, max_nbp, false, s);
 }
 

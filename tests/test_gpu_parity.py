@@ -854,9 +854,9 @@ def test_matrix_screen_with_the_target_set_in_column_blocks(engine, oracle, mm, 
 
 
 def test_matrix_screen_chooses_per_pair(engine, oracle, mm):
-    """One batch, pairs of seven shapes: each goes to its own variant of the matrix kernel; only the pairs with a set of fewer
-    than 64 (or more than 2048) points take the packed-FMA screen -- and no pair sends the others there (VERDICT r3 #2:
-    `use_mx = false; break`).  Winners and costs are the oracle's."""
+    """One batch, pairs of seven shapes: each goes to its own variant of the matrix kernel; a pair with a set of fewer than 64
+    points is not screened at all (every candidate scored exactly), one with more than 2048 takes the direct-form screen --
+    and no pair sends the others anywhere (VERDICT r3 #2: `use_mx = false; break`).  Winners and costs are the oracle's."""
     rng = np.random.default_rng(5)
     angles, _, _ = mm.search_angles(2.0, 90.0)
     shapes = [(200, 200), (448, 521), (600, 521), (521, 30), (521, 600), (63, 64), (521, 521), (240, 216), (2049, 300), (200, 200)]
@@ -869,19 +869,18 @@ def test_matrix_screen_chooses_per_pair(engine, oracle, mm):
     after = engine.screen_stats()
     took = {k: after[k] - before[k] for k in after}
     n = len(angles)
-    # (a batch with a reference set beyond the packed-FMA kernel's registers sends its small pairs to the direct form)
-    assert took == {"direct_f32": 3 * n, "packed_fma": 0, "matrix": 6 * n, "matrix_blocks": n, "exact_f64": 0}, took
+    assert took == {"direct_f32": n, "packed_fma": 0, "matrix": 6 * n, "matrix_blocks": n, "exact_f64": 2 * n}, took
     for p in range(len(shapes)):
         oc = oracle.costs_over_angles(refs[p], tgts[p], angles, float(cs[p][0]), float(cs[p][1]))
         assert out["best_idx"][p] == int(np.argmin(oc)) and out["best_cost"][p] == oc[out["best_idx"][p]]
-    # without the reference sets beyond 528 points the small pairs take the packed-FMA screen
+    # the same without the 2049-point set: no packed-FMA or direct-form launch at all
     keep = [0, 1, 3, 4, 5, 6, 7]
     before = engine.screen_stats()
     engine.best_rotation_batch(mm.Batch([refs[i] for i in keep], [tgts[i] for i in keep], [angles] * len(keep),
                                         [(float(cs[i][0]), float(cs[i][1])) for i in keep]), precision=mm.MM_PRECISION_F32_MATRIX)
     after = engine.screen_stats()
     took = {k: after[k] - before[k] for k in after}
-    assert took == {"direct_f32": 0, "packed_fma": 2 * n, "matrix": 4 * n, "matrix_blocks": n, "exact_f64": 0}, took
+    assert took == {"direct_f32": 0, "packed_fma": 0, "matrix": 4 * n, "matrix_blocks": n, "exact_f64": 2 * n}, took
 
 
 def test_matrix_screen_small_batches_fill_the_workgroup(engine, oracle, mm):

@@ -203,6 +203,13 @@ class Pipe:
             s.ins(f"v_min_i32 v{ACC}, v{ACC}, v{T}", reads=[ACC, T], writes=[ACC], valu=True)
             s.ins(f"v_max_i32 v{ROWMAX}, v{ROWMAX}, v{ACC}", reads=[ROWMAX, ACC], writes=[ROWMAX], valu=True)
 
+    def meet_halves(self):
+        """lanes l and l + 32 hold the minima of the two halves of a row: afterwards ACC holds the lower half's value in both
+        halves and T the upper half's (red_final takes their minimum).  v_permlane32_swap, not ds_bpermute_b32."""
+        s = self.s
+        s.ins(f"v_mov_b32 v{T}, v{ACC}", reads=[ACC], writes=[T], valu=True)
+        s.ins(f"v_permlane32_swap_b32 v{ACC}, v{T}", reads=[ACC, T], writes=[ACC, T], permlane=True)
+
     def red_prefetch(self, off):
         if self.carry:
             self.s.ins(f"ds_read_b32 v{TP}, v{RSADDR} offset:{off}", reads=[RSADDR], writes=[TP], lds_load=True)
@@ -235,7 +242,7 @@ class Pipe:
                 return f
 
             def bperm():
-                s.ins(f"ds_bpermute_b32 v{T}, %6, v{ACC}", reads=[ACC], writes=[T], lds_load=True)
+                self.meet_halves()
                 self.red_prefetch(off)
             return [(False, write), (False, read(0)), (True, fold(0, read(1))), (True, fold(1, read(2))), (True, fold(2, read(3))),
                     (True, fold(3, bperm)), (True, lambda: self.red_final(off))]
@@ -252,7 +259,7 @@ class Pipe:
             s.ins(f"v_min3_i32 v{t}, v{t}, v{t + 3}, v{t + 6}", reads=[t, t + 3, t + 6], writes=[t], valu=True)
             s.ins(f"v_min3_i32 v{t + 9}, v{t + 9}, v{t + 12}, v{t + 15}", reads=[t + 9, t + 12, t + 15], writes=[t + 9], valu=True)
             s.ins(f"v_min_i32 v{ACC}, v{t}, v{t + 9}", reads=[t, t + 9], writes=[ACC], valu=True)
-            s.ins(f"ds_bpermute_b32 v{T}, %6, v{ACC}", reads=[ACC], writes=[T], lds_load=True)
+            self.meet_halves()
             self.red_prefetch(off)
         return [(False, write), (False, read_all), (True, fold_all), (True, lambda: self.red_final(off))]
 
@@ -291,7 +298,7 @@ class Pipe:
         s.ins(f"v_min3_i32 v{u}, v{u}, v{u + 1}, v{u + 2}", reads=rng(u, 3), writes=[u], valu=True)
         s.ins(f"v_min3_i32 v{u + 3}, v{u + 3}, v{u + 4}, v{t + 15}", reads=[u + 3, u + 4, t + 15], writes=[u + 3], valu=True)
         s.ins(f"v_min_i32 v{ACC}, v{u}, v{u + 3}", reads=[u, u + 3], writes=[ACC], valu=True)
-        s.ins(f"ds_bpermute_b32 v{T}, %6, v{ACC}", reads=[ACC], writes=[T], lds_load=True)
+        self.meet_halves()
         s.wait()
         self.red_final(off)
 
@@ -492,6 +499,114 @@ def generate(nct, carry):
     return s.out, sorted(s.used)
 
 
+def generate_bound(nb):
+    """The bound kernel's pass (k_bound_mx, mm_kernels.hip): `nb` column tiles of queries held in registers (operands
+    %4 .., the B fragments: query tiles of one candidate and / or of several candidates) against the row tiles of a set in
+    LDS.  Per row tile ONE ds_read_b128 of the row fragment feeds nb MFMAs -- at one MFMA per read the kernel is bound by LDS
+    bandwidth (1 KB per wave and tile = 128 B / clk / CU at the matrix pipe's rate) -- and every MFMA result is folded by 8
+    v_min3_i32 into two running column minima (two chains; a lane's 16 values all belong to its query).  Two sets of result
+    buffers: the MFMAs of the next row tile are issued ahead of the minima of the tile before; the distance between an MFMA
+    and the first read of its result is padded where the instructions in between are not enough.  The compiler cannot be
+    trusted with this: it places the minima of a tile right behind that tile's MFMA without a wait state (inline asm
+    operands are invisible to its MFMA hazard recogniser), and the hardware does not interlock -- the minima then fold stale
+    registers.
+    Operands: %0 .. %(nb-1) out: min over all row tiles of this lane's column (its half of the rows), per B fragment;
+    %nb =s counter; then LDS byte address of this lane's fragment in row tile 0 (the next ones 1024 bytes apart); s: row
+    tiles - 1; the nb B fragments (4 VGPRs each)."""
+    s = Stream()
+    o_cnt, o_addr, o_nt, o_b = nb, nb + 1, nb + 2, nb + 3
+    A, ADDR = ASET, AADDR
+    D = [[P + 16 * (2 * j), P + 16 * (2 * j + 1)] for j in range(nb)]        # D[j][k]: result buffer k of fragment j
+    C = [[CM + 2 * j, CM + 2 * j + 1] for j in range(nb)]
+
+    def mfmas(k):
+        for j in range(nb):
+            d = D[j][k]
+            s.ins(f"v_mfma_f32_32x32x16_f16 v[{d}:{d + 15}], v[{A[k]}:{A[k] + 3}], %{o_b + j}, 0", reads=rng(A[k], 4), writes=rng(d, 16), mfma=True)
+
+    def folds(k):
+        for q in range(8):              # interleaved over the fragments: no instruction depends on the one before
+            for j in range(nb):
+                c, d = C[j][q & 1], D[j][k]
+                s.ins(f"v_min3_i32 v{c}, v{c}, v{d + 2 * q}, v{d + 2 * q + 1}", reads=[c, d + 2 * q, d + 2 * q + 1], writes=[c], valu=True)
+
+    def load(k, off):
+        s.ins(f"ds_read_b128 v[{A[k]}:{A[k] + 3}], v{ADDR} offset:{off}", reads=[ADDR], writes=rng(A[k], 4), lds_load=True)
+
+    def state():
+        return copy.deepcopy((s.n, s.mfma_at, s.valu_at, s.loading))
+
+    def set_state(x):
+        s.n, s.mfma_at, s.valu_at, s.loading = copy.deepcopy(x)
+
+    s.ins(f"v_mov_b32 v{ADDR}, %{o_addr}", writes=[ADDR], valu=True)
+    load(0, 0)
+    for j in range(nb):
+        for c in C[j]:
+            s.ins(f"v_mov_b32 v{c}, {INF}", writes=[c], valu=True)
+    s.raw(f"s_mov_b32 %{o_cnt}, %{o_nt}")
+    s.wait()
+    mfmas(0)
+    s.raw(f"s_cmp_lt_u32 %{o_cnt}, 2")
+    s.raw("s_cbranch_scc1 2f")
+    entry = state()
+    s.label("1:")
+    bodies = []
+    for it in range(2):
+        m0 = s.mark()
+        load(1, 1024)
+        load(0, 2048)
+        s.wait()
+        mfmas(1)
+        folds(0)
+        mfmas(0)
+        folds(1)
+        s.ins(f"v_add_u32 v{ADDR}, 2048, v{ADDR}", reads=[ADDR], writes=[ADDR], valu=True)
+        s.raw(f"s_sub_u32 %{o_cnt}, %{o_cnt}, 2")
+        s.raw(f"s_cmp_gt_u32 %{o_cnt}, 1")
+        s.raw("s_cbranch_scc1 1b")
+        bodies.append(s.out[m0:])
+        if it == 0:
+            keep = s.mark()
+            after = state()
+    # the first iteration comes right behind the prologue's MFMAs and needs the longer padding; the steady state is safe
+    # with it too (more wait states never hurt) -- tests/test_screen_mx_asm.py executes the text for every trip count
+    strip = lambda b: [x for x in b if not x.startswith("s_nop")]
+    assert len(bodies[0]) >= len(bodies[1]) and strip(bodies[0]) == strip(bodies[1])
+    del s.out[keep:]
+    s.label("2:")
+
+    def tail(st):
+        set_state(st)
+        m0 = s.mark()
+        s.raw(f"s_cmp_eq_u32 %{o_cnt}, 0")
+        s.raw("s_cbranch_scc1 3f")
+        at = state()
+        load(1, 1024)                       # one row tile left
+        s.wait()
+        mfmas(1)
+        folds(0)
+        folds(1)
+        s.raw("s_branch 4f")
+        s.label("3:")
+        set_state(at)
+        folds(0)
+        s.label("4:")
+        for j in range(nb):
+            s.ins(f"v_min_i32 %{j}, v{C[j][0]}, v{C[j][1]}", reads=C[j])
+        t = s.out[m0:]
+        del s.out[m0:]
+        return t
+
+    ta, tb = tail(entry), tail(after)
+    assert strip(ta) == strip(tb)
+    s.out += ta if len(ta) >= len(tb) else tb       # the longer padding serves either entry
+    return s.out, sorted(s.used)
+
+
+BOUND_NB = (1, 2, 4)
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     dst = os.environ.get("MX_OUT") or os.path.join(here, "..", "multimoda-rs_amd", "csrc", "mm_screen_mx_asm.inc")
@@ -511,6 +626,14 @@ def main():
                     f.write(f'    "{line}\\n" \\\n')
                 f.write('    ""\n')
                 f.write(f"#define MM_SCREEN_MX_CLOBBERS_{name} " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
+        for nb in BOUND_NB:
+            out, regs = generate_bound(nb)
+            total += len(out)
+            f.write(f"// ---- the bound kernel's pass, {nb} B fragment(s) per row fragment: {len(out)} instructions\n#define MM_BOUND_MX_ASM_{nb} \\\n")
+            for line in out:
+                f.write(f'    "{line}\\n" \\\n')
+            f.write('    ""\n')
+            f.write(f"#define MM_BOUND_MX_CLOBBERS_{nb} " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
         # the dispatch: one inline function per block, selected at compile time
         f.write("\n#ifdef __HIPCC__\n")
         f.write("template <int NCT, bool CARRY> struct MxMain;\n")
