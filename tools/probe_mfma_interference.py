@@ -1,3 +1,14 @@
+"""PROBE (round 4 finding): the packed-FMA kernels of this library return WRONG values, now and then, while a kernel that
+executes MFMAs runs on the chip at the same time -- another engine's k_screen_mx here, or any MFMA loop of another process
+(tools/probe_mfma_victim.py beside tools/bin/ubench_aggr).  Victims: k_screen_lb (lower bounds of the packed-FMA bounded
+search), k_screen_fast (MM_PRECISION_F32_FAST), k_search<float> (MM_PRECISION_F32): single candidates come out too LARGE
+(e.g. 0.19 for 0.15 mm^2), in 3 - 15 % of the calls.  Not disturbed: k_screen_mx, k_bound_mx, the exact f64 kernels, the
+small per-pair kernels; and a plain-FMA aggressor disturbs nothing.  The cause is not known (synthetic victims built from
+the same instruction kinds -- v_pk_fma_f32, DPP row minima, ds_read_b128, ds_bpermute, v_min3_f32 -- pass beside the same
+aggressor: tools/ubench_interf.hip; LDS / VGPR / global patterns of a victim stay intact: tools/ubench_interf2.hip), so the
+library AVOIDS the combination: under MM_PRECISION_F32_MATRIX and MM_PRECISION_F32_BOUNDED every value that decides a
+result comes from an MFMA or an f64 kernel (profiles/README.md).  One victim call after the other beside a `fast` and a
+`matrix` between-alignment loop on a second engine; prints the number of calls whose values differ from a quiet run."""
 import sys, os, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,7 @@
+"""PROBE, second half of tools/probe_mfma_interference.py: the packed-FMA bound kernel (k_screen_lb through the mm_lower_bounds
+test hook) ALONE in this process, 300 calls compared with the first.  Run it once by itself (0 differing) and once beside
+`tools/bin/ubench_aggr 25` (an MFMA loop of another process: 16 of 300 differing on the box of profiles/r4_mfma_interference.txt)
+or `tools/bin/ubench_aggr 25 2` (a plain-FMA loop: 0)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
