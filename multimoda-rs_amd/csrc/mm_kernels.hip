@@ -603,6 +603,29 @@ static __device__ __forceinline__ h8v mx_fragment(float X, float Y, int hi)
 
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
+// the n points at (px, py) as ntiles x 64 row fragments in LDS (padding rows duplicate the last point), by 256 threads.  Four
+// slots per thread and pass: the loads of a pass are issued together -- fragment by fragment the loop exposed one global-memory
+// round trip per slot (8.5 of them for a 544-point set: ~25 us of a bound kernel's work item, more than its MFMAs)
+static __device__ __forceinline__ void mx_stage_rows(h8v* __restrict__ s_dst, int ntiles, int n, const float* __restrict__ px,
+                                                     const float* __restrict__ py, float S, int tid)
+{
+    const int total = ntiles * 64;
+    for (int s0 = tid; s0 < total; s0 += 256 * 4) {
+        float x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int slot = s0 + 256 * u < total ? s0 + 256 * u : total - 1;
+            const int row = (slot >> 6) * 32 + (slot & 31), rc = row < n ? row : n - 1;
+            x[u] = px[rc]; y[u] = py[rc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int slot = s0 + 256 * u;
+            if (slot < total) s_dst[slot] = mx_fragment<true>(S * x[u], S * y[u], (slot & 63) >> 5);
+        }
+    }
+}
+
 
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -691,11 +714,7 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         __syncthreads();
         // the candidates' cos / sin once per work item (a global load at the top of every candidate would be exposed)
         if (tid < 16 && (tid >> 1) < w.cnt) s_cs[tid] = (tid & 1) ? sinv[pd.tab_off + w.a0 + (tid >> 1)] : cosv[pd.tab_off + w.a0 + (tid >> 1)];
-        for (int slot = tid; slot < nrt * 64; slot += 256) {
-            const int rt = slot >> 6, l = slot & 63, row = rt * 32 + (l & 31);
-            const int rc = row < na ? row : na - 1;      // padding rows duplicate the last reference point
-            s_a[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], l >> 5);
-        }
+        mx_stage_rows(s_a, nrt, na, ptx + pd.ref_off, pty + pd.ref_off, S, tid);      // padding rows duplicate the last reference point
         if constexpr (!MULTI) {
             // this lane's columns -- every wave holds all of them: lane + 64 q -- unrotated, scaled, in registers for all the
             // wave's candidates
@@ -1073,14 +1092,8 @@ k_bound_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work
         const int32_t* ql = LIST ? qlist + (size_t)w.pair * (2 * nq_list) : nullptr;
 
         __syncthreads();   // the previous item's readers are done
-        for (int slot = tid; slot < nrt * 64; slot += 256) {
-            const int row = (slot >> 6) * 32 + (slot & 31), rc = row < na ? row : na - 1;   // padding rows duplicate the last point
-            s_r[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], (slot & 63) >> 5);
-        }
-        for (int slot = tid; slot < ntt * 64; slot += 256) {
-            const int row = (slot >> 6) * 32 + (slot & 31), rc = row < nb ? row : nb - 1;
-            s_t[slot] = mx_fragment<true>(S * ptx[pd.tgt_off + rc], S * pty[pd.tgt_off + rc], (slot & 63) >> 5);
-        }
+        mx_stage_rows(s_r, nrt, na, ptx + pd.ref_off, pty + pd.ref_off, S, tid);
+        mx_stage_rows(s_t, ntt, nb, ptx + pd.tgt_off, pty + pd.tgt_off, S, tid);
         // this lane's queries, unrotated and scaled, and their norm pieces (candidate-independent); columns past the subset
         // repeat its last query (no effect on the maximum over the subset)
         float ax[QT], ay[QT], bx[QT], by[QT];
@@ -1197,14 +1210,8 @@ k_bound_mx_scan(const PairDesc* __restrict__ pairs, int n_pairs, int split, cons
             if (stats && tid == 0) atomicAdd(&stats[stat_slot], (unsigned long long)n);
             if (!staged) {
                 staged = true;
-                for (int slot = tid; slot < nrt * 64; slot += 256) {
-                    const int row = (slot >> 6) * 32 + (slot & 31), rc = row < na ? row : na - 1;
-                    s_r[slot] = mx_fragment<true>(S * ptx[pd.ref_off + rc], S * pty[pd.ref_off + rc], (slot & 63) >> 5);
-                }
-                for (int slot = tid; slot < ntt * 64; slot += 256) {
-                    const int row = (slot >> 6) * 32 + (slot & 31), rc = row < nb ? row : nb - 1;
-                    s_t[slot] = mx_fragment<true>(S * ptx[pd.tgt_off + rc], S * pty[pd.tgt_off + rc], (slot & 63) >> 5);
-                }
+                mx_stage_rows(s_r, nrt, na, ptx + pd.ref_off, pty + pd.ref_off, S, tid);
+                mx_stage_rows(s_t, ntt, nb, ptx + pd.tgt_off, pty + pd.tgt_off, S, tid);
                 const int qa = LIST ? nq_list : (na + stride - 1) / stride;
                 const int qb = LIST ? nq_list : (nb + stride - 1) / stride;
                 const int32_t* ql = LIST ? qlist + (size_t)p * (2 * nq_list) : nullptr;

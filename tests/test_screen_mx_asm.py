@@ -409,7 +409,8 @@ def _run_bound(nb, nt):
             a = _regs(addr)
             touch(d + a, a)
             t = (R[a[0]][1] + int(off)) // 1024
-            assert (R[a[0]][1] + int(off)) % 1024 == 0 and 0 <= t < nt, f"row tile {t} of {nt} requested"      # never past the set
+            # (requests may run up to two tiles past the set: read, never multiplied -- the MFMA branch checks that)
+            assert (R[a[0]][1] + int(off)) % 1024 == 0 and 0 <= t < max(nt + 2, 3), f"row tile {t} of {nt} requested"
             for r in d:
                 R[r] = ("A", t)
                 loading.add(r)
@@ -422,6 +423,7 @@ def _run_bound(nb, nt):
             ta = {R[r] for r in a}
             assert len(ta) == 1
             (_, t), = ta
+            assert 0 <= t < nt, f"row tile {t} of {nt} multiplied"
             for v in range(16):
                 R[d[v]] = Min({(j, t, v, 0)}, {(j, t, v, 1)})
                 mfma_at[d[v]] = st["states"]
@@ -447,10 +449,10 @@ def _run_bound(nb, nt):
 
 
 @pytest.mark.parametrize("nb", [1, 2, 4])
-@pytest.mark.parametrize("nt", [1, 2, 3, 4, 5, 6, 7, 16, 17, 32])
+@pytest.mark.parametrize("nt", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 32])
 def test_bound_pass_folds_every_tile_once(nb, nt):
     result, st = _run_bound(nb, nt)
-    assert st["n_mfma"] == nt * nb and st["n_lds"] == nt           # one read of a row fragment feeds nb MFMAs
+    assert st["n_mfma"] == nt * nb and nt <= st["n_lds"] <= max(nt + 2, 3)     # one read of a row fragment feeds nb MFMAs
     for j in range(nb):
         for h in range(2):
             assert result[j].h[h] == {(j, t, v, h) for t in range(nt) for v in range(16)}

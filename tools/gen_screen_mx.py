@@ -502,27 +502,30 @@ def generate(nct, carry):
 def generate_bound(nb):
     """The bound kernel's pass (k_bound_mx, mm_kernels.hip): `nb` column tiles of queries held in registers (operands
     %4 .., the B fragments: query tiles of one candidate and / or of several candidates) against the row tiles of a set in
-    LDS.  Per row tile ONE ds_read_b128 of the row fragment feeds nb MFMAs -- at one MFMA per read the kernel is bound by LDS
-    bandwidth (1 KB per wave and tile = 128 B / clk / CU at the matrix pipe's rate) -- and every MFMA result is folded by 8
-    v_min3_i32 into two running column minima (two chains; a lane's 16 values all belong to its query).  Two sets of result
-    buffers: the MFMAs of the next row tile are issued ahead of the minima of the tile before; the distance between an MFMA
-    and the first read of its result is padded where the instructions in between are not enough.  The compiler cannot be
-    trusted with this: it places the minima of a tile right behind that tile's MFMA without a wait state (inline asm
-    operands are invisible to its MFMA hazard recogniser), and the hardware does not interlock -- the minima then fold stale
-    registers.
+    LDS.  Per row tile ONE ds_read_b128 of the row fragment feeds nb MFMAs, and every MFMA result is folded by 8
+    v_min3_i32 into two running column minima (two chains; a lane's 16 values all belong to its query).
+    Software pipeline: two sets of result buffers -- the MFMAs of the next row tile are issued ahead of the minima of the
+    tile before -- and FOUR row-fragment registers: the fragments of tiles c + 3, c + 4 are requested while c + 1, c + 2 are
+    multiplied, so that an LDS round trip has half a loop body (two tiles) to complete behind.  (The first version requested a
+    fragment and waited for it on the spot: 295 clocks per tile, most of them LDS latency.)  The loop body is four tiles; what
+    is left (0 .. 3 tiles) has its own code.  Requests may run up to two tiles past the set (read, never multiplied).
+    The distance between an MFMA and the first read of its result is padded where the instructions in between are not
+    enough.  The compiler cannot be trusted with this: it places the minima of a tile right behind that tile's MFMA without
+    a wait state (inline asm operands are invisible to its MFMA hazard recogniser), and the hardware does not interlock --
+    the minima then fold stale registers.
     Operands: %0 .. %(nb-1) out: min over all row tiles of this lane's column (its half of the rows), per B fragment;
     %nb =s counter; then LDS byte address of this lane's fragment in row tile 0 (the next ones 1024 bytes apart); s: row
     tiles - 1; the nb B fragments (4 VGPRs each)."""
     s = Stream()
     o_cnt, o_addr, o_nt, o_b = nb, nb + 1, nb + 2, nb + 3
-    A, ADDR = ASET, AADDR
+    R, ADDR = [60, 64, 68, 76], AADDR                      # four row-fragment registers (v72 .. v75 belong to the screen's blocks)
     D = [[P + 16 * (2 * j), P + 16 * (2 * j + 1)] for j in range(nb)]        # D[j][k]: result buffer k of fragment j
     C = [[CM + 2 * j, CM + 2 * j + 1] for j in range(nb)]
 
-    def mfmas(k):
+    def mfmas(k, r):
         for j in range(nb):
             d = D[j][k]
-            s.ins(f"v_mfma_f32_32x32x16_f16 v[{d}:{d + 15}], v[{A[k]}:{A[k] + 3}], %{o_b + j}, 0", reads=rng(A[k], 4), writes=rng(d, 16), mfma=True)
+            s.ins(f"v_mfma_f32_32x32x16_f16 v[{d}:{d + 15}], v[{R[r]}:{R[r] + 3}], %{o_b + j}, 0", reads=rng(R[r], 4), writes=rng(d, 16), mfma=True)
 
     def folds(k):
         for q in range(8):              # interleaved over the fragments: no instruction depends on the one before
@@ -530,8 +533,8 @@ def generate_bound(nb):
                 c, d = C[j][q & 1], D[j][k]
                 s.ins(f"v_min3_i32 v{c}, v{c}, v{d + 2 * q}, v{d + 2 * q + 1}", reads=[c, d + 2 * q, d + 2 * q + 1], writes=[c], valu=True)
 
-    def load(k, off):
-        s.ins(f"ds_read_b128 v[{A[k]}:{A[k] + 3}], v{ADDR} offset:{off}", reads=[ADDR], writes=rng(A[k], 4), lds_load=True)
+    def load(r, off):
+        s.ins(f"ds_read_b128 v[{R[r]}:{R[r] + 3}], v{ADDR} offset:{off}", reads=[ADDR], writes=rng(R[r], 4), lds_load=True)
 
     def state():
         return copy.deepcopy((s.n, s.mfma_at, s.valu_at, s.loading))
@@ -539,68 +542,104 @@ def generate_bound(nb):
     def set_state(x):
         s.n, s.mfma_at, s.valu_at, s.loading = copy.deepcopy(x)
 
+    strip = lambda b: [x for x in b if not x.startswith("s_nop")]
+
+    def merge_pad(x, y):
+        """two versions of the same instruction sequence that differ in their s_nop padding: the larger padding at every place"""
+        assert strip(x) == strip(y)
+        out, i, j = [], 0, 0
+        while i < len(x) or j < len(y):
+            px = py = -1
+            if i < len(x) and x[i].startswith("s_nop"):
+                px = int(x[i].split()[1]); i += 1
+            if j < len(y) and y[j].startswith("s_nop"):
+                py = int(y[j].split()[1]); j += 1
+            if max(px, py) >= 0:
+                out.append(f"s_nop {max(px, py)}")
+            if i < len(x):
+                assert x[i] == y[j]
+                out.append(x[i]); i += 1; j += 1
+        return out
+
+    # ---- prologue: tiles 0, 1, 2 requested; tile 0 multiplied.  Invariant at the loop top (c = 0): D[.][0] = tile c, R1 = tile
+    # c + 1, R2 = tile c + 2 (requested), v73 = address of tile c, counter = tiles after c
     s.ins(f"v_mov_b32 v{ADDR}, %{o_addr}", writes=[ADDR], valu=True)
-    load(0, 0)
+    load(0, 0); load(1, 1024); load(2, 2048)
     for j in range(nb):
         for c in C[j]:
             s.ins(f"v_mov_b32 v{c}, {INF}", writes=[c], valu=True)
     s.raw(f"s_mov_b32 %{o_cnt}, %{o_nt}")
     s.wait()
-    mfmas(0)
-    s.raw(f"s_cmp_lt_u32 %{o_cnt}, 2")
+    mfmas(0, 0)
+    s.raw(f"s_cmp_lt_u32 %{o_cnt}, 4")
     s.raw("s_cbranch_scc1 2f")
     entry = state()
     s.label("1:")
     bodies = []
     for it in range(2):
         m0 = s.mark()
-        load(1, 1024)
-        load(0, 2048)
-        s.wait()
-        mfmas(1)
-        folds(0)
-        mfmas(0)
-        folds(1)
-        s.ins(f"v_add_u32 v{ADDR}, 2048, v{ADDR}", reads=[ADDR], writes=[ADDR], valu=True)
-        s.raw(f"s_sub_u32 %{o_cnt}, %{o_cnt}, 2")
-        s.raw(f"s_cmp_gt_u32 %{o_cnt}, 1")
+        s.wait()                                  # R1, R2: requested half a body ago
+        load(3, 3072); load(0, 4096)
+        mfmas(1, 1); folds(0); mfmas(0, 2); folds(1)
+        s.wait()                                  # R3, R0
+        load(1, 5120); load(2, 6144)
+        mfmas(1, 3); folds(0); mfmas(0, 0); folds(1)
+        s.ins(f"v_add_u32 v{ADDR}, 4096, v{ADDR}", reads=[ADDR], writes=[ADDR], valu=True)
+        s.raw(f"s_sub_u32 %{o_cnt}, %{o_cnt}, 4")
+        s.raw(f"s_cmp_gt_u32 %{o_cnt}, 3")
         s.raw("s_cbranch_scc1 1b")
         bodies.append(s.out[m0:])
         if it == 0:
             keep = s.mark()
             after = state()
-    # the first iteration comes right behind the prologue's MFMAs and needs the longer padding; the steady state is safe
-    # with it too (more wait states never hurt) -- tests/test_screen_mx_asm.py executes the text for every trip count
-    strip = lambda b: [x for x in b if not x.startswith("s_nop")]
-    assert len(bodies[0]) >= len(bodies[1]) and strip(bodies[0]) == strip(bodies[1])
+    # the first iteration comes right behind the prologue's MFMAs and may need more padding; the steady state is safe with it
+    # too (more wait states never hurt) -- tests/test_screen_mx_asm.py executes the text for every trip count
     del s.out[keep:]
+    s.out[keep - len(bodies[0]):keep] = merge_pad(bodies[0], bodies[1])
     s.label("2:")
 
-    def tail(st):
+    def tails(st):
+        """0 .. 3 tiles after tile c: D0 = tile c, R1 = c + 1, R2 = c + 2 requested"""
         set_state(st)
         m0 = s.mark()
         s.raw(f"s_cmp_eq_u32 %{o_cnt}, 0")
-        s.raw("s_cbranch_scc1 3f")
-        at = state()
-        load(1, 1024)                       # one row tile left
+        s.raw("s_cbranch_scc1 5f")
+        at5 = state()                             # (a taken branch leaves here: the wait states behind it do not count)
+        s.raw(f"s_cmp_eq_u32 %{o_cnt}, 1")
+        s.raw("s_cbranch_scc1 6f")
+        at6 = state()
+        s.raw(f"s_cmp_eq_u32 %{o_cnt}, 2")
+        s.raw("s_cbranch_scc1 7f")
+        at7 = state()
+        # three left
         s.wait()
-        mfmas(1)
+        load(3, 3072)
+        mfmas(1, 1); folds(0); mfmas(0, 2); folds(1)
+        s.wait()
+        mfmas(1, 3); folds(0); folds(1)
+        s.raw("s_branch 8f")
+        s.label("7:")                             # two left
+        set_state(at7)
+        s.wait()
+        mfmas(1, 1); folds(0); mfmas(0, 2); folds(1); folds(0)
+        s.raw("s_branch 8f")
+        s.label("6:")                             # one left
+        set_state(at6)
+        s.wait()
+        mfmas(1, 1); folds(0); folds(1)
+        s.raw("s_branch 8f")
+        s.label("5:")                             # none left
+        set_state(at5)
         folds(0)
-        folds(1)
-        s.raw("s_branch 4f")
-        s.label("3:")
-        set_state(at)
-        folds(0)
-        s.label("4:")
+        s.wait()                                  # (the requests that ran past the set)
+        s.label("8:")
         for j in range(nb):
             s.ins(f"v_min_i32 %{j}, v{C[j][0]}, v{C[j][1]}", reads=C[j])
         t = s.out[m0:]
         del s.out[m0:]
         return t
 
-    ta, tb = tail(entry), tail(after)
-    assert strip(ta) == strip(tb)
-    s.out += ta if len(ta) >= len(tb) else tb       # the longer padding serves either entry
+    s.out += merge_pad(tails(entry), tails(after))          # the larger padding at every place serves either entry
     return s.out, sorted(s.used)
 
 
