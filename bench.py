@@ -422,6 +422,7 @@ class Runner:
         self.rehearse = rehearse           # > 1: this process plays rank 0 of `rehearse` ranks without peers (timing only)
         self.grid = grid                   # (pair_blocks, cand_slices) of the shard grid (N > 1 / rehearsal)
         self.comm = comm                   # rehearsal: the library's world = 1 RCCL communicator (None: torch's)
+        self.fin_group = None              # N > 1: the process group of the finishing thread's broadcasts (its own communicator)
         # the caller's input data: one fresh copy of the case per step (made before the timed region -- this is
         # the data a caller hands over, not work of the step)
         # (lazy_until: the cases of the untimed clock-ramp steps are copied when they are staged and dropped when they
@@ -502,6 +503,20 @@ class Runner:
             out = (r["winners"], None, self.plans[k].pose_evals, 0)
         elif self.plans[k] is None:
             out = full_alignment(mm, self.engs[0], self.cases[k], cfg, None, self.prec)
+        elif self.sharded_finish():
+            # N > 1: pullback g is walked on rank g mod N, pair k of a between batch aligned on rank k mod N, and what they
+            # changed is broadcast from the owner (multimoda_rs_amd.distributed.walk_sharded / align_between_sharded): every
+            # rank ends up with the whole alignment without repeating the whole finish.  Rehearsal: this process plays rank 0
+            # without peers -- its share of the finish, nothing exchanged.
+            from multimoda_rs_amd import distributed as D
+            rk, wd = (self.rank, self.world) if self.world > 1 else (0, self.rehearse)
+            kw = dict(group=self.fin_group, rank=rk, world=wd, exchange=self.world > 1)
+            logs, ev, unres = D.walk_sharded(self.plans[k], **kw)
+            eng = self.engs[k % len(self.engs)]
+            a, b, c, d = self.cases[k]
+            r1, e1 = D.align_between_sharded(eng, [(a, b), (c, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], self.prec, **kw)
+            r2, e2 = D.align_between_sharded(eng, [(a, c), (b, d)], cfg["range_deg"], cfg["step_deg"], cfg["sample_size"], self.prec, **kw)
+            out = (logs, np.concatenate([r1, r2]), ev + e1 + e2, unres)
         else:
             logs, ev, unres = self.plans[k].walk()
             rot, e2 = between_stage(mm, self.engs[k % len(self.engs)], self.cases[k], cfg, self.prec)
@@ -512,6 +527,9 @@ class Runner:
         if k < self.lazy_until:
             self.cases[k] = None
         return out
+
+    def sharded_finish(self):
+        return (self.world > 1 or self.rehearse > 1) and os.environ.get("MM_BENCH_SHARDED_FINISH", "1") != "0"
 
     def close(self):
         for i, p in enumerate(self.plans):
@@ -593,6 +611,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    # the finishing thread's collectives (broadcasts of walked pullbacks) run beside the search thread's all-reduces: a group
+    # of their own, so that the two threads' collectives are never ordered against each other
+    fin_group = dist.new_group(backend=backend) if world > 1 else None
 
     # MM_BENCH_REHEARSE_WORLD=N (single process): play rank 0 of N ranks WITHOUT peers -- this rank's share of the
     # candidate axis, the N > 1 code path (no look-ahead, device exchange, both all-reduces over a world = 1 RCCL
@@ -707,7 +729,11 @@ def main():
         gc.disable()                                      # keep the interpreter's cyclic GC (tens of ms) out of the steps
         # (collected BEFORE the warm-up: a collection between warm-up and timed region idles the device for ~40 ms,
         # and the first big launch after such a pause runs 34.9 instead of 31.3 ms -- the clocks have dropped)
-        nfin = int(os.environ.get("MM_BENCH_FINISHERS", "2" if sharded else "1"))
+        # one finishing thread: with the finish sharded over the ranks it is a fraction of a step (and the finishing thread's
+        # broadcasts must be issued in one order on every rank); MM_BENCH_SHARDED_FINISH=0: every rank finishes everything,
+        # two threads take turns
+        r.fin_group = fin_group
+        nfin = int(os.environ.get("MM_BENCH_FINISHERS", "2" if (sharded and not r.sharded_finish()) else "1"))
         run_steps(range(warmup), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre, nfin)
         barrier()
         for e in engs:

@@ -393,6 +393,12 @@ int  mm_within_plan_create_grid(mm_engine* e, int n_geoms, mm_geometry** geoms,
                                 double step_deg, double range_deg, int bruteforce, int64_t sample_size,
                                 int precision, int rank, int pair_blocks, int cand_slices, mm_within_plan** out);
 int  mm_within_plan_set_shard_grid(mm_within_plan* p, int rank, int pair_blocks, int cand_slices);
+/* mm_within_plan_walk for SOME of the plan's pullbacks: take[g] != 0 (n_geoms bytes).  After a sharded search every rank
+ * holds every winner, so the chain walks -- pure host work, one pullback independent of the other (entry.rs:140-203: four
+ * threads) -- need not be repeated on every rank: rank r walks the pullbacks g with g mod world == r and broadcasts their
+ * logs and coordinates (mm_comm_broadcast; multimoda_rs_amd.distributed.finish_sharded).  Pullbacks not taken are left
+ * untouched, their logs unwritten; pose_evals / n_unresolved count the taken ones. */
+int  mm_within_plan_walk_geoms(mm_within_plan* p, const uint8_t* take, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
 /* TIMING ONLY (bench.py's single-process rehearsal of a rank of a larger job): with `on` != 0 the sharded entry points accept
  * a world = 1 communicator for a plan whose (rank, world) is a tile of a larger grid.  The reduced records then hold this
  * tile alone -- the result is NOT an alignment, and mm_within_plan_walk / _run_sharded report n_unresolved = -1 to say so.
@@ -416,6 +422,9 @@ int  mm_comm_version(void);   /* RCCL's version code, -1 if RCCL cannot be loade
 /* all-reduce(MIN) in place on device memory, enqueued on `stream` (a hipStream_t) */
 int  mm_comm_all_reduce_min_f64(mm_comm* c, double* dev, int64_t n, void* stream);
 int  mm_comm_all_reduce_min_i64(mm_comm* c, int64_t* dev, int64_t n, void* stream);
+/* broadcast of `bytes` bytes of device memory from rank `root`, in place, enqueued on `stream`: how a host that walks pullback g
+ * on rank g mod world only (mm_within_plan_walk_geoms) hands its logs and coordinates to the other ranks */
+int  mm_comm_broadcast(mm_comm* c, void* dev, int64_t bytes, int root, void* stream);
 
 /* The sharded search with the exchange inside the library: for every level
  *   level_launch -> export_cost -> ncclAllReduce(MIN, f64 x jobs) -> export_keys -> ncclAllReduce(MIN, i64 x 3 jobs)

@@ -42,7 +42,7 @@ EXPORTS = [
     "mm_shard_grid", "mm_within_plan_create_grid", "mm_within_plan_set_shard_grid", "mm_comm_unique_id", "mm_comm_init_rank",
     "mm_comm_destroy", "mm_comm_rank", "mm_comm_world", "mm_comm_version", "mm_comm_all_reduce_min_f64",
     "mm_comm_all_reduce_min_i64", "mm_within_plan_search_sharded", "mm_within_plan_run_sharded",
-    "mm_within_plan_search_sharded_begin", "mm_engine_wait_exchange", "mm_within_plan_set_timing_rehearsal",
+    "mm_within_plan_search_sharded_begin", "mm_engine_wait_exchange", "mm_within_plan_set_timing_rehearsal", "mm_within_plan_walk_geoms", "mm_comm_broadcast",
 ]
 # include/mm_centerline.h
 EXPORTS_CENTERLINE = [
@@ -269,6 +269,10 @@ def lib():
     L.mm_within_plan_create_grid.argtypes = [P, I, P, D, D, I, I64, I, I, I, I, C.POINTER(P)]
     L.mm_within_plan_set_shard_grid.restype = I
     L.mm_within_plan_set_shard_grid.argtypes = [P, I, I, I]
+    L.mm_within_plan_walk_geoms.restype = I
+    L.mm_within_plan_walk_geoms.argtypes = [P, P, P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.mm_comm_broadcast.restype = I
+    L.mm_comm_broadcast.argtypes = [P, P, I64, I, P]
     L.mm_within_plan_set_timing_rehearsal.restype = I
     L.mm_within_plan_set_timing_rehearsal.argtypes = [P, I]
     L.mm_comm_unique_id.restype = I
@@ -549,6 +553,9 @@ class Comm:
     def all_reduce_min_f64(self, dev_ptr: int, n: int, stream: int):
         check(lib().mm_comm_all_reduce_min_f64(self.handle, C.c_void_p(dev_ptr), int(n), C.c_void_p(stream)),
               "mm_comm_all_reduce_min_f64")
+
+    def broadcast(self, dev_ptr: int, nbytes: int, root: int, stream: int):
+        check(lib().mm_comm_broadcast(self.handle, C.c_void_p(dev_ptr), int(nbytes), int(root), C.c_void_p(stream)), "mm_comm_broadcast")
 
     def all_reduce_min_i64(self, dev_ptr: int, n: int, stream: int):
         check(lib().mm_comm_all_reduce_min_i64(self.handle, C.c_void_p(dev_ptr), int(n), C.c_void_p(stream)),

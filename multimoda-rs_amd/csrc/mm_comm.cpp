@@ -159,6 +159,20 @@ int mm_comm_all_reduce_min_f64(mm_comm* h, double* dev, int64_t n, void* stream)
     return comm_all_reduce_min(c, dev, n, true, (hipStream_t)stream);
 }
 
+int mm_comm_broadcast(mm_comm* h, void* dev, int64_t bytes, int root, void* stream)
+{
+    if (!h || (bytes > 0 && !dev) || bytes < 0) return set_error(MM_ERR_INVALID, "mm_comm_broadcast: bad argument");
+    Comm* c = reinterpret_cast<Comm*>(h);
+    if (root < 0 || root >= c->world) return set_error(MM_ERR_INVALID, "mm_comm_broadcast: root is not a rank of the communicator");
+    if (bytes == 0) return MM_OK;
+    hipError_t he = hipSetDevice(c->device);
+    if (he != hipSuccess) return hip_error(he, "hipSetDevice");
+    const RcclApi& a = rccl();
+    if (!a.handle) return set_error(MM_ERR_COMM, a.error);
+    const ncclResult_t r = a.Broadcast(dev, dev, (size_t)bytes, ncclUint8, root, c->c, (hipStream_t)stream);
+    return r == ncclSuccess ? MM_OK : rccl_error(a, r, "ncclBroadcast");
+}
+
 int mm_comm_all_reduce_min_i64(mm_comm* h, int64_t* dev, int64_t n, void* stream)
 {
     if (!h || (n > 0 && !dev) || n < 0) return set_error(MM_ERR_INVALID, "mm_comm_all_reduce_min_i64: bad argument");

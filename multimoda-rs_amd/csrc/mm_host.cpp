@@ -326,6 +326,8 @@ struct WithinPlan {
                            std::vector<PairSpec>& pairs, std::vector<int>& active, std::vector<double>* centre_out);
     int search();
     int walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved);
+    std::vector<uint8_t> walk_take;   // mm_within_plan_walk_geoms: the pullbacks to walk (empty: all)
+    bool taken(int g) const { return walk_take.empty() || walk_take[(size_t)g] != 0; }
 };
 
 // The search sets built on the HOST and uploaded as four planes (the path of round 1; kept behind
@@ -801,7 +803,7 @@ int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresol
     // independent pure-host chains; walk them concurrently, one thread per pullback, like the
     // reference's crossbeam scope (entry.rs:140-203).
     bool all_resolved = true;
-    for (uint8_t r : resolved) all_resolved = all_resolved && (r != 0);
+    for (size_t j = 0; j < resolved.size(); ++j) all_resolved = all_resolved && (resolved[j] != 0 || !taken(job_geom[j]));
     if (all_resolved) {
         // Pass 1 (serial, O(frames)): the chain couples frames only through the frame centroids.
         // Rotating a frame about its own centroid leaves that centroid bit for bit
@@ -812,6 +814,7 @@ int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresol
         struct Step { int g; int32_t i; double cum, tx, ty, cx, cy, best; };
         std::vector<Step> steps;
         for (int g = 0; g < n_geoms; ++g) {
+            if (!taken(g)) continue;
             const mm_geometry* G = geoms[g];
             double cumulative = 0.0;
             double pcx = G->n_frames > 0 ? G->centroid[0] : 0.0, pcy = G->n_frames > 0 ? G->centroid[1] : 0.0;
@@ -845,7 +848,7 @@ int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresol
                 }
             }
         });
-        if (pose_evals) for (int64_t v : evals) *pose_evals += v;
+        if (pose_evals) for (size_t j = 0; j < evals.size(); ++j) if (taken(job_geom[j])) *pose_evals += evals[j];
         return MM_OK;
     }
     std::vector<double> cumulative(n_geoms, 0.0);
@@ -856,7 +859,7 @@ int WithinPlan::walk(mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresol
         std::vector<Step> steps;
         for (int g = 0; g < n_geoms; ++g) {
             mm_geometry* G = geoms[g];
-            if (i >= G->n_frames) continue;
+            if (i >= G->n_frames || !taken(g)) continue;
             const double pcx = G->centroid[3 * (i - 1)], pcy = G->centroid[3 * (i - 1) + 1];
             if (cumulative[g] != 0.0)  // align_within.rs:79-82
                 mm_frame_rotate(G, i, cumulative[g], G->centroid[3 * i], G->centroid[3 * i + 1]);
@@ -1415,6 +1418,20 @@ int mm_within_plan_walk(mm_within_plan* h, mm_alignlog** logs, int64_t* pose_eva
     if (int drc = select_device(wp->e)) return drc;   // unresolved steps search on the chain state
     const int rc = wp->walk(logs, pose_evals, n_unresolved);
     if (wp->rehearsal && n_unresolved) *n_unresolved = -1;    // not an alignment: the records held one tile of a larger job
+    return rc;
+}
+
+int mm_within_plan_walk_geoms(mm_within_plan* h, const uint8_t* take, mm_alignlog** logs, int64_t* pose_evals, int64_t* n_unresolved)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp || !take) return set_error(MM_ERR_INVALID, "within plan / take == NULL");
+    if (pose_evals) *pose_evals = 0;
+    if (n_unresolved) *n_unresolved = 0;
+    if (int drc = select_device(wp->e)) return drc;
+    wp->walk_take.assign(take, take + wp->n_geoms);
+    const int rc = wp->walk(logs, pose_evals, n_unresolved);
+    wp->walk_take.clear();
+    if (wp->rehearsal && n_unresolved) *n_unresolved = -1;
     return rc;
 }
 

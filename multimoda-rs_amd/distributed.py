@@ -299,3 +299,94 @@ def search_inprocess(plans: Sequence):
         torch.cuda.synchronize()
         for p, b in zip(plans, bufs):
             p.level_commit_dev(l, b.cost.data_ptr(), b.keys.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------
+# the finish of a sharded alignment, sharded too
+# ------------------------------------------------------------------------------------------
+# After a sharded search every rank holds every winner.  The chain walks (host work, one pullback independent of the other:
+# the reference's four crossbeam threads, entry.rs:140-203) and the between alignments (2 || + 2 ||, entry.rs:206-277) used
+# to be repeated on every rank -- at N = 8 that finish (2.8 ms) was longer than the rank's launch (2.4 ms).  Here pullback g
+# is walked on rank g mod world alone and pair k of a between batch is aligned on rank k mod world alone; what they changed
+# -- logs, coordinates, the rotation -- goes to the other ranks in ONE broadcast per pullback from its owner.
+def _mutable_arrays(g):
+    """the arrays of a FlatGeometry that a chain walk or a between alignment rewrites"""
+    return [a for a in (g.centroids, g.lumen, g.cath, g.extra, g.ref, getattr(g, "lumen_centroids", None)) if a is not None]
+
+
+def broadcast_state(arrays, src: int, group=None, comm: "N.Comm" = None, stream: int = 0):
+    """One broadcast of a list of numpy arrays / ctypes buffers from rank `src`, in place.  comm: the library's
+    communicator (``mm_comm_broadcast`` on a device staging buffer); else torch.distributed on `group` (gloo: host tensors)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    views = [np.frombuffer(a, dtype=np.uint8) if not isinstance(a, np.ndarray) else a.reshape(-1).view(np.uint8) for a in arrays]
+    sizes = [v.size for v in views]
+    rank = comm.rank if comm is not None else dist.get_rank(group)
+    flat = np.concatenate(views) if rank == src else np.empty(sum(sizes), dtype=np.uint8)
+    if comm is not None:
+        t = torch.from_numpy(flat).cuda()
+        comm.broadcast(t.data_ptr(), flat.size, src, stream)
+        torch.cuda.synchronize()
+        flat = t.cpu().numpy()
+    else:
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.from_numpy(flat)
+        t = t.cuda() if on_dev else t
+        dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+        flat = t.cpu().numpy() if on_dev else flat
+    if rank != src:
+        at = 0
+        for v, n in zip(views, sizes):
+            v[:] = flat[at:at + n]
+            at += n
+
+
+def walk_sharded(plan, group=None, rank: Optional[int] = None, world: Optional[int] = None, exchange: bool = True,
+                 comm: "N.Comm" = None):
+    """The chain walks of a searched plan, pullback g on rank g mod world, then every pullback's logs and coordinates
+    broadcast from its owner: every rank returns what ``plan.walk()`` returns on one GPU.  (rank, world, exchange=False:
+    a single process playing one rank of a larger job for timing -- nothing is exchanged, the result is not an alignment.
+    comm: the library's communicator for the broadcasts (``mm_comm_broadcast``); default: torch.distributed on `group`.)"""
+    import torch
+    import torch.distributed as dist
+    if world is None:
+        world, rank = world_size(group), (dist.get_rank(group) if world_size(group) > 1 else 0)
+    G = len(plan.geoms)
+    take = [g % world == rank for g in range(G)]
+    logs, evals, unresolved = plan.walk(take=take)
+    if world > 1 and exchange:
+        for g, geom in enumerate(plan.geoms):
+            broadcast_state(_mutable_arrays(geom) + [logs[g]._buf], g % world, group, comm, plan.engine.stream)
+        t = torch.tensor([evals, unresolved], dtype=torch.int64)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = t.cuda() if on_dev else t
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        evals, unresolved = int(t[0].item()), int(t[1].item())
+    return logs, evals, unresolved
+
+
+def align_between_sharded(engine, pairs, rot_deg: float, step_rot_deg: float, sample_size: int, precision: int, group=None,
+                          rank: Optional[int] = None, world: Optional[int] = None, exchange: bool = True, comm: "N.Comm" = None):
+    """``geometry.align_between`` with pair k aligned on rank k mod world alone; the moved geometry (b of every pair) and
+    its rotation are broadcast from the owner.  Returns (rotations, pose_evals) like align_between, on every rank."""
+    import torch
+    import torch.distributed as dist
+    from .geometry import align_between
+    if world is None:
+        world, rank = world_size(group), (dist.get_rank(group) if world_size(group) > 1 else 0)
+    mine = [k for k in range(len(pairs)) if k % world == rank]
+    rot = np.zeros(len(pairs), dtype=np.float64)
+    evals = 0
+    if mine:
+        r, evals = align_between(engine, [pairs[k] for k in mine], rot_deg, step_rot_deg, sample_size, precision)
+        rot[mine] = r
+    if world > 1 and exchange:
+        for k, (_, b) in enumerate(pairs):
+            broadcast_state(_mutable_arrays(b) + [rot[k:k + 1]], k % world, group, comm, engine.stream)
+        t = torch.tensor([evals], dtype=torch.int64)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = t.cuda() if on_dev else t
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        evals = int(t[0].item())
+    return rot, evals

@@ -373,13 +373,20 @@ class WithinPlan:
         N.check(N.lib().mm_within_plan_level_commit_dev(self._h, int(level), C.c_void_p(gcost_dev), C.c_void_p(keys_dev)),
                 "mm_within_plan_level_commit_dev")
 
-    def walk(self):
+    def walk(self, take=None):
+        """The chain walk (logs per geometry, pose_evals, n_unresolved).  take: a bool per pullback -- walk only those
+        (``mm_within_plan_walk_geoms``; the others stay untouched and their logs unwritten: distributed.walk_sharded)."""
         G = len(self.geoms)
         log_bufs = [(N.MMAlignLog * max(g.n_frames - 1, 1))() for g in self.geoms]
         lptrs = (C.c_void_p * G)(*[C.cast(b, C.c_void_p) for b in log_bufs])
         pe, nu = C.c_int64(0), C.c_int64(0)
-        N.check(N.lib().mm_within_plan_walk(self._h, C.cast(lptrs, C.c_void_p), C.byref(pe), C.byref(nu)),
-                "mm_within_plan_walk")
+        if take is not None:
+            mask = (C.c_uint8 * G)(*[1 if t else 0 for t in take])
+            N.check(N.lib().mm_within_plan_walk_geoms(self._h, C.cast(mask, C.c_void_p), C.cast(lptrs, C.c_void_p), C.byref(pe),
+                                                      C.byref(nu)), "mm_within_plan_walk_geoms")
+        else:
+            N.check(N.lib().mm_within_plan_walk(self._h, C.cast(lptrs, C.c_void_p), C.byref(pe), C.byref(nu)),
+                    "mm_within_plan_walk")
         logs = [AlignLogs(b, g.n_frames - 1) for b, g in zip(log_bufs, self.geoms)]
         return logs, int(pe.value), int(nu.value)
 

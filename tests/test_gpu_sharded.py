@@ -243,6 +243,38 @@ def test_run_sharded_world2_gloo_on_the_gpu(exchange):
     assert "SHARD_WORKER_OK" in r.stdout
 
 
+def test_sharded_finish_world2_gloo():
+    """the FINISH of a sharded alignment sharded too -- pullback g walked on rank g mod world, between pair k
+    aligned on rank k mod world, what they changed broadcast from the owner (distributed.walk_sharded /
+    align_between_sharded over mm_within_plan_walk_geoms): two `gloo` ranks on the one GPU, every rank against the oracle's
+    whole 4-phase alignment (logs, rotations, every coordinate)."""
+    import __graft_entry__ as ge
+    ge.build()
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", MM_EXCHANGE="device")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29300 + (os.getpid() % 200)),
+           os.path.join(ROOT, "tests", "_finish_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "FINISH_WORKER_OK" in r.stdout
+
+
+def test_walk_of_some_pullbacks_leaves_the_others_untouched(engine, oracle, mm):
+    """mm_within_plan_walk_geoms: the taken pullbacks come out as the oracle's chain, the others exactly as they went in."""
+    geoms = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((9, 6, 11))]
+    before = [g.copy() for g in geoms]
+    og = [to_oracle(oracle, g) for g in geoms]
+    plan = mm.WithinPlan(engine, geoms, 1.0, 180.0, True, 501, precision=mm.MM_PRECISION_F32_MATRIX)
+    plan.search()
+    logs, evals, unres = plan.walk(take=[True, False, True])
+    plan.close()
+    assert unres == 0 and evals == (8 + 10) * 361
+    for k in (0, 2):
+        assert logs[k] == oracle.align_within_chain(og[k], 1.0, 180.0, True, 501, n_threads=4) and geoms_equal(geoms[k], og[k])
+    assert np.array_equal(geoms[1].lumen, before[1].lumen) and np.array_equal(geoms[1].centroids, before[1].centroids)
+
+
 # ---------------------------------------------------------------------------------------
 # search sets built on the device (k_build_sets) vs the host-side helper (mm_catheter_lumen_vec)
 # ---------------------------------------------------------------------------------------
