@@ -16,7 +16,7 @@ from ._native import (MM_PRECISION_F32, MM_PRECISION_F32_BOUNDED, MM_PRECISION_F
 from .geometry import (FlatGeometry, WithinPlan, align_between, align_within, between_points, catheter_points,
                        contour_centroid, search_set)
 from .io import InputData, Record, build_geometry_from_inputdata, numpy_to_inputdata, process_directory
-from .api import (GeometryPair, align_frames_in_geometries, from_array_doublepair, from_array_full, retain_heap,
+from .api import (GeometryPair, align_frames_in_geometries, from_array_doublepair, from_array_full,
                   from_array_single, from_array_singlepair, from_file_doublepair, from_file_full,
                   from_file_single, from_file_singlepair)
 from .centerline import (Centerline, align_combined, align_manual, align_three_point, numpy_to_centerline, read_centerline_vtp,

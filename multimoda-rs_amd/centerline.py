@@ -418,7 +418,8 @@ def _align_walls(geoms: Sequence[G.FlatGeometry], anomalous: bool) -> None:
     if not anomalous or not _py_walls() or geoms[0].n_frames < 2:
         return
     from . import frames as FR
-    from . import postproc as PP
+    from .api import _checker
+    PP = _checker("postproc")
     for g in geoms:
         fr = PP.align_walls(FR.to_frames(g), True)
         h = FR.from_frames(fr, g.label, g.meta)

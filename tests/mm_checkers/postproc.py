@@ -19,8 +19,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._libm import sincos
-from .frames import Contour, Frame
+from multimoda_rs_amd._libm import sincos
+from multimoda_rs_amd.frames import Contour, Frame
 
 F64_EPS = 2.220446049250313e-16
 EXTRA_ORDER = ("eem", "calcification", "sidebranch", "catheter", "wall")     # postprocessing.rs:243-250
@@ -283,7 +283,7 @@ def smooth_batched(P: np.ndarray) -> np.ndarray:
 
 def centroids_batched(P: np.ndarray) -> np.ndarray:
     """compute_centroid (contour.rs:213-224) of F contours of equal length: sequential sums / m."""
-    from . import _native as N
+    from multimoda_rs_amd import _native as N
     F, m, _ = P.shape
     return N.contour_centroids(np.ascontiguousarray(P).reshape(F * m, 3), np.arange(F + 1, dtype=np.int64) * m)
 

@@ -12,9 +12,9 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import postproc as PP
-from .frames import Contour
-from .geometry import FlatGeometry
-from .io import EXTRA_KINDS
+from multimoda_rs_amd.frames import Contour
+from multimoda_rs_amd.geometry import FlatGeometry
+from multimoda_rs_amd.io import EXTRA_KINDS
 
 
 class _Reg:

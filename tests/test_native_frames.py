@@ -1,6 +1,6 @@
 """The bookkeeping around the searches behind the C ABI (include/mm_build.h: mm_frames_finish_within,
 mm_frames_postprocess_pair; csrc/mm_frames.cpp) against the Python implementation it replaces (api._finish_within,
-postproc.postprocess_pair / postproc_flat.postprocess_pair_regular), which restates the reference's own tests in
+tests/mm_checkers: postproc.postprocess_pair / postproc_flat.postprocess_pair_regular), which restates the reference's own tests in
 tests/test_postproc.py.  Host only; bit for bit."""
 import math
 import os
@@ -129,7 +129,8 @@ def _pair(mm, monkeypatch, fa=30, fb=26, dz_b=0.5, thick=False, shift_ref=0):
 @pytest.mark.parametrize("case", [dict(), dict(thick=True), dict(dz_b=0.8), dict(dz_b=0.3), dict(dz_b=0.3, thick=True),
                                   dict(shift_ref=7), dict(fa=12, fb=31, shift_ref=3, thick=True)])
 def test_postprocess_pair_native_equals_python(built, mm, case, monkeypatch):
-    from multimoda_rs_amd import frames as FR, native_frames as NF, postproc as PP
+    from multimoda_rs_amd import frames as FR, native_frames as NF
+    from mm_checkers import postproc as PP
     a, b, anomalous = _pair(mm, monkeypatch, **case)
     for an in (anomalous, not anomalous):
         fa, fb = PP.postprocess_pair(FR.to_frames(a), FR.to_frames(b), 0.03, an)

@@ -1,5 +1,5 @@
 """The reference's own tests for the host-side bookkeeping around the hot path, restated against
-multimoda_rs_amd.postproc / .frames (pure host code, no GPU): hole filling
+tests/mm_checkers/postproc.py on multimoda_rs_amd.frames (pure host code, no GPU): hole filling
 (align_within.rs:889-941), pair post-processing (postprocessing.rs:595-978), integrity check
 (io/integrity_check.rs:349-560), walls (processing/wall.rs has no tests of its own: properties), and
 the frame-list <-> flat conversions."""
@@ -13,7 +13,7 @@ import refgeom
 
 @pytest.fixture(scope="module")
 def PP(mm):
-    from multimoda_rs_amd import postproc
+    from mm_checkers import postproc
     return postproc
 
 
@@ -304,7 +304,7 @@ def test_flat_round_trip(mm, FR):
                  "lumen_centroids"):
         assert np.array_equal(getattr(g, name), getattr(h, name)), name
     assert h.extra is None and h.meta["aortic_thickness"] == g.meta["aortic_thickness"]
-    from multimoda_rs_amd import postproc as PP
+    from mm_checkers import postproc as PP
     PP.assign_aortic(fr)
     w = FR.from_frames(PP.create_wall_frames(fr, True), g.label, g.meta)
     assert w.meta["extra_counts"]["wall"].tolist() == [40] * 5 and w.extra.shape == (200, 3)
@@ -367,6 +367,7 @@ def test_align_walls_untwists(PP, FR):
     (True, True, True, (0, 2, 5)), (False, False, False, ()),
 ])
 def test_finish_within_batched_equals_frame_model(mm, PP, FR, with_eem, anomalous, smooth, thick):
+    from mm_checkers import api_python
     from multimoda_rs_amd import api
     from multimoda_rs_amd.io import EXTRA_KINDS
     F, m = 6, 48
@@ -381,7 +382,7 @@ def test_finish_within_batched_equals_frame_model(mm, PP, FR, with_eem, anomalou
     g.meta["aortic_thickness"] = [0.8 + 0.1 * i if i in thick else None for i in range(F)]
     g.meta["pulmonary_thickness"] = [None] * F
     a, b = g.copy(), g.copy()
-    assert api._finish_within_batched(a, anomalous, smooth) is True
+    assert api_python.finish_within_batched(a, anomalous, smooth) is True
     mm.centerline.with_lumen_centroids(b)
     fr = FR.to_frames(b)
     if anomalous:
@@ -399,7 +400,7 @@ def test_finish_within_batched_equals_frame_model(mm, PP, FR, with_eem, anomalou
     # irregular geometries fall back
     c = g.copy()
     c.meta["extra_counts"]["calcification"] = np.ones(F, dtype=np.int64)
-    assert api._finish_within_batched(c, anomalous, smooth) is False
+    assert api_python.finish_within_batched(c, anomalous, smooth) is False
 
 
 # ---- the flat fast path of postprocess_geom_pair equals the frame-list one ---------------------------
@@ -442,7 +443,7 @@ def _regular_geom(mm, F, m, seed, z0, dz, ref_at, with_eem, with_wall, thick, ro
     dict(Fa=4, Fb=4, ra=1, rb=1, anomalous=True, eem=True, wall=True, thick_a=(0, 1, 2, 3), thick_b=(), lc=False),
 ])
 def test_postprocess_pair_flat_equals_frame_model(mm, PP, FR, case):
-    from multimoda_rs_amd.postproc_flat import postprocess_pair_regular
+    from mm_checkers.postproc_flat import postprocess_pair_regular
     m = 48
     a = _regular_geom(mm, case["Fa"], m, 11, 0.0, 0.5, case["ra"], case["eem"], case["wall"], case["thick_a"],
                       roll=case.get("roll", 0), lc=case.get("lc", True))

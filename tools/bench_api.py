@@ -22,6 +22,30 @@ ge.build()
 import multimoda_rs_amd as mm  # noqa: E402
 
 
+def retain_heap(mmap_threshold: int = 32 << 20, trim_threshold: int = 1 << 30, top_pad: int = 64 << 20) -> bool:
+    """Opt-in allocator policy for processes that call the entry points repeatedly (glibc only; returns False elsewhere).
+
+    One `from_array_full` on 4 x 512 frames returns ~100 MB of arrays and builds ~50 MB of intermediates.  With glibc's
+    defaults every array above 128 KB is its own mmap: freeing the previous call's results unmaps them (3-5 ms on the
+    config3 shape) and the next call page-faults the same memory in again.  This sets M_MMAP_THRESHOLD (blocks up to
+    32 MB come from the heap), M_TRIM_THRESHOLD and M_TOP_PAD (the heap is not handed back between calls), process-wide:
+    the memory of freed results stays with the process.  Nothing in the library depends on it."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        mallopt = libc.mallopt
+    except (OSError, AttributeError):
+        return False
+    M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD = -1, -2, -3
+    ok = mallopt(M_MMAP_THRESHOLD, int(mmap_threshold)) == 1
+    ok = (mallopt(M_TRIM_THRESHOLD, int(trim_threshold)) == 1) and ok
+    ok = (mallopt(M_TOP_PAD, int(top_pad)) == 1) and ok
+    return bool(ok)
+
+
+_POOL = None
+
+
 def input_data(g, label, diastole):
     """The (N, 4) [frame, x, y, z] array contract of numpy_to_inputdata from a synthetic pullback."""
     F = g.n_frames
@@ -39,10 +63,10 @@ def main():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--stages", action="store_true", help="per-stage wall times of one call (MM_API_TRACE)")
-    ap.add_argument("--retain-heap", action="store_true", help="call mm.retain_heap() first (see its docstring)")
+    ap.add_argument("--retain-heap", action="store_true", help="call retain_heap() first (see its docstring)")
     a = ap.parse_args()
     if a.retain_heap:
-        print("retain_heap:", mm.retain_heap(), file=sys.stderr)
+        print("retain_heap:", retain_heap(), file=sys.stderr)
     base = mm.synthetic_case(a.frames, 501)
     data = [input_data(g, lab, dia) for g, lab, dia in zip(base, ("rest", "rest", "stress", "stress"), (True, False, True, False))]
     eng = mm.Engine()
