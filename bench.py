@@ -224,7 +224,7 @@ def committed_pmc(workload, precision):
     FETCH_SIZE can under-report wide streaming reads by up to 2x; these are dword loads, uncalibrated) and the quantity
     that actually saturates: VALU issue.  None where no matching profile is committed."""
     names = {("config3", "fast"): ["r3_config3_fast_pmc_summary.csv", "r2_config3_fast_pmc_summary.csv"],
-             ("config3", "matrix"): ["r3_config3_matrix_pmc_summary.csv"],
+             ("config3", "matrix"): ["r4_config3_matrix_pmc_summary.csv", "r3_config3_matrix_pmc_summary.csv"],
              ("config3", "f32"): ["r1_config3_pmc_summary.csv"]}.get((workload, precision), [])
     if not names and workload != "config3":
         # same kernel, same set size (N = 521), other frame / candidate counts: the per-candidate figures carry over
@@ -238,7 +238,7 @@ def committed_pmc(workload, precision):
         return None
     import csv
     val, dur, grid = {}, {}, 0
-    for r in csv.DictReader(open(path)):
+    for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):
         if r["kernel"].startswith(("k_screen_mx",) if precision == "matrix" else ("k_screen_fast", "k_search<float")):
             g = int(r["grid_threads"])
             if g >= grid:
