@@ -73,6 +73,12 @@ enum {
                              Chosen per PAIR for sets of 64 .. 2048 points on either side (the reference's sample_size /
                              n_points are user kwargs, binding/functions.rs:144-167); a pair outside that range takes the
                              packed-FMA or the direct-form screen, the other pairs of its batch are not affected   */
+    /* CAUTION (round 4, MI355X): the kernels of MM_PRECISION_F32 and MM_PRECISION_F32_FAST -- packed-FMA vector code --
+     * returned WRONG screened values in 3 - 15 % of the calls while a kernel that executes MFMAs (this library's matrix-pipe
+     * screen on another stream, or any MFMA loop of another process) ran on the chip at the same time; the matrix-pipe
+     * kernels, the exact f64 kernels and the small per-pair kernels did not.  Cause unknown (profiles/README.md, tools/
+     * probe_mfma_interference.py).  Under MM_PRECISION_F32_MATRIX, _BOUNDED and _F64 every value that decides a result comes
+     * from an MFMA or an f64 kernel; they are the defaults of every layer above this header. */
 };
 
 /* flags of one search */

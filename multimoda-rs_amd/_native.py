@@ -723,7 +723,7 @@ class Engine:
         return out, int(fm.value)
 
     # -- one search ------------------------------------------------------------------
-    def best_rotation(self, ref, tgt, angles, centre, skip_zero=True, precision=MM_PRECISION_F32,
+    def best_rotation(self, ref, tgt, angles, centre, skip_zero=True, precision=MM_PRECISION_F32_MATRIX,
                       return_costs=False):
         ref, tgt = _xy(ref), _xy(tgt)
         rx, ry = _f64(ref[:, 0]), _f64(ref[:, 1])
@@ -740,7 +740,7 @@ class Engine:
         return bi.value, ba.value, bc.value
 
     # -- batch -----------------------------------------------------------------------
-    def best_rotation_batch(self, batch: Batch, precision=MM_PRECISION_F32, return_costs=False):
+    def best_rotation_batch(self, batch: Batch, precision=MM_PRECISION_F32_MATRIX, return_costs=False):
         n = batch.n_pairs
         bidx = np.full(n, -1, dtype=np.int32)
         bang = np.zeros(n, dtype=np.float64)
@@ -754,7 +754,7 @@ class Engine:
             out["costs"] = costs
         return out
 
-    def plan(self, batch: Batch, precision=MM_PRECISION_F32, angle_begin=0, angle_end=2**31 - 1) -> "Plan":
+    def plan(self, batch: Batch, precision=MM_PRECISION_F32_MATRIX, angle_begin=0, angle_end=2**31 - 1) -> "Plan":
         return Plan(self, batch, precision, angle_begin, angle_end)
 
 

@@ -404,6 +404,9 @@ def _full(geoms, step, rng, smooth, bruteforce, sample_size, engine, both_batche
     return (*out, tuple(logs))
 
 
+_POOL = None
+
+
 def _pool():
     """One small thread pool for the per-pullback / per-pair host work of the entry points (the reference uses crossbeam
     scopes of 4 and 2 threads, entry.rs:140-290); created once -- starting and joining one per call costs a millisecond."""

@@ -24,7 +24,7 @@ class ShiftRotationSearch:
     """Stage once (point sets resident in HBM), run many times."""
 
     def __init__(self, engine: N.Engine, geoms: Sequence[G.FlatGeometry], shift_lo: int, shift_hi: int,
-                 step_deg: float, range_deg: float, sample_size: int, precision: int = N.MM_PRECISION_F32_FAST,
+                 step_deg: float, range_deg: float, sample_size: int, precision: int = N.MM_PRECISION_F32_MATRIX,
                  want_costs: bool = False):
         self.angles, deg, _ = N.search_angles(step_deg, range_deg)
         if deg:

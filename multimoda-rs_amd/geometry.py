@@ -210,7 +210,7 @@ class FlatGeometry:
 # drivers (host orchestration lives in C++: csrc/mm_host.cpp)
 # --------------------------------------------------------------------------------------
 def align_within(engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: float, range_deg: float,
-                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32, mode: int = 0):
+                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32_MATRIX, mode: int = 0):
     """``align_frames_in_geometry`` lines 24-134 (align_within.rs) for several pullbacks in
     lockstep; geometries are updated in place.  Returns (logs per geometry as 7-tuples
     ``(id, matched_to, rot_deg, tx, ty, cx, cy)`` -- binding/functions.rs:26-40, pose_evals)."""
@@ -233,7 +233,7 @@ class WithinPlan:
     Same results as :func:`align_within`; a plan runs once."""
 
     def __init__(self, engine: N.Engine, geoms: Sequence[FlatGeometry], step_deg: float, range_deg: float,
-                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32, shard=None):
+                 bruteforce: bool, sample_size: int, precision: int = N.MM_PRECISION_F32_MATRIX, shard=None):
         """shard = (rank, world): this plan owns the share [n*rank/world, n*(rank+1)/world) of every candidate
         list from the start (same as set_shard afterwards, without staging level 0 twice).
         shard = (rank, pair_blocks, cand_slices): a tile of the (frame pair x candidate) grid
@@ -430,7 +430,7 @@ class WithinPlan:
 
 
 def align_between(engine: N.Engine, pairs: Sequence[Sequence[FlatGeometry]], rot_deg: float, step_rot_deg: float,
-                  sample_size: int, precision: int = N.MM_PRECISION_F32):
+                  sample_size: int, precision: int = N.MM_PRECISION_F32_MATRIX):
     """``align_between_geometries`` (align_between.rs:11-68) for independent (a, b) pairs; every
     b is moved onto its a in place.  Returns (best rotations in radians, pose_evals)."""
     P = len(pairs)

@@ -43,7 +43,6 @@ def retain_heap(mmap_threshold: int = 32 << 20, trim_threshold: int = 1 << 30, t
     return bool(ok)
 
 
-_POOL = None
 
 
 def input_data(g, label, diastole):
