@@ -883,6 +883,34 @@ def test_matrix_screen_chooses_per_pair(engine, oracle, mm):
     assert took == {"direct_f32": 0, "packed_fma": 0, "matrix": 4 * n, "matrix_blocks": n, "exact_f64": 2 * n}, took
 
 
+@pytest.mark.parametrize("matrix", [False, True])
+@pytest.mark.parametrize("na,nb", [(64, 64), (223, 223), (521, 521), (300, 521), (521, 97), (528, 528)])
+def test_lower_bounds_never_exceed_the_exact_cost(engine, oracle, mm, na, nb, matrix):
+    """The bound kernels themselves (test hook mm_lower_bounds: the first round's bound for EVERY candidate of one search),
+    packed-FMA (k_screen_lb) and matrix pipe (k_bound_mx): a bound never exceeds the exact squared cost by more than the
+    kernel's e2 and delta allow -- whatever subset of points the queries are -- and, with the numpy bound of the same
+    queries in hand, it IS that bound up to the same error: a bound that is merely valid (0.0, as the first k_bound_mx
+    returned: minima folded behind an MFMA without its wait states) would pass the first check and fail this one."""
+    rng = np.random.default_rng(77 + na * 3 + nb)
+    ref, tgt = blob(rng, na), blob(rng, nb) + rng.normal(0, 0.03, (nb, 2))
+    c = tgt.mean(axis=0)
+    ref, tgt = ref - c, tgt - c
+    angles, _, _ = mm.search_angles(3.0, 180.0)
+    lb, e2, delta, stride = engine.lower_bounds(ref, tgt, angles, (0.0, 0.0), matrix=matrix)
+    oc = oracle.costs_over_angles(ref, tgt, angles, 0.0, 0.0)
+    assert np.all(np.sqrt(np.maximum(lb - e2, 0.0)) - delta <= oc), "a lower bound above the exact cost"
+    qa, want = ref[::stride], []
+    for th in angles:
+        cs, sn = np.cos(th), np.sin(th)
+        rt = np.stack([tgt[:, 0] * cs - tgt[:, 1] * sn, tgt[:, 0] * sn + tgt[:, 1] * cs], 1)
+        d1 = ((qa[:, None, :] - rt[None, :, :]) ** 2).sum(2).min(1).max()
+        d2 = ((rt[::stride][:, None, :] - ref[None, :, :]) ** 2).sum(2).min(1).max()
+        want.append(max(d1, d2))
+    rho = np.hypot(ref[:, 0], ref[:, 1]).max() + np.hypot(tgt[:, 0], tgt[:, 1]).max()
+    assert np.abs(lb - np.array(want)).max() <= e2 + 2 * delta * rho + 1e-12, "not the bound of its queries"
+    assert (lb / np.maximum(oc ** 2, 1e-30)).mean() > 0.8          # every stride-th point: within a few per cent of H^2 on smooth contours
+
+
 def test_matrix_screen_small_batches_fill_the_workgroup(engine, oracle, mm):
     """a single search of 361 candidates used to get one candidate per 256-thread workgroup (three of four waves
     idle); now at least four.  Same result at 1, 3, 4, 5 and 361 candidates."""
