@@ -28,6 +28,20 @@ __global__ void __launch_bounds__(256, 2) aggressor_valu(float* out, int iters)
     }
     if (x + y + z + w == 123.0f) out[0] = x;
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256, 2) aggressor_pk(float* out, int iters)     // mode 3: packed FMAs at full rate, no MFMA
+{
+    v2f x[8];
+    for (int k = 0; k < 8; ++k) x[k] = (v2f){(float)threadIdx.x + k, 1.0f + k};
+    const v2f a = {0.5f, 0.25f}, b = {1.0f, 2.0f};
+    for (int i = 0; i < iters * 4; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = __builtin_elementwise_fma(x[k], a, b);
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    }
+    float t = 0; for (int k = 0; k < 8; ++k) t += x[k].x + x[k].y;
+    if (t == 123.0f) out[0] = t;
+}
 int main(int argc, char** argv)
 {
     const double secs = argc > 1 ? atof(argv[1]) : 20.0;
@@ -35,7 +49,8 @@ int main(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     long n = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
-        if (argc > 2 && atoi(argv[2]) == 2) hipLaunchKernelGGL(aggressor_valu, dim3(256 * 2), dim3(256), 0, 0, out, 20000);
+        if (argc > 2 && atoi(argv[2]) == 3) hipLaunchKernelGGL(aggressor_pk, dim3(256 * 8), dim3(256), 0, 0, out, 20000);
+        else if (argc > 2 && atoi(argv[2]) == 2) hipLaunchKernelGGL(aggressor_valu, dim3(256 * 2), dim3(256), 0, 0, out, 20000);
         else hipLaunchKernelGGL(aggressor, dim3(256 * 2), dim3(256), 0, 0, out, 20000);
         hipDeviceSynchronize(); ++n;
     }
