@@ -399,6 +399,14 @@ int  mm_within_plan_create_grid(mm_engine* e, int n_geoms, mm_geometry** geoms,
                                 double step_deg, double range_deg, int bruteforce, int64_t sample_size,
                                 int precision, int rank, int pair_blocks, int cand_slices, mm_within_plan** out);
 int  mm_within_plan_set_shard_grid(mm_within_plan* p, int rank, int pair_blocks, int cand_slices);
+/* Staging follows the tile: a plan CREATED on a tile with pair_blocks > 1 copies to the device, and builds search sets
+ * of, only the frames its pair block reads (frames i-1 and i of its jobs: its share of the pullbacks plus one halo
+ * frame per boundary) -- 1 / pair_blocks of the host-side copy, the PCIe transfer and the pool.  Its tolerance (tol of
+ * mm_within_plan_dims) is then defined for its own jobs only and reported as 0 for the others; a host-side merge takes
+ * the largest over the ranks (the device-side exchange already uses the owner's).  Moving such a plan to another pair
+ * block with mm_within_plan_set_shard_grid stages that block's frames again.
+ *   mm_within_plan_staged   raw contour points copied to the device / points in the plan's set pool */
+int  mm_within_plan_staged(mm_within_plan* p, int64_t* raw_points, int64_t* set_points);
 /* mm_within_plan_walk for SOME of the plan's pullbacks: take[g] != 0 (n_geoms bytes).  After a sharded search every rank
  * holds every winner, so the chain walks -- pure host work, one pullback independent of the other (entry.rs:140-203: four
  * threads) -- need not be repeated on every rank: rank r walks the pullbacks g with g mod world == r and broadcasts their

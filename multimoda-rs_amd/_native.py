@@ -42,7 +42,7 @@ EXPORTS = [
     "mm_shard_grid", "mm_within_plan_create_grid", "mm_within_plan_set_shard_grid", "mm_comm_unique_id", "mm_comm_init_rank",
     "mm_comm_destroy", "mm_comm_rank", "mm_comm_world", "mm_comm_version", "mm_comm_all_reduce_min_f64",
     "mm_comm_all_reduce_min_i64", "mm_within_plan_search_sharded", "mm_within_plan_run_sharded",
-    "mm_within_plan_search_sharded_begin", "mm_engine_wait_exchange", "mm_within_plan_set_timing_rehearsal", "mm_within_plan_walk_geoms", "mm_comm_broadcast",
+    "mm_within_plan_search_sharded_begin", "mm_engine_wait_exchange", "mm_within_plan_set_timing_rehearsal", "mm_within_plan_walk_geoms", "mm_comm_broadcast", "mm_within_plan_staged",
 ]
 # include/mm_centerline.h
 EXPORTS_CENTERLINE = [
@@ -261,6 +261,8 @@ def lib():
     L.mm_within_plan_destroy.argtypes = [P]
     L.mm_within_plan_set_shard.restype = I
     L.mm_within_plan_set_shard.argtypes = [P, I, I]
+    L.mm_within_plan_staged.restype = I
+    L.mm_within_plan_staged.argtypes = [P, C.POINTER(I64), C.POINTER(I64)]
     L.mm_within_plan_dims.restype = I
     L.mm_within_plan_dims.argtypes = [P, C.POINTER(I32), C.POINTER(I32), P]
     L.mm_shard_grid.restype = I

@@ -289,6 +289,16 @@ struct WithinPlan {
     // this plan's tile of the (frame pair x candidate) grid: world = grid_p * grid_c ranks, rank = pair block
     // rank / grid_c, candidate slice rank % grid_c (grid_p = 1: the pure candidate-axis split)
     int rank = 0, world = 1, grid_p = 1, grid_c = 1;
+    // what build_sets_device staged: every frame, or (a plan created on a tile with several pair blocks) only the frames
+    // block sets_pb of sets_gp reads -- the other sets are empty and their pairs trivial with an empty slice
+    bool sets_partial = false;
+    int sets_pb = 0, sets_gp = 1;
+    int64_t staged_points = 0;
+    bool owns(int j) const
+    {
+        const int64_t J = (int64_t)job_geom.size(), pb = rank / grid_c;
+        return (int64_t)j >= J * pb / grid_p && (int64_t)j < J * (pb + 1) / grid_p;
+    }
     bool searched = false;
     int launched_level = -1;          // level most recently enqueued by level_launch
     // exchange records of search_sharded (device; from the engine's blob cache)
@@ -310,6 +320,7 @@ struct WithinPlan {
     int prepare();
     int build_sets_host(int32_t n_sets);
     int build_sets_device(int32_t n_sets);
+    int restage_sets();
     int level_launch(size_t l);
     int level_local(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
     int level_collect(size_t l, double* cost, int32_t* uniform, double* angle, int32_t* idx, int32_t* active);
@@ -379,12 +390,28 @@ int WithinPlan::build_sets_device(int32_t n_sets)
     std::vector<SetSrc> src((size_t)n_sets);
     std::vector<int32_t> lens((size_t)n_sets);
     std::vector<int64_t> lum_base(n_geoms), cath_base(n_geoms);
+    // The frames this rank's tile reads: frames i-1 and i of every job (g, i) of its pair block -- a contiguous run of
+    // frames per geometry.  With one pair block (and on a plan that may still be re-tiled) that is every frame.
+    std::vector<int32_t> f0(n_geoms, 0), f1(n_geoms, -1);
+    sets_partial = grid_p > 1; sets_gp = grid_p; sets_pb = rank / grid_c;
+    if (sets_partial) {
+        for (int g = 0; g < n_geoms; ++g) f0[g] = INT32_MAX;
+        for (int j = 0; j < (int)job_geom.size(); ++j)
+            if (owns(j)) {
+                const int g = job_geom[j];
+                f0[g] = std::min(f0[g], job_frame[j] - 1); f1[g] = std::max(f1[g], job_frame[j]);
+            }
+    } else {
+        for (int g = 0; g < n_geoms; ++g) f1[g] = geoms[g]->n_frames - 1;
+    }
     int64_t raw_pts = 0;
-    for (int g = 0; g < n_geoms; ++g) {
+    for (int g = 0; g < n_geoms; ++g) {       // the bases are those of frame 0, so that base + off[i] addresses frame i
         const mm_geometry* G = geoms[g];
-        lum_base[g] = raw_pts; raw_pts += G->lumen_off[G->n_frames];
         const bool hc = spec[g].has_cath && G->cath_off;
-        cath_base[g] = raw_pts; if (hc) raw_pts += G->cath_off[G->n_frames];
+        lum_base[g] = cath_base[g] = 0;
+        if (f1[g] < f0[g]) continue;
+        lum_base[g] = raw_pts - G->lumen_off[f0[g]]; raw_pts += G->lumen_off[f1[g] + 1] - G->lumen_off[f0[g]];
+        if (hc) { cath_base[g] = raw_pts - G->cath_off[f0[g]]; raw_pts += G->cath_off[f1[g] + 1] - G->cath_off[f0[g]]; }
     }
     for (int g = 0; g < n_geoms; ++g) {
         const mm_geometry* G = geoms[g];
@@ -394,6 +421,12 @@ int WithinPlan::build_sets_device(int32_t n_sets)
             const int64_t ll = G->lumen_off[i + 1] - G->lumen_off[i], cl = hc ? G->cath_off[i + 1] - G->cath_off[i] : 0;
             if (ll < 0 || cl < 0 || ll > INT32_MAX || cl > INT32_MAX || spec[g].lumen > INT32_MAX || spec[g].cath > INT32_MAX)
                 return set_error(MM_ERR_INVALID, "contour too long");
+            if (i < f0[g] || i > f1[g]) {       // not read by this tile: an empty set
+                d = SetSrc{};
+                d.lum_take = d.cath_take = 1;
+                lens[(size_t)(set_base[g] + i)] = 0;
+                continue;
+            }
             d.lum_at = lum_base[g] + G->lumen_off[i];
             d.cath_at = hc ? cath_base[g] + G->cath_off[i] : 0;
             d.lum_len = (int32_t)ll; d.lum_take = (int32_t)spec[g].lumen;
@@ -403,6 +436,7 @@ int WithinPlan::build_sets_device(int32_t n_sets)
             lens[(size_t)(set_base[g] + i)] = d.n;
         }
     }
+    staged_points = raw_pts;
     TraceTimer t_alloc("prepare:   descriptors + pool");
     int rc = plan.alloc_pool(e, lens, /*transient=*/false);
     if (rc) return rc;
@@ -428,8 +462,13 @@ int WithinPlan::build_sets_device(int32_t n_sets)
         };
         for (int g = 0; g < n_geoms; ++g) {
             const mm_geometry* G = geoms[g];
-            add(G->lumen, lum_base[g], G->lumen_off[G->n_frames]);
-            if (spec[g].has_cath && G->cath_off) add(G->cath, cath_base[g], G->cath_off[G->n_frames]);
+            if (f1[g] < f0[g]) continue;
+            const int64_t l0 = G->lumen_off[f0[g]], l1 = G->lumen_off[f1[g] + 1];
+            add(G->lumen + 3 * l0, lum_base[g] + l0, l1 - l0);
+            if (spec[g].has_cath && G->cath_off) {
+                const int64_t c0 = G->cath_off[f0[g]], c1 = G->cath_off[f1[g] + 1];
+                add(G->cath + 3 * c0, cath_base[g] + c0, c1 - c0);
+            }
         }
         parallel_for((int)pieces.size(), [&](int k) { std::memcpy(h + pieces[(size_t)k].at, pieces[(size_t)k].from, pieces[(size_t)k].bytes); });
         std::memcpy(h + o_src, src.data(), (size_t)n_sets * sizeof(SetSrc));
@@ -449,11 +488,30 @@ int WithinPlan::build_sets_device(int32_t n_sets)
     const double *h_rho2 = (const double*)(h + o_out), *h_scale = h_rho2 + n_sets;
     for (int32_t s = 0; s < n_sets; ++s) plan.set_rho[(size_t)s] = std::sqrt(h_rho2[s]) * (1.0 + 1e-12);
     for (int g = 0; g < n_geoms; ++g) {
-        double scale = 0.0;
-        for (int32_t i = 0; i < geoms[g]->n_frames; ++i) scale = std::max(scale, h_scale[set_base[g] + i]);
-        eps[g] = std::ldexp(4.0 * scale + 1.0, -42);   // chain-state coordinates stay within |frame-0 centroid| + radius
+        double scale = 0.0, rho = 0.0;
+        for (int32_t i = 0; i < geoms[g]->n_frames; ++i) {
+            scale = std::max(scale, h_scale[set_base[g] + i]);
+            rho = std::max(rho, plan.set_rho[(size_t)(set_base[g] + i)]);
+        }
+        // chain-state coordinates stay within |frame-0 centroid| + radius.  A tile that staged only its own frames has
+        // not seen frame 0: it adds that bound explicitly (the ranks of one pair block hold the same frames and so the
+        // same eps; a job's tolerance is its owners', mm_within_plan_dims reports 0 for the others)
+        if (sets_partial)
+            scale = std::max(scale, std::max(std::fabs(geoms[g]->centroid[0]), std::fabs(geoms[g]->centroid[1])) + rho);
+        eps[g] = std::ldexp(4.0 * scale + 1.0, -42);
     }
     return MM_OK;
+}
+
+// The sets again, for the tile the plan has been moved to (mm_within_plan_set_shard_grid on a plan that staged one pair
+// block's frames).
+int WithinPlan::restage_sets()
+{
+    hipError_t he = hipStreamSynchronize(e->aux);
+    if (he == hipSuccess) he = hipStreamSynchronize(plan.stream);
+    if (he != hipSuccess) return hip_error(he, "restage_sets");
+    if (plan.pts_blob && plan.own_pts) { e->blob_release(plan.pts_blob, plan.pts_cap); plan.pts_blob = nullptr; }
+    return build_sets_device(set_base[n_geoms]);
 }
 
 int WithinPlan::prepare()
@@ -527,8 +585,8 @@ void WithinPlan::build_level_pairs(size_t l, const std::vector<double>& centres,
         PairSpec sp{sid - 1, sid, 0.0, 0.0, MM_SEARCH_SKIP_ZERO, lp, ln, 2.0 * eps[g], eps[g]};
         // this rank's tile: the jobs of its pair block, and of their lists its slice of the candidate axis; a job of
         // another block keeps its place in the level (every rank commits every job) with an empty slice
-        const int pb = rank / grid_c, cs = rank % grid_c;
-        const bool mine = (int64_t)j >= (int64_t)J * pb / grid_p && (int64_t)j < (int64_t)J * (pb + 1) / grid_p;
+        const int cs = rank % grid_c;
+        const bool mine = owns(j);
         sp.slice_begin = mine ? (int32_t)((int64_t)ln * cs / grid_c) : 0;
         sp.slice_end = mine ? (int32_t)((int64_t)ln * (cs + 1) / grid_c) : 0;
         pairs.push_back(sp);
@@ -1281,6 +1339,11 @@ int mm_within_plan_set_shard_grid(mm_within_plan* h, int rank, int pair_blocks, 
     if (int drc = select_device(wp->e)) return drc;
     if (rank != wp->rank || pair_blocks != wp->grid_p || cand_slices != wp->grid_c) {
         wp->rank = rank; wp->world = world; wp->grid_p = pair_blocks; wp->grid_c = cand_slices; wp->level0_staged = false;
+        // a plan created on a tile holds that pair block's frames only: another block needs its own (a plan created
+        // unsharded holds every frame and is re-tiled in place)
+        if (wp->sets_partial && (pair_blocks != wp->sets_gp || rank / cand_slices != wp->sets_pb)) {
+            if (int rc = wp->restage_sets()) return rc;
+        }
         if (wp->level0_ok) {  // re-stage level 0 for the new slice now, not inside the search
             wp->build_level_pairs(0, std::vector<double>(), std::vector<uint8_t>(wp->job_geom.size(), 1), wp->lvl_pairs,
                                   wp->lvl_active, nullptr);
@@ -1292,6 +1355,15 @@ int mm_within_plan_set_shard_grid(mm_within_plan* h, int rank, int pair_blocks, 
     return MM_OK;
 }
 
+int mm_within_plan_staged(mm_within_plan* h, int64_t* raw_points, int64_t* set_points)
+{
+    WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
+    if (!wp) return set_error(MM_ERR_INVALID, "within plan == NULL");
+    if (raw_points) *raw_points = wp->staged_points;
+    if (set_points) *set_points = wp->plan.n_points;
+    return MM_OK;
+}
+
 int mm_within_plan_dims(mm_within_plan* h, int32_t* n_jobs, int32_t* n_levels, double* tol)
 {
     WithinPlan* wp = reinterpret_cast<WithinPlan*>(h);
@@ -1299,7 +1371,9 @@ int mm_within_plan_dims(mm_within_plan* h, int32_t* n_jobs, int32_t* n_levels, d
     const int J = (int)wp->job_geom.size();
     if (n_jobs) *n_jobs = J;
     if (n_levels) *n_levels = (int32_t)wp->levels.size();
-    if (tol) for (int j = 0; j < J; ++j) tol[j] = 2.0 * wp->eps[wp->job_geom[j]];
+    // (a plan that staged only its pair block's frames knows the tolerance of its own jobs only: 0 for the others, the
+    // exchange takes a job's tolerance from its owners -- distributed.merge_level)
+    if (tol) for (int j = 0; j < J; ++j) tol[j] = (wp->sets_partial && !wp->owns(j)) ? 0.0 : 2.0 * wp->eps[wp->job_geom[j]];
     return MM_OK;
 }
 

@@ -146,13 +146,19 @@ def merge_level(local: Dict[str, np.ndarray], tol: Optional[np.ndarray], group=N
     if world == 1:
         return merge_shards(1, local["cost"], local["uniform"], local["angle"], local["idx"], tol)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    # one packed f64 record per pair: [cost, angle, idx, uniform] (idx/uniform are small ints: exact in f64)
+    # one packed f64 record per pair: [cost, angle, idx, uniform, tol] (idx/uniform are small ints: exact in f64).
+    # The tolerance travels with the record: a rank that staged only its pair block's frames knows the tolerance of its
+    # own jobs (0 for the others, mm_within_plan_staged), the owners of a job agree on it -- every rank merges with the
+    # largest.
+    n = len(local["cost"])
+    tol_row = np.zeros(n, dtype=np.float64) if tol is None else np.asarray(tol, dtype=np.float64)
     rec = torch.from_numpy(np.stack([local["cost"], local["angle"], local["idx"].astype(np.float64),
-                                     local["uniform"].astype(np.float64)], axis=0)).to(dev)
+                                     local["uniform"].astype(np.float64), tol_row], axis=0)).to(dev)
     gathered = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(gathered, rec, group=group)
-    g = torch.stack(gathered, dim=0).cpu().numpy()     # [world, 4, n]
-    return merge_shards(world, g[:, 0, :], g[:, 3, :].astype(np.int32), g[:, 1, :], g[:, 2, :].astype(np.int32), tol)
+    g = torch.stack(gathered, dim=0).cpu().numpy()     # [world, 5, n]
+    tol_all = None if tol is None else g[:, 4, :].max(axis=0)
+    return merge_shards(world, g[:, 0, :], g[:, 3, :].astype(np.int32), g[:, 1, :], g[:, 2, :].astype(np.int32), tol_all)
 
 
 # ------------------------------------------------------------------------------------------

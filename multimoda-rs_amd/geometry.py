@@ -306,8 +306,16 @@ class WithinPlan:
         N.check(N.lib().mm_within_plan_search_sharded(self._h, comm.handle), "mm_within_plan_search_sharded")
         self._begun = False
 
+    def staged(self):
+        """(raw contour points copied to the device, points in the plan's set pool) -- ``mm_within_plan_staged``: a plan
+        created on a tile with several pair blocks stages its own block's frames only."""
+        raw, pts = C.c_int64(0), C.c_int64(0)
+        N.check(N.lib().mm_within_plan_staged(self._h, C.byref(raw), C.byref(pts)), "mm_within_plan_staged")
+        return int(raw.value), int(pts.value)
+
     def dims(self):
-        """(n_jobs, n_levels, per-job tie tolerance)."""
+        """(n_jobs, n_levels, per-job tie tolerance; 0 for the jobs of another pair block on a plan that staged only its
+        own block's frames)."""
         nj, nl = C.c_int32(0), C.c_int32(0)
         N.check(N.lib().mm_within_plan_dims(self._h, C.byref(nj), C.byref(nl), None), "mm_within_plan_dims")
         tol = np.zeros(nj.value, dtype=np.float64)

@@ -23,20 +23,41 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision, exchange="gather", grid=None):
+def drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision, exchange="gather", grid=None,
+                  on_tile=False, moved=False):
     """Run `world` shard plans in lockstep; returns per rank (geoms, logs, evals, unresolved).
     grid = (pair_blocks, cand_slices) with pair_blocks * cand_slices == world: tiles of the (frame pair x candidate)
-    grid (mm_within_plan_set_shard_grid); None = the pure candidate-axis split (set_shard)."""
+    grid (mm_within_plan_set_shard_grid); None = the pure candidate-axis split (set_shard).
+    on_tile: the plans are CREATED on their tiles (mm_within_plan_create_grid), which stages only the frames of the tile's
+    pair block; moved: created on the NEXT rank's tile and then moved to their own (the frames are staged again)."""
     from multimoda_rs_amd import distributed as D
     cases = [[g.copy() for g in base] for _ in range(world)]
-    plans = [mm.WithinPlan(engine, cases[r], step, rng_deg, bruteforce, ss, precision=precision) for r in range(world)]
-    for r, p in enumerate(plans):
-        if grid is None:
-            p.set_shard(r, world)
+    if on_tile:
+        assert grid is not None and grid[0] * grid[1] == world
+        plans = [mm.WithinPlan(engine, cases[r], step, rng_deg, bruteforce, ss, precision=precision,
+                               shard=((r + 1) % world if moved else r, grid[0], grid[1])) for r in range(world)]
+        full = sum(int(g.lumen_off[-1]) + (int(g.cath_off[-1]) if g.cath_off is not None else 0) for g in base)
+        if moved:
+            for r, p in enumerate(plans):
+                p.set_shard_grid(r, grid[0], grid[1])
+        raw = [p.staged()[0] for p in plans]
+        if grid[0] > 1:
+            assert max(raw) < full                         # nobody staged every frame ...
+            assert sum(raw[::grid[1]]) >= full             # ... and the pair blocks cover them (with their halo frames)
         else:
-            assert grid[0] * grid[1] == world
-            p.set_shard_grid(r, grid[0], grid[1])
+            assert raw == [full] * world
+    else:
+        plans = [mm.WithinPlan(engine, cases[r], step, rng_deg, bruteforce, ss, precision=precision) for r in range(world)]
+        for r, p in enumerate(plans):
+            if grid is None:
+                p.set_shard(r, world)
+            else:
+                assert grid[0] * grid[1] == world
+                p.set_shard_grid(r, grid[0], grid[1])
     n_jobs, n_levels, tol = plans[0].dims()
+    for p in plans[1:]:                        # a job's tolerance is its owners' (0 from a plan that did not stage it)
+        tol = np.maximum(tol, p.dims()[2])
+    assert (tol > 0).all()
     if exchange == "gather":
         for l in range(n_levels):
             loc = [p.level_local(l, n_jobs) for p in plans]
@@ -108,6 +129,40 @@ def test_grid_sharded_within_plan_equals_single_rank_and_oracle(engine, oracle, 
                                                        exchange, grid=grid):
             evals0 = evals if evals0 is None else evals0
             assert evals == evals0 and unres == 0
+            for k in range(len(base)):
+                assert logs[k] == ologs[k]
+                assert geoms_equal(geoms[k], ogeoms[k])
+    finally:
+        engine.set_bound_min_candidates(16384)
+
+
+@pytest.mark.parametrize("exchange", ["gather", "device"])
+@pytest.mark.parametrize("precision", [2, 4])
+@pytest.mark.parametrize("grid,moved", [((1, 2), False), ((2, 1), False), ((2, 2), False), ((4, 2), False), ((8, 1), False),
+                                        ((27, 1), False), ((32, 1), False), ((3, 2), True), ((27, 1), True)])
+@pytest.mark.parametrize("bruteforce,step,rng_deg,ss", CASES[:2])
+def test_plans_created_on_their_tile_stage_their_frames_only(engine, oracle, mm, bruteforce, step, rng_deg, ss, grid, moved,
+                                                             precision, exchange):
+    """mm_within_plan_create_grid with several pair blocks: each plan copies and builds only the frames its pair block
+    reads (its jobs' frames i-1 and i), the other sets are empty -- same logs and coordinates as the oracle on every
+    rank.  The pullbacks sit away from the origin, so the tolerance (derived from the coordinates' magnitude) of a plan
+    that has not seen frame 0 matters."""
+    engine.set_bound_min_candidates(0)
+    try:
+        world = grid[0] * grid[1]
+        base = [mm.synthetic_pullback(f, 501, pullback_id=i) for i, f in enumerate((9, 6, 9, 7))]
+        for k, g in enumerate(base):
+            shift = np.array([37.5 * (k + 1), -12.25 * (k + 2), 0.0])
+            g.lumen[:] += shift; g.centroids[:] += shift
+            if g.cath is not None:
+                g.cath[:] += shift
+            if g.ref is not None:
+                g.ref[:] += shift
+        ogeoms = [to_oracle(oracle, g) for g in base]
+        ologs = [oracle.align_within_chain(o, step, rng_deg, bruteforce, ss, n_threads=8) for o in ogeoms]
+        for geoms, logs, evals, unres in drive_sharded(mm, engine, base, world, step, rng_deg, bruteforce, ss, precision,
+                                                       exchange, grid=grid, on_tile=True, moved=moved):
+            assert unres == 0
             for k in range(len(base)):
                 assert logs[k] == ologs[k]
                 assert geoms_equal(geoms[k], ogeoms[k])
