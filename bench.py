@@ -481,6 +481,8 @@ class Runner:
                 self.plans[k].level_launch(0)
                 self.plans[k]._begun = True
             else:
+                if os.environ.get("MM_BENCH_NO_WAIT"):       # experiment: the look-ahead launch does not wait for the previous step's
+                    prev = None
                 self.plans[k].search_begin(after=None if prev is None else self.engs[prev % len(self.engs)])
 
     def search(self, k):
@@ -652,9 +654,16 @@ def main():
     LOOK = int(os.environ.get("MM_BENCH_ENGINES", "5" if (world > 1 or rehearse > 1) else "3"))
     if LOOK < 2:
         raise SystemExit("MM_BENCH_ENGINES must be >= 2")
-    engs = [mm.Engine(local_rank) for _ in range(LOOK)]
+    # The bounded search resolves a case in ~1.3 ms of device time, less than one host thread needs to stage a case
+    # (1.4 ms: 25.6 MB through pinned memory and PCIe, level 0's descriptors) or to finish one (1.3 ms: chain walk, two
+    # between batches): its pipeline is six engines deep with two finishing threads (measured 3/1: 1.8 - 2.1 ms per step,
+    # 5/2: 1.60 - 1.64, 6/2: 1.56, 8/2: 1.48; MM_BENCH_BOUNDED_ENGINES / MM_BENCH_FINISHERS)
+    LOOK_BOUNDED = max(LOOK, int(os.environ.get("MM_BENCH_BOUNDED_ENGINES", "6")))
+    n_engines = LOOK_BOUNDED if (args.precision == "bounded" or not args.no_extra_legs) and world == 1 and rehearse <= 1 else LOOK
+    engs_all = [mm.Engine(local_rank) for _ in range(n_engines)]
+    engs = engs_all[:LOOK]
     if os.environ.get("MM_BENCH_BOUND_MATRIX"):      # A/B: 0 = the bounded search on the packed-FMA kernels of rounds 1-3; 11/12/21/22 = variant
-        for e_ in engs:
+        for e_ in engs_all:
             e_.set_bound_matrix(int(os.environ["MM_BENCH_BOUND_MATRIX"]))
     ext = cfg.get("shift")
     pipelined = mode == 1 and ext is None and not os.environ.get("MM_BENCH_SEQUENTIAL")
@@ -673,9 +682,9 @@ def main():
         for e in engs:
             e.synchronize()
 
-    def read_profiles():
+    def read_profiles(engs=None):
         ms, pe, tot, bound_ = [], [], {"launches": 0, "ms": 0.0, "pair_evals": 0.0, "candidates": 0}, None
-        for e in engs:
+        for e in (engs_main if engs is None else engs):
             a, b = e.profile_launches()
             ms.append(a); pe.append(b)
             bs = e.bound_stats()
@@ -693,7 +702,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0].item())
 
-    def timed_leg(prec, warmup, steps, pipe, resident=False, cfg=cfg, bruteforce=True):
+    LOOK_MAIN, engs_main = LOOK, engs
+
+    def timed_leg(prec, warmup, steps, pipe, resident=False, cfg=cfg, bruteforce=True, deep=False):
         """W untimed + K timed steps of one precision.  Inside the timed region: K stagings (raw pullbacks ->
         HBM -> search sets), K searches, K finishes.  The pipeline is primed before it (the first LOOK cases are
         staged during set-up / warm-up), so the stagings in the region are those of steps W+LOOK .. W+K+LOOK-1:
@@ -712,6 +723,10 @@ def main():
                 ramp = 0
         warmup += ramp
         n_total = warmup + steps
+        # deep: the bounded search's pipeline (see LOOK_BOUNDED above)
+        deep = deep and len(engs_all) > len(engs_main) and pipe
+        LOOK, engs = (len(engs_all), engs_all) if deep else (LOOK_MAIN, engs_main)
+        STAGER = LOOK >= 3
         r = Runner(mm, engs, base, cfg, prec, mode, rank, world, ext, n_total + LOOK, rehearse, grid, rehearse_comm,
                    lazy_until=warmup - 1 if ramp else 0, bruteforce=bruteforce)
         for k in range(n_total if resident else LOOK):
@@ -733,7 +748,7 @@ def main():
         # broadcasts must be issued in one order on every rank); MM_BENCH_SHARDED_FINISH=0: every rank finishes everything,
         # two threads take turns
         r.fin_group = fin_group
-        nfin = int(os.environ.get("MM_BENCH_FINISHERS", "2" if (sharded and not r.sharded_finish()) else "1"))
+        nfin = int(os.environ.get("MM_BENCH_FINISHERS", "2" if ((sharded and not r.sharded_finish()) or deep) else "1"))
         run_steps(range(warmup), r.search, r.finish, pipe, stage_fn, LOOK, begin, STAGER, pre, nfin)
         barrier()
         for e in engs:
@@ -744,11 +759,11 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
-        prof = read_profiles()
+        prof = read_profiles(engs)
         last_case = r.cases[n_total - 1]
         stage_ms = 1e3 * r.stage_s / max(r.staged, 1)
         r.close()
-        return dict(ramp=ramp, dt=reduce_max(dt), results=results, evals=sum(x[2] for x in results), unresolved=sum(x[3] for x in results),
+        return dict(ramp=ramp, engines=LOOK, finishers=nfin, dt=reduce_max(dt), results=results, evals=sum(x[2] for x in results), unresolved=sum(x[3] for x in results),
                     prof=prof, last_case=last_case, stage_ms=stage_ms, staged=r.staged)
 
     def ladder_leg():
@@ -883,7 +898,7 @@ def main():
                 raise SystemExit(f"exchange '{m}' and exchange 'gather' disagree on rank {rank}")
         os.environ["MM_EXCHANGE"] = chosen
 
-    main_leg = timed_leg(PREC, args.warmup, args.steps, pipelined)
+    main_leg = timed_leg(PREC, args.warmup, args.steps, pipelined, deep=args.precision == "bounded")
     if rehearse > 1:
         full = cfg["frames"] and sum(g.n_frames - 1 for g in base) * len(mm.search_angles(cfg["step_deg"], cfg["range_deg"])[0])
         ms = main_leg["dt"] / args.steps * 1e3
@@ -954,10 +969,11 @@ def main():
         # screen; winners identical).  Reported beside the headline, never as `value`: a candidate that is ruled
         # out is resolved, not evaluated, so these are not pose-evals in SURVEY 8(d)'s sense.
         try:
-            kb = max(args.steps, 40)      # a step is 2.3 ms of device work: enough of them that fill and drain do not dominate
-            leg = timed_leg(mm.MM_PRECISION_F32_BOUNDED, 2, kb, pipelined)
+            kb = max(args.steps, 200)     # a step is ~1.5 ms: enough of them that fill, drain and the clock ramp do not dominate
+            leg = timed_leg(mm.MM_PRECISION_F32_BOUNDED, 40, kb, pipelined, deep=True)
             extra["bounded_search"] = {
                 "candidates_resolved_per_s": leg["evals"] / leg["dt"], "ms_per_step": leg["dt"] / kb * 1e3, "steps": kb,
+                "pipeline": {"engines": leg["engines"], "finishing_threads": leg["finishers"]},
                 "identical_to_bruteforce_result": same_result(leg), "counts": leg["prof"][3],
                 "note": "MM_PRECISION_F32_BOUNDED on the same workload and steps: every candidate of the grid is either "
                         "ruled out by a lower bound of its Hausdorff distance or evaluated; same winners, logs and "

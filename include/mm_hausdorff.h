@@ -155,6 +155,13 @@ int  mm_engine_set_bound_matrix(mm_engine* e, int on);
 int  mm_lower_bounds(mm_engine* e, const double* rx, const double* ry, int nr, const double* tx, const double* ty, int nt,
                      double cx, double cy, const double* angles, int n_angles, int flags, int matrix, float* out_lb2,
                      double* e2, double* delta, int* stride);
+/* TEST HOOK (nothing in the product calls it): what the first pick of the matrix-pipe bounded search leaves for the choice
+ * of the third round's queries -- for ONE candidate angle the squared distance from every reference point to its nearest
+ * rotated target point (row_min2[nr]) and from every rotated target point to its nearest reference point (col_min2[nt]),
+ * as the f16 hi+lo matrix kernel computes them (each within *e2 of the exact squared value), and the screened squared
+ * Hausdorff value (*value2 = the maximum over both).  Sets of 64 .. 528 points. */
+int  mm_pick_minima(mm_engine* e, const double* rx, const double* ry, int nr, const double* tx, const double* ty, int nt,
+                    double cx, double cy, double angle, int flags, float* row_min2, float* col_min2, float* value2, double* e2);
 
 /* ---- the metric: hausdorff_distance (process_utils.rs:78-82) ------------------------ */
 /* f64-exact on the device; empty set on either side -> 0.0 (process_utils.rs:86-88). */

@@ -28,7 +28,7 @@ MM_SEARCH_SKIP_ZERO = 1
 EXPORTS = [
     "mm_device_count", "mm_last_error", "mm_version",
     "mm_engine_create", "mm_engine_destroy", "mm_engine_synchronize", "mm_engine_stream", "mm_engine_wait_search",
-    "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches", "mm_engine_bound_stats", "mm_engine_screen_stats", "mm_engine_set_bound_matrix", "mm_lower_bounds",
+    "mm_engine_profile", "mm_engine_profile_read", "mm_engine_profile_launches", "mm_engine_bound_stats", "mm_engine_screen_stats", "mm_engine_set_bound_matrix", "mm_lower_bounds", "mm_pick_minima",
     "mm_engine_set_bound_min_candidates",
     "mm_hausdorff_2d", "mm_hausdorff_batch", "mm_refine_angles", "mm_filter_points_in_region",
     "mm_refine_downsample_count", "mm_search_angles", "mm_best_rotation", "mm_best_rotation_batch",
@@ -203,6 +203,8 @@ def lib():
     L.mm_engine_profile_launches.argtypes = [P, I64, P, P, C.POINTER(I64)]
     L.mm_engine_bound_stats.restype = I
     L.mm_engine_bound_stats.argtypes = [P, P]
+    L.mm_pick_minima.restype = I
+    L.mm_pick_minima.argtypes = [P, P, P, I, P, P, I, D, D, D, I, P, P, P, P]
     L.mm_lower_bounds.restype = I
     L.mm_lower_bounds.argtypes = [P, P, P, I, P, P, I, D, D, P, I, I, I, P, P, P, P]
     L.mm_engine_set_bound_matrix.restype = I
@@ -663,6 +665,19 @@ class Engine:
                                     float(centre[1]), _ptr(ang), len(ang), MM_SEARCH_SKIP_ZERO if skip_zero else 0, int(bool(matrix)),
                                     _ptr(out), C.byref(e2), C.byref(delta), C.byref(stride)), "mm_lower_bounds")
         return out, e2.value, delta.value, stride.value
+
+    def pick_minima(self, ref, tgt, angle, centre, skip_zero=True):
+        """TEST HOOK (``mm_pick_minima``): squared row minima, squared column minima, screened squared value and e2 of one
+        candidate, as the first pick of the matrix-pipe bounded search leaves them."""
+        ref = np.ascontiguousarray(ref, dtype=np.float64); tgt = np.ascontiguousarray(tgt, dtype=np.float64)
+        rx, ry = np.ascontiguousarray(ref[:, 0]), np.ascontiguousarray(ref[:, 1])
+        tx, ty = np.ascontiguousarray(tgt[:, 0]), np.ascontiguousarray(tgt[:, 1])
+        rows, cols = np.zeros(len(rx), dtype=np.float32), np.zeros(len(tx), dtype=np.float32)
+        val, e2 = np.zeros(1, dtype=np.float32), C.c_double(0.0)
+        check(lib().mm_pick_minima(self._h, _ptr(rx), _ptr(ry), len(rx), _ptr(tx), _ptr(ty), len(tx), float(centre[0]),
+                                   float(centre[1]), float(angle), MM_SEARCH_SKIP_ZERO if skip_zero else 0, _ptr(rows), _ptr(cols),
+                                   _ptr(val), C.byref(e2)), "mm_pick_minima")
+        return rows, cols, float(val[0]), e2.value
 
     def set_bound_matrix(self, on: bool):
         """MM_PRECISION_F32_BOUNDED: bounds and survivors on the matrix pipe (default) or on the packed-FMA kernels."""

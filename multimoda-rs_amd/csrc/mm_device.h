@@ -77,6 +77,7 @@ struct BatchDev {
     int32_t*  pick_idx;    // [2 * n_pairs] per pair: candidate with the smallest bound after round 1 / round 3 (-1: none)
     WorkItem* items_pick;  // [2 * n_pairs] queue entries of the two picks
     WorkItem* items_lb;    // three queues of `runs cap` entries: round 2, round 3, survivors
+    int32_t*  klist;       // [n_cand] per pair (at its out_off): the survivors' candidate indices (k_lb_keep_mx)
     float*    emit;        // per pair emit_rows + emit_cols: row / column minima of the first pick
     int32_t   emit_rows, emit_cols;
     int32_t*  qlist;       // per pair 2 * lb_list_queries(): decisive reference / target point indices
@@ -99,7 +100,7 @@ hipError_t launch_screen_fast(const BatchDev& b, int max_na, int max_nbp, hipStr
 hipError_t launch_screen_mx(const BatchDev& b, int work_begin, int n_work, int nct, int multi, int a_cap, hipStream_t s);
 hipError_t launch_screen_none(const BatchDev& b, int work_begin, int n_work, hipStream_t s);   // screened value 0 for every candidate
 void       mx_variant(int n_tgt, int* nct, int* multi);
-size_t     lds_bytes_mx(int nct, bool multi, int a_cap);
+size_t     lds_bytes_mx(int nct, bool multi, int a_cap, int waves);
 int        mx_min_points();
 int        mx_max_points();
 int        max_rows_fast();

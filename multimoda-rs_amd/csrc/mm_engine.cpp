@@ -534,6 +534,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     const size_t o_lb32 = take(use_lb ? (size_t)A * 4 : 0), o_pick = take(use_lb ? (size_t)P * 8 : 0);
     const size_t o_items_pick = take(use_lb ? (size_t)P * 2 * sizeof(WorkItem) : 0);
     const size_t o_items_lb = take(use_lb ? (size_t)lb_runs_cap * 3 * sizeof(WorkItem) : 0);
+    const size_t o_klist = take(use_lb && lb_mx_tiles > 0 ? (size_t)A * 4 : 0);
     const size_t o_emit = take(use_lb ? (size_t)P * (size_t)(emit_rows + emit_cols) * 4 : 0);
     const size_t o_qlist = take(use_lb ? (size_t)P * 2 * (size_t)lb_list_queries() * 4 : 0);
     const size_t o_bc = take((size_t)P * 8), o_bi = take((size_t)P * 4), o_nr = take((size_t)P * 4);
@@ -584,7 +585,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     dev.lb_mx_qt = e->bound_matrix_qt; dev.lb_mx_nc = e->bound_matrix_nc;
     dev.lb32 = (float*)(B + o_lb32); dev.pick_idx = (int32_t*)(B + o_pick); dev.items_pick = (WorkItem*)(B + o_items_pick);
     dev.items_lb = (WorkItem*)(B + o_items_lb); dev.emit = (float*)(B + o_emit); dev.emit_rows = emit_rows; dev.emit_cols = emit_cols;
-    dev.qlist = (int32_t*)(B + o_qlist);
+    dev.qlist = (int32_t*)(B + o_qlist); dev.klist = (int32_t*)(B + o_klist);
     dev.best_cost = (double*)(B + o_bc); dev.best_idx = (int32_t*)(B + o_bi); dev.n_rescored = (int32_t*)(B + o_nr);
     dev.near_cnt = (int32_t*)(B + o_nc); dev.near_idx = (int32_t*)(B + o_ni);
     dev.all_costs = want_costs ? (double*)(B + off_all_costs) : nullptr;
@@ -1254,6 +1255,38 @@ int mm_lower_bounds(mm_engine* h, const double* rx, const double* ry, int nr, co
     if (e2) *e2 = plan.host_pairs[0].e2;
     if (delta) *delta = plan.host_pairs[0].delta;
     if (stride) *stride = plan.lb_stride;
+    return MM_OK;
+}
+
+int mm_pick_minima(mm_engine* h, const double* rx, const double* ry, int nr, const double* tx, const double* ty, int nt,
+                   double cx, double cy, double angle, int flags, float* row_min2, float* col_min2, float* value2, double* e2)
+{
+    Engine* e = reinterpret_cast<Engine*>(h);
+    if (!e || !row_min2 || !col_min2 || nr <= 0 || nt <= 0) return set_error(MM_ERR_INVALID, "mm_pick_minima: bad arguments");
+    MM_HIP(hipSetDevice(e->device));
+    std::vector<SetRef> sets{SetRef{rx, ry, nr, cx, cy}, SetRef{tx, ty, nt, cx, cy}};
+    std::vector<PairSpec> pairs{PairSpec{0, 1, cx, cy, flags, &angle, 1, 0.0, 0.0}};
+    const int64_t keep_min = e->bound_min_candidates;
+    const bool keep_mx = e->bound_matrix;
+    e->bound_min_candidates = 0; e->bound_matrix = true;
+    Plan plan;
+    int rc = plan.stage_sets(e, sets, true);
+    if (!rc) rc = plan.stage_level(pairs, MM_PRECISION_F32_BOUNDED, 0, INT32_MAX, false);
+    e->bound_min_candidates = keep_min; e->bound_matrix = keep_mx;
+    if (rc) return rc;
+    if (!plan.use_lb || plan.lb_mx_tiles <= 0) return set_error(MM_ERR_INVALID, "mm_pick_minima: the matrix-pipe bounded search does not take these sets");
+    const WorkItem item{0, 0, 1, 0};
+    const int32_t counters[8] = {0, 1, 0, 0, 0, 0, 0, 0};
+    MM_HIP(hipMemcpyAsync(plan.dev.items_pick, &item, sizeof item, hipMemcpyHostToDevice, plan.stream));
+    MM_HIP(hipMemcpyAsync(plan.dev.n_items, counters, sizeof counters, hipMemcpyHostToDevice, plan.stream));
+    MM_HIP(hipStreamSynchronize(plan.stream));                     // (the sources are on this stack frame)
+    hipError_t he = launch_screen_picks(plan.dev, 0, plan.max_na, plan.max_nbp, plan.stream);
+    if (he != hipSuccess) return hip_error(he, "pick kernel launch");
+    MM_HIP(hipMemcpyAsync(row_min2, plan.dev.emit, (size_t)nr * 4, hipMemcpyDeviceToHost, plan.stream));
+    MM_HIP(hipMemcpyAsync(col_min2, plan.dev.emit + plan.dev.emit_rows, (size_t)nt * 4, hipMemcpyDeviceToHost, plan.stream));
+    if (value2) MM_HIP(hipMemcpyAsync(value2, plan.dev.sq32, 4, hipMemcpyDeviceToHost, plan.stream));
+    MM_HIP(hipStreamSynchronize(plan.stream));
+    if (e2) *e2 = plan.host_pairs[0].e2;
     return MM_OK;
 }
 

@@ -606,21 +606,23 @@ typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 // the n points at (px, py) as ntiles x 64 row fragments in LDS (padding rows duplicate the last point), by 256 threads.  Four
 // slots per thread and pass: the loads of a pass are issued together -- fragment by fragment the loop exposed one global-memory
 // round trip per slot (8.5 of them for a 544-point set: ~25 us of a bound kernel's work item, more than its MFMAs)
+template <int NT = 256>
 static __device__ __forceinline__ void mx_stage_rows(h8v* __restrict__ s_dst, int ntiles, int n, const float* __restrict__ px,
                                                      const float* __restrict__ py, float S, int tid)
 {
+    constexpr int U = NT >= 256 ? 4 : 9;        // slots per thread and pass (one wave: 17 row tiles in two passes)
     const int total = ntiles * 64;
-    for (int s0 = tid; s0 < total; s0 += 256 * 4) {
-        float x[4], y[4];
+    for (int s0 = tid; s0 < total; s0 += NT * U) {
+        float x[U], y[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int slot = s0 + 256 * u < total ? s0 + 256 * u : total - 1;
+        for (int u = 0; u < U; ++u) {
+            const int slot = s0 + NT * u < total ? s0 + NT * u : total - 1;
             const int row = (slot >> 6) * 32 + (slot & 31), rc = row < n ? row : n - 1;
             x[u] = px[rc]; y[u] = py[rc];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int slot = s0 + 256 * u;
+        for (int u = 0; u < U; ++u) {
+            const int slot = s0 + NT * u;
             if (slot < total) s_dst[slot] = mx_fragment<true>(S * x[u], S * y[u], (slot & 63) >> 5);
         }
     }
@@ -670,22 +672,32 @@ static __device__ __forceinline__ int wave_max_i32_dpp(int v)
     return a > c ? a : c;
 }
 
-// NCT: column tiles of one block (the whole target set when !MULTI); a_cap: row tiles the launch's LDS layout provides for
-template <int NCT, bool MULTI>
-__global__ void __launch_bounds__(256, 2)
+// unsigned minimum over the wave (order-reversing map onto the signed maximum above)
+static __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v)
+{
+    return ~(unsigned)wave_max_i32_dpp((int)~(v ^ 0x80000000u)) ^ 0x80000000u;
+}
+
+// NCT: column tiles of one block (the whole target set when !MULTI); a_cap: row tiles the launch's LDS layout provides for.
+// WAVES: waves of a workgroup, one candidate each at a time.  4 for the host-built work lists (8 consecutive candidates of
+// a pair share the staged rows); 1 for the device queues of the bounded search, whose items are single candidates (the
+// picks) or short runs: with 4, three waves of every workgroup sat idle and the launch took four rounds of workgroups.
+template <int NCT, bool MULTI, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES, 2)
 k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, int n_work_host,
-            const int* __restrict__ n_work_dev, int a_cap, const float* __restrict__ ptx, const float* __restrict__ pty,
-            const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
+            const int* __restrict__ n_work_dev, const int32_t* __restrict__ sel, int a_cap, const float* __restrict__ ptx,
+            const float* __restrict__ pty, const float* __restrict__ cosv, const float* __restrict__ sinv, float* __restrict__ out_sq)
 {
     constexpr int NB = NCT * 32;                                      // padded columns of one block
     constexpr int NQ = (NCT + 1) / 2;                                 // columns per lane
     extern __shared__ __align__(16) unsigned char smem[];
     h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [a_cap][64] row fragments of the pair (all waves)
-    h4v* s_bw = reinterpret_cast<h4v*>(s_a + a_cap * 64);            // [4][NCT][64] column fragments, 8 bytes each: a wave's
+    h4v* s_bw = reinterpret_cast<h4v*>(s_a + a_cap * 64);            // [WAVES][NCT][64] column fragments, 8 bytes each: a wave's
                                                                       //            own copy, for the candidate it is on
-    int* s_redx = reinterpret_cast<int*>(s_bw + 4 * NCT * 64);       // [4][MX_RED] row-reduction scratch, one per wave
-    int* s_rsx = s_redx + 4 * MX_RED;                                 // MULTI: [4][a_cap * 32] row store, one per wave
-    float* s_cs = reinterpret_cast<float*>(s_rsx + (MULTI ? 4 * a_cap * 32 : 0));   // [8][2] cos, sin of the work item's candidates
+    int* s_redx = reinterpret_cast<int*>(s_bw + WAVES * NCT * 64);   // [WAVES][MX_RED] row-reduction scratch, one per wave
+    int* s_rsx = s_redx + WAVES * MX_RED;                             // MULTI: [WAVES][a_cap * 32] row store, one per wave
+    float* s_cs = reinterpret_cast<float*>(s_rsx + (MULTI ? WAVES * a_cap * 32 : 0));   // [8][2] cos, sin of the work item's candidates
+    int* s_ci = reinterpret_cast<int*>(s_cs + 16);                    // [8] their indices in the pair's list
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
     h4v* s_b = s_bw + wave * NCT * 64;
@@ -712,9 +724,15 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         const float S = __builtin_ldexpf(1.0f, pd.pad0), inv_s2 = __builtin_ldexpf(1.0f, -2 * pd.pad0);
 
         __syncthreads();
-        // the candidates' cos / sin once per work item (a global load at the top of every candidate would be exposed)
-        if (tid < 16 && (tid >> 1) < w.cnt) s_cs[tid] = (tid & 1) ? sinv[pd.tab_off + w.a0 + (tid >> 1)] : cosv[pd.tab_off + w.a0 + (tid >> 1)];
-        mx_stage_rows(s_a, nrt, na, ptx + pd.ref_off, pty + pd.ref_off, S, tid);      // padding rows duplicate the last reference point
+        // the candidates' cos / sin once per work item (a global load at the top of every candidate would be exposed).
+        // sel (the survivors of a bounded search): the item is entries a0 .. a0 + cnt of the pair's list of candidates,
+        // not a run of consecutive ones
+        if (tid < 16 && (tid >> 1) < w.cnt) {
+            const int a = sel ? sel[pd.out_off + w.a0 + (tid >> 1)] : w.a0 + (tid >> 1);
+            s_cs[tid] = (tid & 1) ? sinv[pd.tab_off + a] : cosv[pd.tab_off + a];
+            if (!(tid & 1)) s_ci[tid >> 1] = a;
+        }
+        mx_stage_rows<64 * WAVES>(s_a, nrt, na, ptx + pd.ref_off, pty + pd.ref_off, S, tid);      // padding rows duplicate the last reference point
         if constexpr (!MULTI) {
             // this lane's columns -- every wave holds all of them: lane + 64 q -- unrotated, scaled, in registers for all the
             // wave's candidates
@@ -730,8 +748,9 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
             __syncthreads();
 
             // one wave, one candidate: no barrier and nothing shared below this line
-            for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
-                const float c = s_cs[2 * (a - w.a0)], s = s_cs[2 * (a - w.a0) + 1];
+            for (int k = wave; k < w.cnt; k += WAVES) {
+                const float c = s_cs[2 * k], s = s_cs[2 * k + 1];
+                const int a = s_ci[k];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int j = lane + 64 * q;
@@ -749,8 +768,9 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         } else {
             __syncthreads();
             const int nblk = (((nb + 31) >> 5) + NCT - 1) / NCT;         // equal blocks of NCT column tiles (the engine's choice)
-            for (int a = w.a0 + wave; a < w.a0 + w.cnt; a += 4) {
-                const float c = s_cs[2 * (a - w.a0)], s = s_cs[2 * (a - w.a0) + 1];
+            for (int k = wave; k < w.cnt; k += WAVES) {
+                const float c = s_cs[2 * k], s = s_cs[2 * k + 1];
+                const int a = s_ci[k];
                 for (int i = lane; i < nrt * 32; i += 64) s_rs[i] = 0x7f800000;      // row store: +inf
                 int m = 0;
                 for (int blk = 0; blk < nblk; ++blk) {
@@ -778,21 +798,123 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
     }
 }
 
-size_t lds_bytes_mx(int nct, bool multi, int a_cap)
+// The first pick of a bounded search: one wave, one candidate, and besides its screened value the candidate's ROW minima
+// (per reference point) and COLUMN minima (per target point) leave for k_lb_topk -- the generated block in its `emit` form
+// (row store + column store in LDS).  Same values as k_screen_mx<NCT, false> (same operands, same tiles).
+template <int NCT>
+__global__ void __launch_bounds__(64, 2)
+k_screen_mx_emit(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ work, const int* __restrict__ n_work_dev, int a_cap,
+                 const float* __restrict__ ptx, const float* __restrict__ pty, const float* __restrict__ cosv,
+                 const float* __restrict__ sinv, float* __restrict__ out_sq, float* __restrict__ emit, int emit_rows, int emit_cols)
 {
-    return (size_t)a_cap * 64 * 16 + (size_t)4 * nct * 64 * 8 + (size_t)4 * MX_RED * 4 + (multi ? (size_t)4 * a_cap * 32 * 4 : 0) + 64;
+    constexpr int NB = NCT * 32, NQ = (NCT + 1) / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    h8v* s_a = reinterpret_cast<h8v*>(smem);                          // [a_cap][64] row fragments
+    h4v* s_b = reinterpret_cast<h4v*>(s_a + a_cap * 64);             // [NCT][64] column fragments
+    int* s_red = reinterpret_cast<int*>(s_b + NCT * 64);             // [MX_RED] row-reduction scratch
+    int* s_rs = s_red + MX_RED;                                       // [a_cap * 32] row store
+    int* s_col = s_rs + a_cap * 32;                                   // [NQ * 64] column store
+    const int lane = threadIdx.x, l32 = lane & 31, hi = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned vB = lds0 + (unsigned)((size_t)s_b - (size_t)smem) + lane * 8;
+    const unsigned vA = lds0 + lane * 16;
+    const unsigned red_w = lds0 + (unsigned)((size_t)s_red - (size_t)smem);
+    const unsigned vRW = red_w + (hi * 16) * MM_SCREEN_MX_RED_STRIDE + l32 * 4;
+    const int rh = (l32 >> 2) & 1, rv = (l32 & 3) + 4 * (l32 >> 3);
+    const unsigned vRR = red_w + (rh * 16 + rv) * MM_SCREEN_MX_RED_STRIDE + hi * 64;
+    const unsigned vPERM = (unsigned)((lane ^ 32) * 4);
+    const unsigned vRS = lds0 + (unsigned)((size_t)s_rs - (size_t)smem) + l32 * 4;
+    const unsigned vCS = lds0 + (unsigned)((size_t)s_col - (size_t)smem) + lane * 4;
+    const int n_work = *n_work_dev;
+
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const WorkItem w = work[wi];
+        const PairDesc pd = pairs[w.pair];
+        const int na = pd.n_ref, nb = pd.n_tgt, a = w.a0;
+        const int nrt = (na + 31) >> 5, nloop = (nrt - 1) >> 1, tail = (nrt - 1) & 1;
+        const float S = __builtin_ldexpf(1.0f, pd.pad0), inv_s2 = __builtin_ldexpf(1.0f, -2 * pd.pad0);
+        const float c = cosv[pd.tab_off + a], s = sinv[pd.tab_off + a];
+        __syncthreads();
+        mx_stage_rows<64>(s_a, nrt, na, ptx + pd.ref_off, pty + pd.ref_off, S, lane);
+        for (int i = lane; i < nrt * 32; i += 64) s_rs[i] = 0x7f800000;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = lane + 64 * q;
+            if (j < NB) {
+                const int jc = j < nb ? j : nb - 1;
+                const float x = S * ptx[pd.tgt_off + jc], y = S * pty[pd.tgt_off + jc];
+                s_b[(j >> 5) * 64 + (j & 31) + 32] = mx_col_norm(x, y);
+                s_b[(j >> 5) * 64 + (j & 31)] = mx_col_coords(__builtin_fmaf(x, c, -(y * s)), __builtin_fmaf(x, s, y * c));
+            }
+        }
+        __syncthreads();
+        int m = MxEmit<NCT>::run(vB, vA, vRW, vRR, vPERM, nloop, tail, vRS, vCS);     // max of the column minima
+        __syncthreads();
+        float* const em = emit + (size_t)w.pair * (size_t)(emit_rows + emit_cols);
+        for (int i = lane; i < nrt * 32; i += 64) {
+            const int r = s_rs[i];
+            m = r > m ? r : m;
+            if (i < na) em[i] = __int_as_float(r) * inv_s2;
+        }
+        for (int j = lane; j < nb; j += 64) em[emit_rows + j] = __int_as_float(s_col[j]) * inv_s2;
+        m = wave_max_i32_dpp(m);
+        if (lane == 0) out_sq[pd.out_off + a] = __int_as_float(m) * inv_s2;
+    }
+}
+
+template <int NCT>
+static hipError_t launch_mx_emit_t(const BatchDev& b, const WorkItem* work, const int* n_dev, int cap, int a_cap, hipStream_t s)
+{
+    const size_t lds = (size_t)a_cap * 64 * 16 + (size_t)NCT * 64 * 8 + (size_t)MX_RED * 4 + (size_t)a_cap * 32 * 4 +
+                       (size_t)((NCT + 1) / 2) * 64 * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx_emit<NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_screen_mx_emit<NCT>), dim3(std::min(cap, 256 * 8 * 2)), dim3(64), lds, s, b.pairs, work, n_dev, a_cap, b.p32x,
+                       b.p32y, b.cos32, b.sin32, b.sq32, b.emit, b.emit_rows, b.emit_cols);
+    return hipGetLastError();
+}
+
+static hipError_t launch_mx_emit(const BatchDev& b, const WorkItem* work, const int* n_dev, int cap, int nct, int a_cap, hipStream_t s)
+{
+    if (a_cap < 1 || a_cap > 17) return hipErrorInvalidValue;
+#define MM_MXE(N) case N: return launch_mx_emit_t<N>(b, work, n_dev, cap, a_cap, s);
+    switch (nct) {
+        MM_MXE(2) MM_MXE(3) MM_MXE(4) MM_MXE(5) MM_MXE(6) MM_MXE(7) MM_MXE(8) MM_MXE(9) MM_MXE(10) MM_MXE(11) MM_MXE(12) MM_MXE(13)
+        MM_MXE(14) MM_MXE(15) MM_MXE(16) MM_MXE(17)
+        default: return hipErrorInvalidValue;
+    }
+#undef MM_MXE
+}
+
+size_t lds_bytes_mx(int nct, bool multi, int a_cap, int waves)
+{
+    return (size_t)a_cap * 64 * 16 + (size_t)waves * nct * 64 * 8 + (size_t)waves * MX_RED * 4 +
+           (multi ? (size_t)waves * a_cap * 32 * 4 : 0) + 128;
 }
 
 // n_dev == nullptr: one workgroup per item of the host-built list; else a device queue of at most `cap` items whose length is
 // *n_dev (a bounded grid strides over it)
+// waves: 4, or 1 for a queue of single candidates (the picks of a bounded search).  sel: see the kernel.
 template <int NCT, bool MULTI>
-static hipError_t launch_mx_t(const BatchDev& b, const WorkItem* work, int n_work, const int* n_dev, int cap, int a_cap, hipStream_t s)
+static hipError_t launch_mx_t(const BatchDev& b, const WorkItem* work, int n_work, const int* n_dev, int cap, int a_cap, int waves,
+                              const int32_t* sel, hipStream_t s)
 {
-    const size_t lds = lds_bytes_mx(NCT, MULTI, a_cap);
+    if constexpr (!MULTI) {
+        if (waves == 1) {
+            const size_t lds = lds_bytes_mx(NCT, false, a_cap, 1);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx<NCT, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            const int grid = n_dev ? std::min(cap, 256 * 8 * 2) : n_work;
+            hipLaunchKernelGGL((k_screen_mx<NCT, false, 1>), dim3(grid), dim3(64), lds, s, b.pairs, work, n_work, n_dev, sel, a_cap,
+                               b.p32x, b.p32y, b.cos32, b.sin32, b.sq32);
+            return hipGetLastError();
+        }
+    }
+    const size_t lds = lds_bytes_mx(NCT, MULTI, a_cap, 4);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_mx<NCT, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int grid = n_dev ? std::min(cap, 256 * 8) : n_work;
-    hipLaunchKernelGGL((k_screen_mx<NCT, MULTI>), dim3(grid), dim3(256), lds, s, b.pairs, work, n_work, n_dev, a_cap, b.p32x, b.p32y,
+    hipLaunchKernelGGL((k_screen_mx<NCT, MULTI>), dim3(grid), dim3(256), lds, s, b.pairs, work, n_work, n_dev, sel, a_cap, b.p32x, b.p32y,
                        b.cos32, b.sin32, b.sq32);
     return hipGetLastError();
 }
@@ -808,11 +930,11 @@ void mx_variant(int nb, int* nct, int* multi)
 
 // work[0 .. n_work) of b.work + work_begin: items of pairs that all take the variant (nct, multi); a_cap >= their row tiles
 static hipError_t launch_mx_any(const BatchDev& b, const WorkItem* w, int n_work, const int* n_dev, int cap, int nct, int multi, int a_cap,
-                                hipStream_t s)
+                                hipStream_t s, int waves = 4, const int32_t* sel = nullptr)
 {
-    if (a_cap < 1 || a_cap > MX_ROW_TILES_MAX || lds_bytes_mx(nct, multi != 0, a_cap) > 160 * 1024) return hipErrorInvalidValue;
-#define MM_MX(N) case N: return multi ? launch_mx_t<(N < 9 ? 9 : N), true>(b, w, n_work, n_dev, cap, a_cap, s) \
-                                      : launch_mx_t<N, false>(b, w, n_work, n_dev, cap, a_cap, s);
+    if (a_cap < 1 || a_cap > MX_ROW_TILES_MAX || lds_bytes_mx(nct, multi != 0, a_cap, 4) > 160 * 1024) return hipErrorInvalidValue;
+#define MM_MX(N) case N: return multi ? launch_mx_t<(N < 9 ? 9 : N), true>(b, w, n_work, n_dev, cap, a_cap, 4, sel, s) \
+                                      : launch_mx_t<N, false>(b, w, n_work, n_dev, cap, a_cap, waves, sel, s);
     if (multi && nct < 9) return hipErrorInvalidValue;       // (several blocks: at least 18 column tiles, 9 per block)
     switch (nct) {
         MM_MX(2) MM_MX(3) MM_MX(4) MM_MX(5) MM_MX(6) MM_MX(7) MM_MX(8) MM_MX(9) MM_MX(10) MM_MX(11) MM_MX(12) MM_MX(13)
@@ -1281,7 +1403,11 @@ k_lb_pick(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, in
         const unsigned long long k = ((unsigned long long)__float_as_uint(lb32[pd.out_off + a]) << 32) | (unsigned)a;
         key = k < key ? k : key;
     }
-    atomicMin(&s_key, key);
+    {   // the wave's smallest key (value, then index) by two DPP reductions; one LDS atomic per wave, not per thread
+        const unsigned hi = wave_min_u32_dpp((unsigned)(key >> 32));
+        const unsigned lo = wave_min_u32_dpp((unsigned)(key >> 32) == hi ? (unsigned)key : 0xffffffffu);
+        if ((tid & 63) == 0) atomicMin(&s_key, ((unsigned long long)hi << 32) | lo);
+    }
     __syncthreads();
     if (tid == 0) {
         const int a = (int)(s_key & 0xffffffffull);
@@ -1377,6 +1503,47 @@ k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, fl
     if (stats && queued) atomicAdd(&stats[FINAL ? 2 : 3], queued);
 }
 
+// The same decision for the matrix-pipe rounds, one thread per candidate.  !FINAL: flags only (k_bound_mx_scan collects the
+// flagged candidates itself).  FINAL: the pair's survivors are written to its slice of `klist` (any order) and queued as
+// items of <= 8 list entries -- k_screen_mx's workgroup stages the pair's rows once and gives each of its four waves a
+// survivor, wherever in the list of candidates they lie.  (As runs inside aligned groups of 8 -- k_lb_keep -- the survivors
+// of a pair came in several items of one or two candidates, each a workgroup with two or three waves idle: 0.28 ms of a
+// config3 step for 0.6 % of the candidates.)
+template <bool FINAL>
+__global__ void __launch_bounds__(256)
+k_lb_keep_mx(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, float* __restrict__ sq32,
+             const int32_t* __restrict__ pick_idx, const int32_t* __restrict__ pick2, int32_t* __restrict__ klist,
+             WorkItem* __restrict__ items, int* __restrict__ n_items, unsigned long long* __restrict__ stats,
+             uint8_t* __restrict__ flags)
+{
+    __shared__ int s_n;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const PairDesc pd = pairs[p];
+    if (pd.n_ang <= 0) return;
+    const int c1 = pick_idx[p], c2 = pick2 ? pick2[p] : c1;
+    const float s1 = sq32[pd.out_off + c1], s2 = sq32[pd.out_off + c2];
+    const double ub = sqrt((double)(s2 < s1 ? s2 : s1) + pd.e2) + 2.0 * pd.delta;
+    if (tid == 0) s_n = 0;
+    __syncthreads();              // (also: s1, s2 are read before any thread overwrites a screened value below)
+    for (int a = tid; a < pd.n_ang; a += 256) {
+        const double sv = (double)lb32[pd.out_off + a] - pd.e2;
+        const bool stays = a == c1 || a == c2 || sqrt(sv > 0.0 ? sv : 0.0) <= ub;
+        if (!FINAL) flags[pd.out_off + a] = stays ? 1 : 0;
+        else if (stays) klist[pd.out_off + atomicAdd(&s_n, 1)] = a;
+        else sq32[pd.out_off + a] = __int_as_float(0x7f800000);
+    }
+    if (FINAL) {
+        __syncthreads();
+        const int n = s_n;
+        for (int k = tid; k * 8 < n; k += 256) {
+            const int slot = atomicAdd(n_items, 1);
+            WorkItem w; w.pair = p; w.a0 = 8 * k; w.cnt = n - 8 * k < 8 ? n - 8 * k : 8; w.pad = 0;
+            items[slot] = w;
+        }
+        if (tid == 0 && stats && n) atomicAdd(&stats[2], (unsigned long long)n);
+    }
+}
+
 // The points that decide the picked candidate's Hausdorff distance: the kLbListQ reference points with the
 // largest row minima and the kLbListQ target points with the largest column minima (emitted by the pick's
 // screen).  Neighbouring candidates have (nearly) the same decisive points, so a bound from these few
@@ -1384,40 +1551,33 @@ k_lb_keep(const PairDesc* __restrict__ pairs, const float* __restrict__ lb32, fl
 static constexpr int kLbListRP = 1;
 static constexpr int kLbListQ = 8 * kLbListRP;
 
+// One WAVE per (pair, side) -- four of them per workgroup: a lane scans its share of the minima, the wave agrees on the
+// largest value (first index among equals) with two DPP reductions per choice.  (Round 3's version gave a side to a
+// whole workgroup and let its 256 threads meet in one 64-bit LDS atomic per choice: 0.12 ms per config3 step.)
 __global__ void __launch_bounds__(256)
-k_lb_topk(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pick_idx, const float* __restrict__ emit,
-          int emit_rows, int emit_cols, int32_t* __restrict__ qlist)
+k_lb_topk(const PairDesc* __restrict__ pairs, int n_pairs, const int32_t* __restrict__ pick_idx, const float* __restrict__ emit,
+          int emit_rows, int emit_cols, int max_n, int32_t* __restrict__ qlist)
 {
-    __shared__ unsigned long long s_best;
     extern __shared__ __align__(16) unsigned char smem[];
-    int* s_val = reinterpret_cast<int*>(smem);
-    const int p = blockIdx.x >> 1, tid = threadIdx.x;   // two workgroups per pair: reference side, target side
-    const PairDesc pd = pairs[p];
-    if (pd.n_ang <= 0 || pick_idx[p] < 0) return;
-    {
-        const int side = blockIdx.x & 1;
-        const int n = side ? pd.n_tgt : pd.n_ref;
-        const float* src = emit + (size_t)p * (size_t)(emit_rows + emit_cols) + (side ? emit_rows : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* s_val = reinterpret_cast<int*>(smem) + wave * max_n;
+    const int slot = blockIdx.x * 4 + wave;            // (pair, side): reference side, target side
+    const int p = slot >> 1, side = slot & 1;
+    const bool live = p < n_pairs && pairs[p < n_pairs ? p : 0].n_ang > 0 && pick_idx[p < n_pairs ? p : 0] >= 0;
+    const PairDesc pd = pairs[live ? p : 0];
+    const int n = live ? (side ? pd.n_tgt : pd.n_ref) : 0;
+    const float* src = emit + (size_t)(live ? p : 0) * (size_t)(emit_rows + emit_cols) + (side ? emit_rows : 0);
+    for (int i = lane; i < n; i += 64) { const int v = __float_as_int(src[i]); s_val[i] = v > 0 ? v : 0; }
+    __syncthreads();
+    int lastsel = 0;
+    for (int k = 0; k < kLbListQ; ++k) {
+        int bv = -1, bi = 0x7fffffff;                   // a chosen point is marked -1: nothing left = every value -1
+        for (int i = lane; i < n; i += 64) { const int v = s_val[i]; if (v > bv) { bv = v; bi = i; } }
+        const int top = wave_max_i32_dpp(bv);
+        const int sel = top >= 0 ? -wave_max_i32_dpp(bv == top ? -bi : -0x7fffffff) : lastsel;
+        lastsel = sel;
+        if (live && lane == 0) { qlist[(size_t)p * (2 * kLbListQ) + side * kLbListQ + k] = sel; if (top >= 0) s_val[sel] = -1; }
         __syncthreads();
-        for (int i = tid; i < n; i += 256) { const int v = __float_as_int(src[i]); s_val[i] = v > 0 ? v : 0; }
-        int lastsel = 0;
-        for (int k = 0; k < kLbListQ; ++k) {
-            if (tid == 0) s_best = 0ull;
-            __syncthreads();
-            unsigned long long key = 0ull;   // (value + 1, n - index): the first index wins ties; 0 = nothing left
-            for (int i = tid; i < n; i += 256)
-                if (s_val[i] >= 0) {
-                    const unsigned long long kk = ((unsigned long long)(unsigned)(s_val[i] + 1) << 32) | (unsigned)(n - i);
-                    key = kk > key ? kk : key;
-                }
-            atomicMax(&s_best, key);
-            __syncthreads();
-            const unsigned long long b = s_best;
-            const int sel = b ? n - (int)(b & 0xffffffffull) : lastsel;
-            lastsel = sel;
-            if (tid == 0) { qlist[(size_t)p * (2 * kLbListQ) + side * kLbListQ + k] = sel; if (b) s_val[sel] = -1; }
-            __syncthreads();
-        }
     }
 }
 
@@ -1440,7 +1600,8 @@ k_shortlist(const PairDesc* __restrict__ pairs, const float* __restrict__ sq32,
         const unsigned int u = __float_as_uint(sq32[pd.out_off + a]);
         m = u < m ? u : m;
     }
-    atomicMin(&s_min, m);
+    m = wave_min_u32_dpp(m);
+    if ((tid & 63) == 0) atomicMin(&s_min, m);
     __syncthreads();
     // A candidate stays if its smallest possible exact cost does not exceed the smallest
     // upper bound: the screened squared value S is within e2 of the f32-exact one (e2 = 0 for
@@ -1894,16 +2055,12 @@ hipError_t launch_screen_picks(const BatchDev& b, int round, int max_na, int max
 {
     if (b.n_pairs <= 0) return hipSuccess;
     if (b.kept_mx_nct > 0) {
-        // bounded search on the matrix pipe: the pick's VALUE (the pair's upper bound) comes from k_screen_mx.  The
-        // packed-FMA screen still runs for the first pick, but only for what it EMITS -- the row / column minima from which
-        // k_lb_topk chooses the third round's queries, a heuristic: whatever it leaves there, the bounds stay valid -- and
-        // k_screen_mx then overwrites its value.  (Why: profiles/README.md, "packed-FMA kernels beside MFMA kernels".)
-        if (round == 0) {
-            hipError_t e = launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, true, s);
-            if (e != hipSuccess) return e;
-            return launch_mx_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, b.kept_mx_nct, 0, b.kept_mx_acap, s);
-        }
-        return launch_mx_any(b, b.items_pick + b.n_pairs, 0, b.n_items + 4, b.n_pairs, b.kept_mx_nct, 0, b.kept_mx_acap, s);
+        // bounded search on the matrix pipe: the pick's value (the pair's upper bound) comes from the matrix kernel, and so
+        // do, for the first pick, the row / column minima from which k_lb_topk chooses the third round's queries (the
+        // generated block's `emit` form) -- no packed-FMA kernel runs under this precision any more (why that matters:
+        // profiles/README.md, "packed-FMA kernels beside MFMA kernels")
+        if (round == 0) return launch_mx_emit(b, b.items_pick, b.n_items + 1, b.n_pairs, b.kept_mx_nct, b.kept_mx_acap, s);
+        return launch_mx_any(b, b.items_pick + b.n_pairs, 0, b.n_items + 4, b.n_pairs, b.kept_mx_nct, 0, b.kept_mx_acap, s, 1);
     }
     if (round == 0) return launch_fast_any(b, b.items_pick, 0, b.n_items + 1, b.n_pairs, max_na, max_nbp, true, s);
     return launch_fast_any(b, b.items_pick + b.n_pairs, 0, b.n_items + 4, b.n_pairs, max_na, max_nbp, false, s);
@@ -1931,8 +2088,8 @@ hipError_t launch_screen_none(const BatchDev& b, int work_begin, int n_work, hip
 hipError_t launch_lb_topk(const BatchDev& b, int max_n, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_lb_topk, dim3(2 * b.n_pairs), dim3(256), (size_t)max_n * 4, s, b.pairs, b.pick_idx, b.emit,
-                       b.emit_rows, b.emit_cols, b.qlist);
+    hipLaunchKernelGGL(k_lb_topk, dim3((2 * b.n_pairs + 3) / 4), dim3(256), (size_t)max_n * 16, s, b.pairs, b.n_pairs, b.pick_idx,
+                       b.emit, b.emit_rows, b.emit_cols, max_n, b.qlist);
     return hipGetLastError();
 }
 
@@ -1953,6 +2110,16 @@ hipError_t launch_lb_spread(const BatchDev& b, hipStream_t s)
 hipError_t launch_lb_keep(const BatchDev& b, int final, int cap, hipStream_t s)
 {
     if (b.n_pairs <= 0) return hipSuccess;
+    if (b.lb_mx > 0 && b.kept_mx_nct > 0) {
+        if (!final)
+            hipLaunchKernelGGL(k_lb_keep_mx<false>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx,
+                               (const int32_t*)nullptr, b.klist, b.items_lb + cap, b.n_items + 3, b.stats, b.flag);
+        else
+            hipLaunchKernelGGL(k_lb_keep_mx<true>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx,
+                               (const int32_t*)(b.pick_idx + b.n_pairs), b.klist, b.items_lb + 2 * (size_t)cap, b.n_items + 5, b.stats,
+                               (uint8_t*)nullptr);
+        return hipGetLastError();
+    }
     if (!final)
         hipLaunchKernelGGL(k_lb_keep<false>, dim3(b.n_pairs), dim3(256), 0, s, b.pairs, b.lb32, b.sq32, b.pick_idx,
                            (const int32_t*)nullptr, b.items_lb + cap, b.n_items + 3, b.stats, b.lb_mx > 0 ? b.flag : (uint8_t*)nullptr);
@@ -1966,9 +2133,10 @@ hipError_t launch_lb_keep(const BatchDev& b, int final, int cap, hipStream_t s)
 hipError_t launch_screen_kept(const BatchDev& b, int max_na, int max_nbp, int cap, hipStream_t s)
 {
     if (cap <= 0) return hipSuccess;
-    // every pair of the batch takes the same variant of the matrix-pipe screen: the survivors go through it (runs of <= 8
-    // candidates from the device queue, one wave per candidate)
-    if (b.kept_mx_nct > 0) return launch_mx_any(b, b.items_lb + 2 * (size_t)cap, 0, b.n_items + 5, cap, b.kept_mx_nct, 0, b.kept_mx_acap, s);
+    // every pair of the batch takes the same variant of the matrix-pipe screen: the survivors go through it (<= 8 entries
+    // of a pair's list of survivors per queue item, one wave per candidate)
+    if (b.kept_mx_nct > 0)
+        return launch_mx_any(b, b.items_lb + 2 * (size_t)cap, 0, b.n_items + 5, cap, b.kept_mx_nct, 0, b.kept_mx_acap, s, 4, b.klist);
     return launch_fast_any(b, b.items_lb + 2 * (size_t)cap, 0, b.n_items + 5, cap, max_na, max_nbp, false, s);
 }
 

@@ -911,6 +911,30 @@ def test_lower_bounds_never_exceed_the_exact_cost(engine, oracle, mm, na, nb, ma
     assert (lb / np.maximum(oc ** 2, 1e-30)).mean() > 0.5          # every stride-th point: most of H^2 on these noisy blobs (0.74 - 0.99)
 
 
+@pytest.mark.parametrize("na,nb", [(64, 64), (65, 97), (223, 223), (240, 200), (521, 521), (300, 521), (521, 97), (528, 528), (512, 449)])
+def test_first_pick_leaves_row_and_column_minima(engine, oracle, mm, na, nb):
+    """The `emit` form of the generated matrix block (k_screen_mx_emit, test hook mm_pick_minima): the squared distance from
+    every reference point to its nearest rotated target point and from every target point to its nearest reference point,
+    against numpy in f64, within the kernel's error bound e2; their maximum is the screened value and brackets the oracle's
+    Hausdorff distance.  (k_lb_topk only ranks them -- a wrong minimum would cost tightness, not validity -- so nothing
+    else in the suite would notice.)"""
+    rng = np.random.default_rng(5 + 7 * na + nb)
+    ref, tgt = blob(rng, na), blob(rng, nb) + rng.normal(0, 0.03, (nb, 2))
+    c = tgt.mean(axis=0)
+    ref, tgt = ref - c, tgt - c
+    for th in (0.0, 0.37, -2.9):
+        rows, cols, val, e2 = engine.pick_minima(ref, tgt, th, (0.0, 0.0), skip_zero=False)
+        cs, sn = np.cos(th), np.sin(th)
+        rt = np.stack([tgt[:, 0] * cs - tgt[:, 1] * sn, tgt[:, 0] * sn + tgt[:, 1] * cs], 1)
+        d2 = ((ref[:, None, :] - rt[None, :, :]) ** 2).sum(2)
+        assert rows.shape == (na,) and cols.shape == (nb,)
+        assert np.abs(rows - d2.min(1)).max() <= e2 + 1e-12, "row minima"
+        assert np.abs(cols - d2.min(0)).max() <= e2 + 1e-12, "column minima"
+        assert val == max(rows.max(), cols.max())
+        h = oracle.costs_over_angles(ref, tgt, np.array([th]), 0.0, 0.0)[0]
+        assert abs(val - h * h) <= e2 + 1e-12
+
+
 def test_matrix_screen_small_batches_fill_the_workgroup(engine, oracle, mm):
     """a single search of 361 candidates used to get one candidate per 256-thread workgroup (three of four waves
     idle); now at least four.  Same result at 1, 3, 4, 5 and 361 candidates."""

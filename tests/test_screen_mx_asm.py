@@ -80,8 +80,9 @@ class Max:
         return Max(self.h[0] | o.h[0], self.h[1] | o.h[1])
 
 
-def _run(nct, carry, nrt):
-    prog, stride, clobbers = _program(f"{nct}{'C' if carry else ''}")
+def _run(nct, carry, nrt, emit=False):
+    prog, stride, clobbers = _program(f"{nct}{'E' if emit else ('C' if carry else '')}")
+    colstore = {}                # emit: 256-byte slot of the column store -> Min written
     nloop, tail = (nrt - 1) // 2, (nrt - 1) & 1
     R = {}                       # vector register -> Min / Max / ("A", row tile) / ("B", column tile) / ("addr", bytes) / ("rs", bytes)
     loading, mfma_at, valu_at = set(), {}, {}
@@ -254,7 +255,10 @@ def _run(nct, carry, nrt):
             src, off = args[1].split(" offset:")
             src, off = _regs(src), int(off)
             touch(src, src)
-            if a0 == "%4":
+            if a0 == "%10":
+                assert emit and off % 256 == 0 and off // 256 not in colstore
+                colstore[off // 256] = R[src[0]]
+            elif a0 == "%4":
                 assert off % stride == 0
                 v = off // stride
                 if v == 0:
@@ -276,11 +280,11 @@ def _run(nct, carry, nrt):
             raise AssertionError("unknown instruction: " + ln)
         pc = nxt
     assert not loading and result is not None
-    return dict(gens=gens, result=result, store=store, **st)
+    return dict(gens=gens, result=result, store=store, colstore=colstore, **st)
 
 
-def _check(nct, carry, nrt):
-    r = _run(nct, carry, nrt)
+def _check(nct, carry, nrt, emit=False):
+    r = _run(nct, carry, nrt, emit)
     assert r["n_mfma"] == nrt * nct
     # row minima: every row tile through the scratch in order, each complete, element by element, half by half
     assert len(r["gens"]) == nrt
@@ -307,10 +311,25 @@ def _check(nct, carry, nrt):
             assert len(w) == 1, "a slot of the row store is written once per block"
             for h in range(2):
                 assert w[0].h[h] == want_rows[rt] | {("PREV", rt)}, f"row store slot {rt}"
+    if emit:
+        # the column store: lane l of slot p holds column 64 p + l -- the lower half column tile 2p, the upper half 2p + 1;
+        # an odd last tile in both halves -- each the COMPLETE minimum of its column tile
+        assert sorted(r["colstore"]) == list(range((nct + 1) // 2))
+        for p_, w in r["colstore"].items():
+            assert w.h[0] == want_cols[2 * p_]
+            assert w.h[1] == want_cols[2 * p_ + 1 if 2 * p_ + 1 < nct else 2 * p_]
     return r
 
 
 NRTS = [1, 2, 3, 4, 5, 6, 7, 17, 33]
+
+
+@pytest.mark.parametrize("nct", range(2, 18))
+def test_emit_form_leaves_row_and_column_minima(nct):
+    """carry + column store (the pick of a bounded search): the row store holds every row's minimum, the column store every
+    column's, and the value that leaves is still the maximum over the column minima"""
+    for nrt in NRTS:
+        _check(nct, True, nrt, emit=True)
 
 
 @pytest.mark.parametrize("carry", [False, True])

@@ -403,20 +403,26 @@ def restore(s, pipe, snap):
     s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.bpar, pipe.red, pipe.next_b, pipe.busy = copy.deepcopy(snap)
 
 
-def column_final(s, nct):
+def column_final(s, nct, emit=False):
     """lanes l and l + 32 hold different rows of column l & 31.  The swap leaves the lower halves of two column tiles in one
-    register and the upper halves in the other; their minimum is complete for both tiles."""
+    register and the upper halves in the other; their minimum is complete for both tiles.
+    emit: the complete column minima also go to a column store in LDS (%10: this lane's dword of its first 64 columns) --
+    lane l of pair p holds column 64 p + l, 256 bytes per pair; an odd last tile holds its 32 columns in both halves."""
     done = []
     for p in range(nct // 2):
         a, b = CM + 2 * p, CM + 2 * p + 1
         s.ins(f"v_permlane32_swap_b32 v{a}, v{b}", reads=[a, b], writes=[a, b], permlane=True)
         s.ins(f"v_min_i32 v{a}, v{a}, v{b}", reads=[a, b], writes=[a], valu=True)
+        if emit:
+            s.ins(f"ds_write_b32 %10, v{a} offset:{256 * p}", reads=[a])
         done.append(a)
     if nct & 1:
         a = CM + nct - 1
         s.ins(f"v_mov_b32 v{T}, v{a}", reads=[a], writes=[T], valu=True)
         s.ins(f"v_permlane32_swap_b32 v{a}, v{T}", reads=[a, T], writes=[a, T], permlane=True)
         s.ins(f"v_min_i32 v{a}, v{a}, v{T}", reads=[a, T], writes=[a], valu=True)
+        if emit:
+            s.ins(f"ds_write_b32 %10, v{a} offset:{256 * (nct // 2)}", reads=[a])
         done.append(a)
     while len(done) > 1:
         nxt = []
@@ -431,7 +437,8 @@ def column_final(s, nct):
     s.ins(f"v_max_i32 %0, v{done[0]}, v{ROWMAX}", reads=[done[0], ROWMAX])
 
 
-def generate(nct, carry):
+def generate(nct, carry, emit=False):
+    assert carry or not emit
     s = Stream()
     pipe = Pipe(s, nct, carry)
     # ---- prologue: row tile 0 -------------------------------------------------------------------------------------------
@@ -487,7 +494,7 @@ def generate(nct, carry):
         pipe.reduce_blocking(X[1], P, Q, 128)
         s.label("4:")
         # both paths end behind the final instructions of reduce_blocking: the same distances to every hazard below
-        column_final(s, nct)
+        column_final(s, nct, emit)
         s.wait()                                       # (the unused B and A requests of the last steps)
         text = s.out[m0:]
         del s.out[m0:]
@@ -665,6 +672,15 @@ def main():
                     f.write(f'    "{line}\\n" \\\n')
                 f.write('    ""\n')
                 f.write(f"#define MM_SCREEN_MX_CLOBBERS_{name} " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
+        for nct in range(NCT_MIN, NCT_MAX + 1):
+            out, regs = generate(nct, True, True)
+            total += len(out)
+            f.write(f"// ---- nct = {nct}, carry + column store (the pick of a bounded search leaves its row and column minima): {len(out)} instructions\n")
+            f.write(f"#define MM_SCREEN_MX_ASM_{nct}E \\\n")
+            for line in out:
+                f.write(f'    "{line}\\n" \\\n')
+            f.write('    ""\n')
+            f.write(f"#define MM_SCREEN_MX_CLOBBERS_{nct}E " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
         for nb in BOUND_NB:
             out, regs = generate_bound(nb)
             total += len(out)
@@ -688,8 +704,19 @@ def main():
                         "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"v\"(vPERM), \"s\"(nloop), \"s\"(tail), \"v\"(vRS)\n"
                         f"                     : MM_SCREEN_MX_CLOBBERS_{name});\n"
                         "        return m;\n    }\n};\n")
+        f.write("template <int NCT> struct MxEmit;\n")
+        for nct in range(NCT_MIN, NCT_MAX + 1):
+            f.write(f"template <> struct MxEmit<{nct}> {{\n"
+                    "    static __device__ __forceinline__ int run(unsigned vB, unsigned vA, unsigned vRW, unsigned vRR, unsigned vPERM,\n"
+                    "                                              int nloop, int tail, unsigned vRS, unsigned vCS)\n    {\n"
+                    "        int m, counter;\n"
+                    f"        asm volatile(MM_SCREEN_MX_ASM_{nct}E\n"
+                    "                     : \"=&v\"(m), \"=&s\"(counter)\n"
+                    "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"v\"(vPERM), \"s\"(nloop), \"s\"(tail), \"v\"(vRS), \"v\"(vCS)\n"
+                    f"                     : MM_SCREEN_MX_CLOBBERS_{nct}E);\n"
+                    "        return m;\n    }\n};\n")
         f.write("#endif\n")
-    print(total, "instructions in", 2 * (NCT_MAX - NCT_MIN + 1), "blocks ->", os.path.normpath(dst))
+    print(total, "instructions in", 3 * (NCT_MAX - NCT_MIN + 1), "blocks ->", os.path.normpath(dst))
 
 
 if __name__ == "__main__":
