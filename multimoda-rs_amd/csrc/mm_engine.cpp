@@ -450,6 +450,20 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     // matrix-pipe screen: one WAVE per candidate, four waves per workgroup -- a workgroup of fewer than four candidates
     // leaves waves idle for the whole item (small batches: a single search of 361 candidates)
     if (use_mx) apb = std::max(apb, 4);
+    // ... and of SMALL sets more of them: a work item stages the pair's rows once (global loads, two barriers: ~3 us with
+    // two workgroups per CU to hide it), and 8 candidates of 7 x 7 tiles are over in 3.6 us.  A wave should see ~600 tiles
+    // per item (17 x 17 tiles: 2 candidates, as measured above; 7 x 7: 12), as far as the batch has candidates for
+    // 24 workgroups per CU.
+    const int64_t apb_fill = std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs);
+    auto apb_of = [&](int p) {
+        if (!use_mx || pair_key[(size_t)p] < 2) return apb;
+        const PairDesc& d = host_pairs[p];
+        int nct = 0, multi = 0;
+        mx_variant(d.n_tgt, &nct, &multi);
+        const int64_t tiles = (int64_t)((d.n_ref + 31) / 32) * ((d.n_tgt + 31) / 32);
+        const int64_t per_wave = std::min<int64_t>(16, std::max<int64_t>(2, (578 + tiles - 1) / tiles));
+        return (int)std::max<int64_t>(apb, std::min<int64_t>(4 * per_wave, apb_fill));
+    };
     groups.clear();
     {
         // balanced chunks: ceil(n / apb) workgroups whose sizes differ by at most one (a 90-candidate
@@ -461,7 +475,10 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         for (int p = 0; p < P; ++p) order[(size_t)p] = p;
         if (use_mx) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return pair_key[(size_t)x] < pair_key[(size_t)y]; });
         std::vector<int64_t> wstart((size_t)P + 1, 0);
-        for (int q = 0; q < P; ++q) wstart[(size_t)q + 1] = wstart[(size_t)q] + (host_pairs[order[(size_t)q]].n_ang + apb - 1) / apb;
+        for (int q = 0; q < P; ++q) {
+            const int ap = apb_of(order[(size_t)q]);
+            wstart[(size_t)q + 1] = wstart[(size_t)q] + (host_pairs[order[(size_t)q]].n_ang + ap - 1) / ap;
+        }
         if (wstart[(size_t)P] > INT32_MAX) return set_error(MM_ERR_TOO_LARGE, "too many work items");
         host_work.resize((size_t)wstart[(size_t)P]);
         WorkItem* hw = host_work.data();

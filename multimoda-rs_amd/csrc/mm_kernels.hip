@@ -560,6 +560,7 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 static constexpr int MX_TMAX = MM_SCREEN_MX_NCT_MAX;          // column tiles of one block
 static constexpr int MX_ROW_TILES_MAX = 64;                     // row tiles (LDS: 1 KB of fragments per row tile)
 static constexpr int MX_RED = 32 * (MM_SCREEN_MX_RED_STRIDE / 4);   // ints of one wave's reduction scratch
+static constexpr int MX_ITEM = 64;                              // candidates of one work item, at most (the engine's apb)
 
 static __device__ __forceinline__ void mx_split(float X, _Float16& h, _Float16& l)
 {
@@ -696,8 +697,8 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
                                                                       //            own copy, for the candidate it is on
     int* s_redx = reinterpret_cast<int*>(s_bw + WAVES * NCT * 64);   // [WAVES][MX_RED] row-reduction scratch, one per wave
     int* s_rsx = s_redx + WAVES * MX_RED;                             // MULTI: [WAVES][a_cap * 32] row store, one per wave
-    float* s_cs = reinterpret_cast<float*>(s_rsx + (MULTI ? WAVES * a_cap * 32 : 0));   // [8][2] cos, sin of the work item's candidates
-    int* s_ci = reinterpret_cast<int*>(s_cs + 16);                    // [8] their indices in the pair's list
+    float* s_cs = reinterpret_cast<float*>(s_rsx + (MULTI ? WAVES * a_cap * 32 : 0));   // [MX_ITEM][2] cos, sin of the work item's candidates
+    int* s_ci = reinterpret_cast<int*>(s_cs + 2 * MX_ITEM);           // [MX_ITEM] their indices in the pair's list
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
     h4v* s_b = s_bw + wave * NCT * 64;
@@ -727,10 +728,10 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
         // the candidates' cos / sin once per work item (a global load at the top of every candidate would be exposed).
         // sel (the survivors of a bounded search): the item is entries a0 .. a0 + cnt of the pair's list of candidates,
         // not a run of consecutive ones
-        if (tid < 16 && (tid >> 1) < w.cnt) {
-            const int a = sel ? sel[pd.out_off + w.a0 + (tid >> 1)] : w.a0 + (tid >> 1);
-            s_cs[tid] = (tid & 1) ? sinv[pd.tab_off + a] : cosv[pd.tab_off + a];
-            if (!(tid & 1)) s_ci[tid >> 1] = a;
+        for (int t = tid; t < 2 * w.cnt; t += 64 * WAVES) {
+            const int a = sel ? sel[pd.out_off + w.a0 + (t >> 1)] : w.a0 + (t >> 1);
+            s_cs[t] = (t & 1) ? sinv[pd.tab_off + a] : cosv[pd.tab_off + a];
+            if (!(t & 1)) s_ci[t >> 1] = a;
         }
         mx_stage_rows<64 * WAVES>(s_a, nrt, na, ptx + pd.ref_off, pty + pd.ref_off, S, tid);      // padding rows duplicate the last reference point
         if constexpr (!MULTI) {
@@ -889,7 +890,7 @@ static hipError_t launch_mx_emit(const BatchDev& b, const WorkItem* work, const 
 size_t lds_bytes_mx(int nct, bool multi, int a_cap, int waves)
 {
     return (size_t)a_cap * 64 * 16 + (size_t)waves * nct * 64 * 8 + (size_t)waves * MX_RED * 4 +
-           (multi ? (size_t)waves * a_cap * 32 * 4 : 0) + 128;
+           (multi ? (size_t)waves * a_cap * 32 * 4 : 0) + (size_t)MX_ITEM * 12;
 }
 
 // n_dev == nullptr: one workgroup per item of the host-built list; else a device queue of at most `cap` items whose length is

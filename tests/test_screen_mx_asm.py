@@ -42,16 +42,20 @@ def _program(name):
         lines.append(m.group(1))
     stride = int(re.search(r"MM_SCREEN_MX_RED_STRIDE (\d+)", text).group(1))
     clob = re.search(rf"#define MM_SCREEN_MX_CLOBBERS_{name} (.*)", text).group(1)
-    return lines, stride, {int(x) for x in re.findall(r'"v(\d+)"', clob)}
+    return lines, stride, {int(x) for x in re.findall(r'"v(\d+)"', clob)} | {AG + int(x) for x in re.findall(r'"a(\d+)"', clob)}
+
+
+AG = 1000          # accumulation registers: a{i} is register AG + i
 
 
 def _regs(tok):
     tok = tok.strip()
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return list(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"v(\d+)", tok)
-    return [int(m.group(1))] if m else None
+        base = AG if m.group(1) == "a" else 0
+        return list(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    return [(AG if m.group(1) == "a" else 0) + int(m.group(2))] if m else None
 
 
 class Min:
@@ -239,6 +243,7 @@ def _run(nct, carry, nrt, emit=False):
                 val = [Min({("PREV", slot)}, {("PREV", slot)})]
             elif addr == "%2":
                 assert off % 512 == 0 and len(d) == 2 and off // 512 < nct
+                assert d[0] - AG in (4 * (off // 512), 4 * (off // 512) + 2), "column tile t lives in a[4t : 4t + 3]"
                 val = [("B", off // 512)] * 2
             elif addr == "%5":
                 assert off % 8 == 0 and len(d) == 2

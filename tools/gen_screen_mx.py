@@ -58,8 +58,9 @@ import copy
 import os
 
 INF = "0x7f800000"
-P, Q, R, S, X = 100, 116, 132, 148, [164, 180]
-ROWMAX, CM, ASET, T, ACC, AADDR, RSADDR, TP, BSET, LAND = 36, 40, [60, 64], 68, 72, 73, 74, 75, [80, 88], 196
+P, Q, R, S, X = 84, 100, 116, 132, [148, 164]
+ROWMAX, CM, ASET, T, ACC, AADDR, RSADDR, TP, LAND = 36, 40, [60, 64], 68, 72, 73, 74, 75, 180
+AG = 1000                 # register ids from here on are accumulation registers: AG + i is a{i}
 NCT_MIN, NCT_MAX = 2, 17
 RED_STRIDE = 136          # bytes between rows of the reduction scratch (34 dwords: 8-byte aligned reads, 2-way conflicts)
 MFMA_STATES = 12          # instructions between an 8-pass MFMA and the first touch of its destination (11 required)
@@ -125,6 +126,10 @@ class Stream:
         return len(self.out)
 
 
+def regname(r):
+    return f'"a{r - AG}"' if r >= AG else f'"v{r}"'
+
+
 def rng(base, n):
     return list(range(base, base + n))
 
@@ -135,30 +140,30 @@ class Pipe:
     def __init__(self, s, nct, carry):
         self.s, self.nct, self.carry = s, nct, carry
         self.pending = None                 # group whose minima are still to be issued
-        self.bpar = 0                       # B operand set of the next group
         self.red = None                     # [buffer, list of stages still to run, row-store offset] of the reduction in progress
-        self.next_b = None                  # tiles whose B fragments are in flight / loaded for the next group
         self.busy = set()                   # result buffers holding values still to be folded (bookkeeping check)
 
     # ---- operands -------------------------------------------------------------------------------------------------
     def load_b(self, tiles):
         # a column fragment is stored as 8 bytes per lane -- (x1, x2, y1, y2) or (256, 1, n2h, n2l) -- and read twice: the K
-        # slots 4..7 repeat slots 0..3 (the row fragments are laid out to match; for the norm half their slots 4..7 are 0)
-        base = BSET[self.bpar]
-        for i, t in enumerate(tiles):
-            d = base + 4 * i
-            self.s.ins(f"ds_read_b64 v[{d}:{d + 1}], %2 offset:{t * 512}", writes=rng(d, 2), lds_load=True)
-            self.s.ins(f"ds_read_b64 v[{d + 2}:{d + 3}], %2 offset:{t * 512}", writes=rng(d + 2, 2), lds_load=True)
-        self.next_b = list(tiles)
+        # slots 4..7 repeat slots 0..3 (the row fragments are laid out to match; for the norm half their slots 4..7 are 0).
+        # It goes into ACCUMULATION registers a[4t : 4t + 3] and stays there for the whole candidate: every MFMA of column
+        # tile t takes it from there.  (Until round 4 it was read again for every tile: 1 KB of LDS traffic per MFMA, a third
+        # of the CU's LDS bandwidth, under which the row reductions queued -- tools/exp_mx2.sh: 7 % of the launch at 17 x 17
+        # tiles, 12 % at 7 x 7.)
+        for t in tiles:
+            d = AG + 4 * t
+            self.s.ins(f"ds_read_b64 a[{4 * t}:{4 * t + 1}], %2 offset:{t * 512}", writes=rng(d, 2), lds_load=True)
+            self.s.ins(f"ds_read_b64 a[{4 * t + 2}:{4 * t + 3}], %2 offset:{t * 512}", writes=rng(d + 2, 2), lds_load=True)
 
     def load_a(self, reg, offset):
         self.s.ins(f"ds_read_b128 v[{reg}:{reg + 3}], v{AADDR} offset:{offset}", reads=[AADDR], writes=rng(reg, 4), lds_load=True)
 
-    def mfma(self, d, a, b):
+    def mfma(self, d, a, tile):
         assert d not in self.busy, f"result buffer v{d} overwritten before it was folded"
         self.busy.add(d)
-        self.s.ins(f"v_mfma_f32_32x32x16_f16 v[{d}:{d + 15}], v[{a}:{a + 3}], v[{b}:{b + 3}], 0",
-                   reads=rng(a, 4) + rng(b, 4), writes=rng(d, 16), mfma=True)
+        self.s.ins(f"v_mfma_f32_32x32x16_f16 v[{d}:{d + 15}], v[{a}:{a + 3}], a[{4 * tile}:{4 * tile + 3}], 0",
+                   reads=rng(a, 4) + rng(AG + 4 * tile, 4), writes=rng(d, 16), mfma=True)
 
     # ---- the minima of one group, as a list of closures -------------------------------------------------------------
     def minima(self, g):
@@ -303,44 +308,36 @@ class Pipe:
         self.red_final(off)
 
     # ---- one step -----------------------------------------------------------------------------------------------------
-    def step(self, g, nxt, extra=None, red_n=0):
-        """g: the group whose MFMAs are issued now (its B fragments were requested a step ago); nxt: the tiles of the group
-        after it (their B fragments are requested here); extra: a closure issued with the prefetch (A loads); red_n: stages
-        of the reduction in progress to run in this step."""
+    def step(self, g, extra=None, red_n=0):
+        """g: the group whose MFMAs are issued now; extra: a closure issued with the step's LDS requests (A loads, the
+        candidate's other B fragments); red_n: stages of the reduction in progress to run in this step."""
         s = self.s
-        assert self.next_b == g["tiles"]
-        b = BSET[self.bpar]
-        self.bpar ^= 1
-        s.wait()
+        if s.loading:
+            s.wait()
         prev, self.pending = self.pending, g
         m = self.minima(prev) if prev is not None else []
         half = len(m) // 2 if len(g["tiles"]) == 2 else 0
 
-        self.mfma(g["bufs"][0], g["a"], b)
+        # The LDS requests of the step go out FIRST, right behind the step's wait (the A fragment of the next row tile, one
+        # stage of the reduction in progress), so that the next step's wait finds them done.
+        if extra is not None:
+            extra()
+        self.red_run(min(red_n, 1))
+        self.mfma(g["bufs"][0], g["a"], g["tiles"][0])
         for f in m[:half]:
             f()
         if len(g["tiles"]) == 2:
             # one MFMA, half of the previous group's minima, the other MFMA, the other half: a wave does not queue a second
             # MFMA right behind its own first one (the matrix pipe takes 32 cycles per MFMA, 16 minima take 64)
-            self.mfma(g["bufs"][1], g["a"], b + 4)
-        self.load_b(nxt)
-        if extra is not None:
-            extra()
-        if red_n <= 1:
-            self.red_run(red_n)
-            for f in m[half:]:
-                f()
-        else:
-            # a short row tile: several stages in one step, each behind a wait of its own; the minima go first so that the
-            # first of those waits has something in front of it
-            self.red_run(1)
-            for f in m[half:]:
-                f()
-            for _ in range(red_n - 1):
-                if self.red is not None:
-                    if self.red[1][0][0]:
-                        s.wait()
-                    self.red_run(1)
+            self.mfma(g["bufs"][1], g["a"], g["tiles"][1])
+        for f in m[half:]:
+            f()
+        # a short row tile: several stages in one step, each behind a wait of its own
+        for _ in range(red_n - 1):
+            if self.red is not None:
+                if self.red[1][0][0]:
+                    s.wait()
+                self.red_run(1)
         if prev is not None and prev["kind"] != "init":
             for d in prev["bufs"]:
                 self.busy.discard(d)
@@ -367,14 +364,13 @@ def row_tile(nct, k):
     return G
 
 
-def run_row_tile(pipe, nct, k, a_offset_next, a_reg_next, red_prev, red_off):
+def run_row_tile(pipe, nct, k, a_offset_next, a_reg_next, red_prev, red_off, first=False):
     """steps of row tile k; in its second step the A fragment of row tile k + 1 is requested (offset relative to v73);
     red_prev: the row tile before is reduced beside this one (its row-store offset: red_off)"""
     G = row_tile(nct, k)
     slots = len(G) - 1                            # the steps after the init step: where the reduction's stages go
     narrow = slots >= 6                           # four values at a time (7 stages); else all 16 at once (3 round trips)
     for i, g in enumerate(G):
-        nxt = G[i + 1]["tiles"] if i + 1 < len(G) else [nct - 1]
         extra = None
         red_n = 0
         if i == 0 and red_prev:
@@ -391,16 +387,35 @@ def run_row_tile(pipe, nct, k, a_offset_next, a_reg_next, red_prev, red_off):
         if i >= 1 and pipe.red is not None:
             left, slots_left = len(pipe.red[1]), len(G) - i
             red_n = (left + slots_left - 1) // slots_left
-        pipe.step(g, nxt, extra, red_n)
+        if i == 0 and first:
+            # the candidate's other B fragments go out behind the first MFMA's operands (the init tile's came with the prologue)
+            extra = (lambda: pipe.load_b(range(nct - 1)))
+        pipe.step(g, extra, red_n)
     assert pipe.red is None, "the reduction must be over before the next row tile starts"
 
 
 def snapshot(s, pipe):
-    return copy.deepcopy((s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.bpar, pipe.red, pipe.next_b, pipe.busy))
+    return copy.deepcopy((s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.red, pipe.busy))
 
 
 def restore(s, pipe, snap):
-    s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.bpar, pipe.red, pipe.next_b, pipe.busy = copy.deepcopy(snap)
+    s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.red, pipe.busy = copy.deepcopy(snap)
+
+
+def merge_snapshots(a, b):
+    """The state behind a join of two paths: every hazard at the distance of the path that is CLOSER to it (the code
+    generated from it pads for the worse of the two and is valid on both); the pipeline's own bookkeeping is taken from
+    `a` (the caller generates from merge(a, b) and merge(b, a) and requires the same text)."""
+    (na, ma, va, la, *ra), (nb, mb, vb, lb, *rb) = a, b
+    n = max(na, nb)
+
+    def closest(xa, xb):
+        out = {}
+        for r in set(xa) | set(xb):
+            d = min(na - xa[r] if r in xa else 1 << 30, nb - xb[r] if r in xb else 1 << 30)
+            out[r] = n - d
+        return out
+    return copy.deepcopy((n, closest(ma, mb), closest(va, vb), la | lb, *ra))
 
 
 def column_final(s, nct, emit=False):
@@ -450,15 +465,17 @@ def generate(nct, carry, emit=False):
     for ct in range(nct):
         s.ins(f"v_mov_b32 v{CM + ct}, {INF}", writes=[CM + ct], valu=True)
     s.ins(f"v_mov_b32 v{ROWMAX}, 0", writes=[ROWMAX], valu=True)
-    run_row_tile(pipe, nct, 0, 1024, ASET[1], False, 0)
+    run_row_tile(pipe, nct, 0, 1024, ASET[1], False, 0, first=True)
     s.raw("s_mov_b32 %1, %7")
     s.raw("s_cmp_eq_u32 %1, 0")
     s.raw("s_cbranch_scc1 2f")
     after_prologue = snapshot(s, pipe)
     s.label("1:")
     # ---- loop body: row tiles (2i + 1, 2i + 2), v73 = A address of row tile 2i; generated twice, emitted once ------------------
-    bodies = []
-    for it in range(2):
+    # The body is entered from the prologue and from its own end: it is generated from the MERGED state of the two (every
+    # hazard at the distance of the closer path), until the text no longer changes -- then that text is valid on both edges.
+    def body_from(entry):
+        restore(s, pipe, entry)
         m0 = s.mark()
         run_row_tile(pipe, nct, 1, 2048, ASET[0], True, 0)
         run_row_tile(pipe, nct, 2, 3072, ASET[1], True, 128)     # (the last iteration requests one fragment too many: read, never used)
@@ -468,12 +485,20 @@ def generate(nct, carry, emit=False):
         s.raw("s_sub_u32 %1, %1, 1")
         s.raw("s_cmp_lg_u32 %1, 0")
         s.raw("s_cbranch_scc1 1b")
-        bodies.append(s.out[m0:])
-        if it == 0:
-            keep = s.mark()
-            after_body = snapshot(s, pipe)
-    assert bodies[0] == bodies[1], "the loop body must leave the pipeline in the state it found it in"
-    del s.out[keep:]
+        text, end = s.out[m0:], snapshot(s, pipe)
+        del s.out[m0:]
+        return text, end
+
+    body, after_body = body_from(after_prologue)
+    for _ in range(8):
+        nxt, end = body_from(merge_snapshots(after_prologue, after_body))
+        stable = nxt == body
+        body, after_body = nxt, end
+        if stable:
+            break
+    else:
+        raise AssertionError("the loop body does not settle")
+    s.out += body
     s.label("2:")
 
     # ---- after the loop: odd row-tile count -> epilogue; even -> one more row tile, then the epilogue -----------------------------
@@ -500,7 +525,10 @@ def generate(nct, carry, emit=False):
         del s.out[m0:]
         return text
 
-    t_a, t_b = tail_and_epilogue(after_prologue), tail_and_epilogue(after_body)
+    # the code behind the loop is entered from the prologue (no iteration) and from the loop: generated once, from the merged
+    # state (padded for whichever path is closer to each MFMA), and checked to be what either state alone would accept
+    t_a = tail_and_epilogue(merge_snapshots(after_prologue, after_body))
+    t_b = tail_and_epilogue(merge_snapshots(after_body, after_prologue))
     assert t_a == t_b, "the code behind the loop must not depend on whether the loop ran"
     s.out += t_a
     return s.out, sorted(s.used)
@@ -671,7 +699,7 @@ def main():
                 for line in out:
                     f.write(f'    "{line}\\n" \\\n')
                 f.write('    ""\n')
-                f.write(f"#define MM_SCREEN_MX_CLOBBERS_{name} " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
+                f.write(f"#define MM_SCREEN_MX_CLOBBERS_{name} " + ", ".join(regname(r) for r in regs) + ', "scc", "memory"\n')
         for nct in range(NCT_MIN, NCT_MAX + 1):
             out, regs = generate(nct, True, True)
             total += len(out)
@@ -680,7 +708,7 @@ def main():
             for line in out:
                 f.write(f'    "{line}\\n" \\\n')
             f.write('    ""\n')
-            f.write(f"#define MM_SCREEN_MX_CLOBBERS_{nct}E " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
+            f.write(f"#define MM_SCREEN_MX_CLOBBERS_{nct}E " + ", ".join(regname(r) for r in regs) + ', "scc", "memory"\n')
         for nb in BOUND_NB:
             out, regs = generate_bound(nb)
             total += len(out)
@@ -688,7 +716,7 @@ def main():
             for line in out:
                 f.write(f'    "{line}\\n" \\\n')
             f.write('    ""\n')
-            f.write(f"#define MM_BOUND_MX_CLOBBERS_{nb} " + ", ".join(f'"v{r}"' for r in regs) + ', "scc", "memory"\n')
+            f.write(f"#define MM_BOUND_MX_CLOBBERS_{nb} " + ", ".join(regname(r) for r in regs) + ', "scc", "memory"\n')
         # the dispatch: one inline function per block, selected at compile time
         f.write("\n#ifdef __HIPCC__\n")
         f.write("template <int NCT, bool CARRY> struct MxMain;\n")
