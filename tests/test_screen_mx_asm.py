@@ -172,6 +172,13 @@ def _run(nct, carry, nrt, emit=False):
                 R[d[0]] = Max() if args[1] == "0" else Min()
             wrote(d)
             st["n_valu"] += 1
+        elif op == "v_add_u32" and args[2] == "%4":
+            d = _regs(args[0])
+            touch(d, [])
+            assert int(args[1]) == 8 * stride
+            R[d[0]] = ("rw", 8)                      # the reduction scratch from row 8 on
+            wrote(d)
+            st["n_valu"] += 1
         elif op == "v_add_u32":
             d, src = _regs(args[0]), _regs(args[2])
             assert d == src and R[d[0]][0] in ("addr", "rs")
@@ -223,6 +230,26 @@ def _run(nct, carry, nrt, emit=False):
                 R[d[v]] = Min({(rt, ct, v, 0)}, {(rt, ct, v, 1)})
                 mfma_at[d[v]] = st["states"]
             st["n_mfma"] += 1
+        elif op == "ds_write2_b32":
+            a0 = args[0]
+            d0 = _regs(args[1])
+            d1, o0 = args[2].split(" offset0:")
+            o0, o1 = o0.split(" offset1:")
+            d1, o0, o1 = _regs(d1), int(o0), int(o1)
+            touch(d0 + d1, d0 + d1)
+            base = 0
+            if a0 != "%4":
+                areg = _regs(a0)
+                touch(areg, areg)
+                assert R[areg[0]] == ("rw", 8)
+                base = 8
+            for src, o in ((d0, o0), (d1, o1)):
+                assert (4 * o) % stride == 0 and o < 256
+                v = base + 4 * o // stride
+                if v == 0:
+                    gens.append({})
+                assert v == len(gens[-1]), "rows of the reduction scratch are written in order"
+                gens[-1][v] = R[src[0]]
         elif op in ("ds_read_b128", "ds_read_b64", "ds_read_b32"):
             d = _regs(args[0])
             addr, off = args[1].split(" offset:")
@@ -246,10 +273,10 @@ def _run(nct, carry, nrt, emit=False):
                 assert d[0] - AG in (4 * (off // 512), 4 * (off // 512) + 2), "column tile t lives in a[4t : 4t + 3]"
                 val = [("B", off // 512)] * 2
             elif addr == "%5":
-                assert off % 8 == 0 and len(d) == 2
+                assert off % 16 == 0 and len(d) == 4 and d[0] % 2 == 0
                 g = len(gens) - 1
                 assert len(gens[g]) == 16, "reduction scratch read before all 16 rows are written"
-                val = [Min({("R", g, off // 4 + i, 0)}, {("R", g, off // 4 + i, 1)}) for i in range(2)]
+                val = [Min({("R", g, off // 4 + i, 0)}, {("R", g, off // 4 + i, 1)}) for i in range(4)]
             else:
                 raise AssertionError(ln)
             for r, x in zip(d, val):

@@ -51,7 +51,7 @@ Register map (VGPR):
   v[196:211]            nct < 14: landing zone of the reduction (16 values of a row)
 Operands: %0 out: this lane's maximum; %1 =s loop counter; %2 vB (LDS byte address of this lane's B fragment in column
 tile 0, the wave's own copy); %3 vA (A fragment of row tile 0; the next ones 1024 bytes apart); %4 vRW / %5 vRR
-(row-reduction scratch: write / read address); %6 vPERM (4 * (lane ^ 32)); %7 s: loop iterations = (row tiles - 1) / 2;
+(row-reduction scratch: write / read address); %6 unused (a scalar zero: the halves meet through v_permlane32_swap); %7 s: loop iterations = (row tiles - 1) / 2;
 %8 s: 1 if the row-tile count is even (tail row tile); %9 (carry) vRS: this lane's slot in the row store of row tile 0
 (the next ones 128 bytes apart)."""
 import copy
@@ -62,7 +62,8 @@ P, Q, R, S, X = 84, 100, 116, 132, [148, 164]
 ROWMAX, CM, ASET, T, ACC, AADDR, RSADDR, TP, LAND = 36, 40, [60, 64], 68, 72, 73, 74, 75, 180
 AG = 1000                 # register ids from here on are accumulation registers: AG + i is a{i}
 NCT_MIN, NCT_MAX = 2, 17
-RED_STRIDE = 136          # bytes between rows of the reduction scratch (34 dwords: 8-byte aligned reads, 2-way conflicts)
+RED_STRIDE = 144          # bytes between rows of the reduction scratch (36 dwords: 16-byte aligned reads of a row's values)
+RW2 = 76                  # LDS address of row 8 of this lane's column in the reduction scratch (ds_write2_b32 reaches 255 dwords)
 MFMA_STATES = 12          # instructions between an 8-pass MFMA and the first touch of its destination (11 required)
 PERMLANE_STATES = 3       # a vector write and a v_permlane32_swap reading it (2 required)
 
@@ -198,6 +199,13 @@ class Pipe:
         return L
 
     # ---- the reduction of a finished row tile, in stages --------------------------------------------------------------
+    def red_write(self, buf):
+        """the 16 row minima of this lane's column to the reduction scratch, two rows per instruction"""
+        for v in range(0, 16, 2):
+            base, w = ("%4", v) if v < 8 else (f"v{RW2}", v - 8)
+            self.s.ins(f"ds_write2_b32 {base}, v{buf + v}, v{buf + v + 1} offset0:{w * RED_STRIDE // 4} offset1:{(w + 1) * RED_STRIDE // 4}",
+                       reads=[buf + v, buf + v + 1] + ([RW2] if v >= 8 else []))
+
     def red_final(self, off):
         """ACC holds this half's minimum of the row, T the other half's (ds_bpermute)."""
         s = self.s
@@ -224,15 +232,13 @@ class Pipe:
         s = self.s
 
         def write():
-            for v in range(16):
-                s.ins(f"ds_write_b32 %4, v{buf + v} offset:{v * RED_STRIDE}", reads=[buf + v])
+            self.red_write(buf)
             self.busy.discard(buf)                  # the row minima are on their way to LDS: the buffer is free
 
         if narrow:
             def read(c):
                 def f():
-                    s.ins(f"ds_read_b64 v[{T}:{T + 1}], %5 offset:{16 * c}", writes=rng(T, 2), lds_load=True)
-                    s.ins(f"ds_read_b64 v[{T + 2}:{T + 3}], %5 offset:{16 * c + 8}", writes=rng(T + 2, 2), lds_load=True)
+                    s.ins(f"ds_read_b128 v[{T}:{T + 3}], %5 offset:{16 * c}", writes=rng(T, 4), lds_load=True)
                 return f
 
             def fold(c, then):
@@ -255,8 +261,8 @@ class Pipe:
         t = LAND
 
         def read_all():
-            for q in range(8):
-                s.ins(f"ds_read_b64 v[{t + 2 * q}:{t + 2 * q + 1}], %5 offset:{8 * q}", writes=rng(t + 2 * q, 2), lds_load=True)
+            for q in range(4):
+                s.ins(f"ds_read_b128 v[{t + 4 * q}:{t + 4 * q + 3}], %5 offset:{16 * q}", writes=rng(t + 4 * q, 4), lds_load=True)
 
         def fold_all():
             for i in range(5):
@@ -290,13 +296,12 @@ class Pipe:
         (two free result buffers as landing zone and scratch), three LDS round trips in all."""
         s = self.s
         assert self.red is None and t not in self.busy and u not in self.busy
-        for v in range(16):
-            s.ins(f"ds_write_b32 %4, v{buf + v} offset:{v * RED_STRIDE}", reads=[buf + v])
+        self.red_write(buf)
         self.busy.discard(buf)
         self.red_prefetch(off)
         s.wait()
-        for q in range(8):
-            s.ins(f"ds_read_b64 v[{t + 2 * q}:{t + 2 * q + 1}], %5 offset:{8 * q}", writes=rng(t + 2 * q, 2), lds_load=True)
+        for q in range(4):
+            s.ins(f"ds_read_b128 v[{t + 4 * q}:{t + 4 * q + 3}], %5 offset:{16 * q}", writes=rng(t + 4 * q, 4), lds_load=True)
         s.wait()
         for i in range(5):
             s.ins(f"v_min3_i32 v{u + i}, v{t + 3 * i}, v{t + 3 * i + 1}, v{t + 3 * i + 2}", reads=rng(t + 3 * i, 3), writes=[u + i], valu=True)
@@ -458,6 +463,7 @@ def generate(nct, carry, emit=False):
     pipe = Pipe(s, nct, carry)
     # ---- prologue: row tile 0 -------------------------------------------------------------------------------------------
     s.ins(f"v_mov_b32 v{AADDR}, %3", writes=[AADDR], valu=True)
+    s.ins(f"v_add_u32 v{RW2}, {8 * RED_STRIDE}, %4", writes=[RW2], valu=True)
     if carry:
         s.ins(f"v_mov_b32 v{RSADDR}, %9", writes=[RSADDR], valu=True)
     s.ins(f"ds_read_b128 v[{ASET[0]}:{ASET[0] + 3}], %3 offset:0", writes=rng(ASET[0], 4), lds_load=True)
@@ -729,7 +735,7 @@ def main():
                         "        int m, counter;\n"
                         f"        asm volatile(MM_SCREEN_MX_ASM_{name}\n"
                         "                     : \"=&v\"(m), \"=&s\"(counter)\n"
-                        "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"v\"(vPERM), \"s\"(nloop), \"s\"(tail), \"v\"(vRS)\n"
+                        "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"s\"(0), \"s\"(nloop), \"s\"(tail), \"v\"(vRS)\n"
                         f"                     : MM_SCREEN_MX_CLOBBERS_{name});\n"
                         "        return m;\n    }\n};\n")
         f.write("template <int NCT> struct MxEmit;\n")
@@ -740,7 +746,7 @@ def main():
                     "        int m, counter;\n"
                     f"        asm volatile(MM_SCREEN_MX_ASM_{nct}E\n"
                     "                     : \"=&v\"(m), \"=&s\"(counter)\n"
-                    "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"v\"(vPERM), \"s\"(nloop), \"s\"(tail), \"v\"(vRS), \"v\"(vCS)\n"
+                    "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"s\"(0), \"s\"(nloop), \"s\"(tail), \"v\"(vRS), \"v\"(vCS)\n"
                     f"                     : MM_SCREEN_MX_CLOBBERS_{nct}E);\n"
                     "        return m;\n    }\n};\n")
         f.write("#endif\n")
