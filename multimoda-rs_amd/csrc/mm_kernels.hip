@@ -673,6 +673,30 @@ static __device__ __forceinline__ int wave_max_i32_dpp(int v)
     return a > c ? a : c;
 }
 
+// The generated main phase in its two forms (tools/gen_screen_mx.py): SINGLE -- one MFMA per tile, the row minima cross the
+// lanes through an LDS transpose once per row tile -- and DUAL -- two MFMAs per tile (D and its transpose), both directed
+// minima in-lane, no row reduction.  Column-tile counts up to MM_MX_DUAL_MAX take the dual form: it wins where a row tile has
+// too few column tiles to amortise the single form's reduction (ns per tile per SIMD, dual / single: 64 points 80 / 127,
+// 96: 65 / 82, 128: 57 / 68, 160: 55 / 57, 192: 54 / 54, 208: 53.5 / 51, 521: 51 / 43 -- tools/exp_mx4.sh); from six column
+// tiles on the second MFMA per tile costs more than the reduction it saves (two waves' four MFMAs per tile pair keep the
+// matrix pipe busy 128 of 160 cycles, and a wave that finds it busy stalls its minima too).
+#ifndef MM_MX_DUAL_MAX
+#define MM_MX_DUAL_MAX 5
+#endif
+template <int NCT, bool CARRY>
+static __device__ __forceinline__ int mx_main(unsigned vB, unsigned vA, unsigned vRW, unsigned vRR, int nloop, int tail, unsigned vRS)
+{
+    if constexpr (NCT <= MM_MX_DUAL_MAX) return MxMainD<NCT, CARRY>::run(vB, vA, nloop, tail, vRS);
+    else return MxMain<NCT, CARRY>::run(vB, vA, vRW, vRR, 0u, nloop, tail, vRS);
+}
+template <int NCT>
+static __device__ __forceinline__ int mx_emit(unsigned vB, unsigned vA, unsigned vRW, unsigned vRR, int nloop, int tail, unsigned vRS,
+                                              unsigned vCS)
+{
+    if constexpr (NCT <= MM_MX_DUAL_MAX) return MxEmitD<NCT>::run(vB, vA, nloop, tail, vRS, vCS);
+    else return MxEmit<NCT>::run(vB, vA, vRW, vRR, 0u, nloop, tail, vRS, vCS);
+}
+
 // unsigned minimum over the wave (order-reversing map onto the signed maximum above)
 static __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v)
 {
@@ -711,7 +735,6 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
     const unsigned vRW = red_w + (hi * 16) * MM_SCREEN_MX_RED_STRIDE + l32 * 4;
     const int rh = (l32 >> 2) & 1, rv = (l32 & 3) + 4 * (l32 >> 3);        // row l32 of a tile lives at (half rh, element rv)
     const unsigned vRR = red_w + (rh * 16 + rv) * MM_SCREEN_MX_RED_STRIDE + hi * 64;
-    const unsigned vPERM = (unsigned)((lane ^ 32) * 4);
     const unsigned vRS = lds0 + (unsigned)((size_t)s_rs - (size_t)smem) + l32 * 4;   // MULTI: both halves hold the same value
     const int n_work = n_work_dev ? *n_work_dev : n_work_host;   // device queue: a bounded grid strides over it
 
@@ -762,7 +785,7 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
                     }
                 }
                 // (LDS operations of one wave execute in order: the block's reads below see these writes)
-                int m = MxMain<NCT, false>::run(vB, vA, vRW, vRR, vPERM, nloop, tail, vRS);
+                int m = mx_main<NCT, false>(vB, vA, vRW, vRR, nloop, tail, vRS);
                 m = wave_max_i32_dpp(m);
                 if (lane == 0) out_sq[pd.out_off + a] = __int_as_float(m) * inv_s2;
             }
@@ -788,7 +811,7 @@ k_screen_mx(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ wor
                             s_b[(j >> 5) * 64 + (j & 31)] = mx_col_coords(bx, by);
                         }
                     }
-                    const int mb = MxMain<NCT, true>::run(vB, vA, vRW, vRR, vPERM, nloop, tail, vRS);   // max of the block's column minima
+                    const int mb = mx_main<NCT, true>(vB, vA, vRW, vRR, nloop, tail, vRS);   // max of the block's column minima
                     m = mb > m ? mb : m;
                 }
                 for (int i = lane; i < nrt * 32; i += 64) { const int r = s_rs[i]; m = r > m ? r : m; }
@@ -823,7 +846,6 @@ k_screen_mx_emit(const PairDesc* __restrict__ pairs, const WorkItem* __restrict_
     const unsigned vRW = red_w + (hi * 16) * MM_SCREEN_MX_RED_STRIDE + l32 * 4;
     const int rh = (l32 >> 2) & 1, rv = (l32 & 3) + 4 * (l32 >> 3);
     const unsigned vRR = red_w + (rh * 16 + rv) * MM_SCREEN_MX_RED_STRIDE + hi * 64;
-    const unsigned vPERM = (unsigned)((lane ^ 32) * 4);
     const unsigned vRS = lds0 + (unsigned)((size_t)s_rs - (size_t)smem) + l32 * 4;
     const unsigned vCS = lds0 + (unsigned)((size_t)s_col - (size_t)smem) + lane * 4;
     const int n_work = *n_work_dev;
@@ -849,7 +871,7 @@ k_screen_mx_emit(const PairDesc* __restrict__ pairs, const WorkItem* __restrict_
             }
         }
         __syncthreads();
-        int m = MxEmit<NCT>::run(vB, vA, vRW, vRR, vPERM, nloop, tail, vRS, vCS);     // max of the column minima
+        int m = mx_emit<NCT>(vB, vA, vRW, vRR, nloop, tail, vRS, vCS);     // max of the column minima
         __syncthreads();
         float* const em = emit + (size_t)w.pair * (size_t)(emit_rows + emit_cols);
         for (int i = lane; i < nrt * 32; i += 64) {

@@ -36,7 +36,7 @@ def test_matrix_kernels_keep_two_waves_per_simd_and_spill_nothing(tmp_path):
         get = lambda key: int(re.search(key + r": (\d+)", blk).group(1))
         assert get("VGPRs Spill") == 0 and get(r"ScratchSize \[bytes/lane\]") == 0, name
         if "k_screen_mx" in name:
-            assert get(r"Occupancy \[waves/SIMD\]") == 2, (name, get("VGPRs"), get("AGPRs"))
+            assert get(r"Occupancy \[waves/SIMD\]") >= 2, (name, get("VGPRs"), get("AGPRs"))
             assert get("VGPRs") + get("AGPRs") <= 256, name
         else:
             assert get(r"Occupancy \[waves/SIMD\]") >= 2, name

@@ -84,8 +84,8 @@ class Max:
         return Max(self.h[0] | o.h[0], self.h[1] | o.h[1])
 
 
-def _run(nct, carry, nrt, emit=False):
-    prog, stride, clobbers = _program(f"{nct}{'E' if emit else ('C' if carry else '')}")
+def _run(nct, carry, nrt, emit=False, dual=False):
+    prog, stride, clobbers = _program(f"{'D' if dual else ''}{nct}{'E' if emit else ('C' if carry else '')}")
     colstore = {}                # emit: 256-byte slot of the column store -> Min written
     nloop, tail = (nrt - 1) // 2, (nrt - 1) & 1
     R = {}                       # vector register -> Min / Max / ("A", row tile) / ("B", column tile) / ("addr", bytes) / ("rs", bytes)
@@ -224,11 +224,19 @@ def _run(nct, carry, nrt, emit=False):
             touch(d + a + b, a + b)
             ta, tb = {R[r] for r in a}, {R[r] for r in b}
             assert len(ta) == 1 and len(tb) == 1, f"mixed operand fragments: {ln}"
-            (ka, rt), (kb, ct) = next(iter(ta)), next(iter(tb))
-            assert ka == "A" and kb == "B" and 0 <= rt < nrt, (ln, rt)
-            for v in range(16):
-                R[d[v]] = Min({(rt, ct, v, 0)}, {(rt, ct, v, 1)})
-                mfma_at[d[v]] = st["states"]
+            (ka, ia), (kb, ib) = next(iter(ta)), next(iter(tb))
+            if ka == "A" and kb == "B":           # D = A B^T: a lane's 16 values belong to its column
+                rt, ct = ia, ib
+                assert 0 <= rt < nrt, (ln, rt)
+                for v in range(16):
+                    R[d[v]] = Min({(rt, ct, v, 0)}, {(rt, ct, v, 1)})
+                    mfma_at[d[v]] = st["states"]
+            else:                                  # D' = B A^T (the dual form): a lane's 16 values belong to its row
+                assert dual and ka == "B" and kb == "A" and 0 <= ib < nrt, (ln, ia, ib)
+                rt, ct = ib, ia
+                for v in range(16):
+                    R[d[v]] = Min({("T", rt, ct, v, 0)}, {("T", rt, ct, v, 1)})
+                    mfma_at[d[v]] = st["states"]
             st["n_mfma"] += 1
         elif op == "ds_write2_b32":
             a0 = args[0]
@@ -353,7 +361,48 @@ def _check(nct, carry, nrt, emit=False):
     return r
 
 
+def _check_dual(nct, carry, nrt, emit=False):
+    """The dual form: two MFMAs per tile (D and D'), the column minima from D as in the single form, a row tile's minimum
+    from its D' tiles -- every column tile, all 16 elements, both halves (the halves hold different columns of the same
+    row), folded once into the running maximum (plain) or met with the stored minimum of its slot and written back (carry)."""
+    r = _run(nct, carry, nrt, emit, dual=True)
+    assert r["n_mfma"] == 2 * nrt * nct and not r["gens"]
+    want_cols = [frozenset((rt, ct, v, h) for rt in range(nrt) for v in range(16) for h in range(2)) for ct in range(nct)]
+    want_rows = [frozenset(("T", rt, ct, v, h) for ct in range(nct) for v in range(16) for h in range(2)) for rt in range(nrt)]
+    lo, hi = r["result"].h
+    for w in want_cols:
+        assert w in lo or w in hi, "a column tile's minimum is incomplete"
+    if not carry:
+        for h in (lo, hi):
+            for w in want_rows:
+                assert w in h, "a row tile's minimum is missing from one half"
+        assert (lo | hi) == set(want_rows) | set(want_cols), "something else was folded into the maximum"
+    else:
+        assert (lo | hi) == set(want_cols), "the carry form returns the column minima alone"
+        assert sorted(r["store"]) == list(range(nrt))
+        for rt, w in r["store"].items():
+            assert len(w) == 1, "a slot of the row store is written once per block"
+            for h in range(2):
+                assert w[0].h[h] == want_rows[rt] | {("PREV", rt)}, f"row store slot {rt}"
+    if emit:
+        assert sorted(r["colstore"]) == list(range((nct + 1) // 2))
+        for p_, w in r["colstore"].items():
+            assert w.h[0] == want_cols[2 * p_]
+            assert w.h[1] == want_cols[2 * p_ + 1 if 2 * p_ + 1 < nct else 2 * p_]
+    # 16 minima per tile, five instructions per row tile (+ the loop's address updates), the column fold and the set-up:
+    # nothing else on the vector pipe
+    assert r["n_valu"] <= 16 * nrt * nct + 7 * nrt + 5 * nct + 12, (r["n_valu"], nrt, nct)
+    return r
+
+
 NRTS = [1, 2, 3, 4, 5, 6, 7, 17, 33]
+
+
+@pytest.mark.parametrize("form", ["plain", "carry", "emit"])
+@pytest.mark.parametrize("nct", range(2, 18))
+def test_dual_form_every_tile_once_into_the_right_minima(nct, form):
+    for nrt in NRTS:
+        _check_dual(nct, form != "plain", nrt, emit=form == "emit")
 
 
 @pytest.mark.parametrize("nct", range(2, 18))

@@ -540,6 +540,204 @@ def generate(nct, carry, emit=False):
     return s.out, sorted(s.used)
 
 
+# =====================================================================================================================
+# The DUAL form (round 4): both directed minima taken IN-LANE, no cross-lane row reduction.
+#
+# Per 32 x 32 tile TWO MFMAs on the same operands, swapped:  D = A B^T (a lane's 16 values belong to ITS column: column
+# minimum, as above) and D' = B A^T (a lane's 16 values belong to ITS row -- lane l & 31 is row l & 31 of the row tile, the
+# half picks 16 of the tile's 32 columns -- : row minimum, 8 v_min3_i32 into one register per row tile).  20 issue slots per
+# tile instead of 18, but nothing else: no transpose through LDS, no landing zone, no waits except for the row tile's A
+# fragment; at a row tile's end the halves of its row-minimum register meet (v_permlane32_swap) and go into the running
+# maximum -- four instructions.  tools/ubench_dual.hip: 39.2 ns per tile per SIMD at two waves against 35.7 for the bare
+# loop of the single form -- whose real kernel runs 42 - 43 at 17 x 17 tiles, 51 at 7 x 7 and 67 at 4 x 4 because of its row
+# reduction (tools/exp_mx.sh).  Four 16-register result buffers (D, D' of the tile in flight and of the tile being folded).
+# The matrix pipe is busy 64 of a tile's 80 cycles.
+# Register map: as above up to v75; v70, v71 row-minimum registers of the even / odd row tiles; v75, v77 carry: the stored
+# minimum read back (even / odd row tile); v[84:147] the four result buffers.  Operands as above (%4, %5, %6 unused).
+# =====================================================================================================================
+DD = [[84, 100], [116, 132]]        # [tile parity][0: D, 1: D']
+RMIN = [70, 71]
+TPD = [75, 77]
+
+
+class Dual:
+    def __init__(self, s, nct, carry):
+        self.s, self.nct, self.carry = s, nct, carry
+        self.pending = None          # (column tile, buffer parity, row-tile parity, is the row tile's last tile)
+        self.par = 0
+
+    def load_b(self, tiles):
+        for t in tiles:
+            d = AG + 4 * t
+            self.s.ins(f"ds_read_b64 a[{4 * t}:{4 * t + 1}], %2 offset:{t * 512}", writes=rng(d, 2), lds_load=True)
+            self.s.ins(f"ds_read_b64 a[{4 * t + 2}:{4 * t + 3}], %2 offset:{t * 512}", writes=rng(d + 2, 2), lds_load=True)
+
+    def fold(self, which):
+        """8 minima of the pending tile: which = 0 its column minimum (D), 1 its row minimum (D').  Five of them fold the
+        buffer into itself, independent of each other; three bring the five partial minima and the last value into the
+        accumulator (eight in a row on ONE accumulator, each waiting for the one before, cost 9 % of the loop:
+        tools/exp_mx3.sh, variant X1 against the single form without its reduction)."""
+        t, par, q, _last = self.pending
+        d = DD[par][which]
+        acc = CM + t if which == 0 else RMIN[q]
+        s = self.s
+        for i in range(5):
+            s.ins(f"v_min3_i32 v{d + 3 * i}, v{d + 3 * i}, v{d + 3 * i + 1}, v{d + 3 * i + 2}", reads=rng(d + 3 * i, 3), writes=[d + 3 * i], valu=True)
+        for a, b in ((d, d + 3), (d + 6, d + 9), (d + 12, d + 15)):
+            s.ins(f"v_min3_i32 v{acc}, v{acc}, v{a}, v{b}", reads=[acc, a, b], writes=[acc], valu=True)
+
+    def finish_row_tile(self, q, blocking=False):
+        """the halves of row tile q's minimum register meet; the row's minimum goes into the running maximum (carry: meets the
+        stored minimum of the blocks before and goes back to the row store -- v74 is the slot of the even row tile that is
+        being, or was last, finished: an odd one's is 128 bytes on)"""
+        s = self.s
+        r, off = RMIN[q], 128 * q
+        s.ins(f"v_mov_b32 v{T}, v{r}", reads=[r], writes=[T], valu=True)
+        s.ins(f"v_permlane32_swap_b32 v{r}, v{T}", reads=[r, T], writes=[r, T], permlane=True)
+        if self.carry:
+            if blocking and TPD[q] in s.loading:
+                s.wait()
+            s.ins(f"v_min3_i32 v{r}, v{r}, v{T}, v{TPD[q]}", reads=[r, T, TPD[q]], writes=[r], valu=True)
+            s.ins(f"ds_write_b32 v{RSADDR}, v{r} offset:{off}", reads=[RSADDR, r])
+        else:
+            s.ins(f"v_min_i32 v{r}, v{r}, v{T}", reads=[r, T], writes=[r], valu=True)
+            s.ins(f"v_max_i32 v{ROWMAX}, v{ROWMAX}, v{r}", reads=[ROWMAX, r], writes=[ROWMAX], valu=True)
+        s.ins(f"v_mov_b32 v{r}, {INF}", writes=[r], valu=True)
+
+    def step(self, a_reg, t, q, last, extra=None):
+        """issue the two MFMAs of (row tile of parity q, column tile t); beside them the 8 + 8 minima of the tile before"""
+        s = self.s
+        if s.loading:
+            s.wait()
+        if extra is not None:
+            extra()
+        par, self.par = self.par, self.par ^ 1
+        d, dt = DD[par]
+        prev = self.pending
+        s.ins(f"v_mfma_f32_32x32x16_f16 v[{d}:{d + 15}], v[{a_reg}:{a_reg + 3}], a[{4 * t}:{4 * t + 3}], 0",
+              reads=rng(a_reg, 4) + rng(AG + 4 * t, 4), writes=rng(d, 16), mfma=True)
+        if prev is not None:
+            self.fold(0)
+        s.ins(f"v_mfma_f32_32x32x16_f16 v[{dt}:{dt + 15}], a[{4 * t}:{4 * t + 3}], v[{a_reg}:{a_reg + 3}], 0",
+              reads=rng(a_reg, 4) + rng(AG + 4 * t, 4), writes=rng(dt, 16), mfma=True)
+        if prev is not None:
+            self.fold(1)
+            if prev[3]:
+                self.finish_row_tile(prev[2])
+        self.pending = (t, par, q, last)
+
+    def drain(self):
+        self.fold(0)
+        self.fold(1)
+        _t, _par, q, last = self.pending
+        assert last
+        self.finish_row_tile(q, blocking=True)
+        self.pending = None
+
+
+def dual_row_tile(pipe, nct, q, a_offset_next, a_reg_next, off, first=False):
+    """the steps of a row tile of parity q (its A fragment is in ASET[q]); in its first step the A fragment of the next row
+    tile is requested (offset relative to v73) and -- carry -- its own stored minimum (off: its slot relative to v74 NOW)"""
+    s = pipe.s
+    for t in range(nct):
+        extra = None
+        if t == 0:
+            def extra(q=q):
+                s.ins(f"ds_read_b128 v[{a_reg_next}:{a_reg_next + 3}], v{AADDR} offset:{a_offset_next}", reads=[AADDR], writes=rng(a_reg_next, 4), lds_load=True)
+                if pipe.carry:
+                    s.ins(f"ds_read_b32 v{TPD[q]}, v{RSADDR} offset:{off}", reads=[RSADDR], writes=[TPD[q]], lds_load=True)
+                if first:
+                    pipe.load_b(range(1, nct))
+        pipe.step(ASET[q], t, q, t == nct - 1, extra)
+
+
+def dual_snapshot(s, pipe):
+    return copy.deepcopy((s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.par))
+
+
+def dual_restore(s, pipe, snap):
+    s.n, s.mfma_at, s.valu_at, s.loading, pipe.pending, pipe.par = copy.deepcopy(snap)
+
+
+def generate_dual(nct, carry, emit=False):
+    assert carry or not emit
+    s = Stream()
+    pipe = Dual(s, nct, carry)
+    s.ins(f"v_mov_b32 v{AADDR}, %3", writes=[AADDR], valu=True)
+    if carry:
+        s.ins(f"v_mov_b32 v{RSADDR}, %9", writes=[RSADDR], valu=True)
+    s.ins(f"ds_read_b128 v[{ASET[0]}:{ASET[0] + 3}], %3 offset:0", writes=rng(ASET[0], 4), lds_load=True)
+    pipe.load_b([0])
+    for ct in range(nct):
+        s.ins(f"v_mov_b32 v{CM + ct}, {INF}", writes=[CM + ct], valu=True)
+    s.ins(f"v_mov_b32 v{ROWMAX}, 0", writes=[ROWMAX], valu=True)
+    for r in RMIN:
+        s.ins(f"v_mov_b32 v{r}, {INF}", writes=[r], valu=True)
+    dual_row_tile(pipe, nct, 0, 1024, ASET[1], 0, first=True)
+    s.raw("s_mov_b32 %1, %7")
+    s.raw("s_cmp_eq_u32 %1, 0")
+    s.raw("s_cbranch_scc1 2f")
+    after_prologue = dual_snapshot(s, pipe)
+    s.label("1:")
+
+    def body_from(entry):
+        dual_restore(s, pipe, entry)
+        m0 = s.mark()
+        dual_row_tile(pipe, nct, 1, 2048, ASET[0], 128)
+        # (the even row tile's slot is 256 bytes on when its stored minimum is requested; v74 has advanced by the time the
+        # tile is finished -- in the next iteration's, or the tail's, first step)
+        dual_row_tile(pipe, nct, 0, 3072, ASET[1], 256)
+        s.ins(f"v_add_u32 v{AADDR}, 2048, v{AADDR}", reads=[AADDR], writes=[AADDR], valu=True)
+        if carry:
+            s.ins(f"v_add_u32 v{RSADDR}, 256, v{RSADDR}", reads=[RSADDR], writes=[RSADDR], valu=True)
+        s.raw("s_sub_u32 %1, %1, 1")
+        s.raw("s_cmp_lg_u32 %1, 0")
+        s.raw("s_cbranch_scc1 1b")
+        text, end = s.out[m0:], dual_snapshot(s, pipe)
+        del s.out[m0:]
+        return text, end
+
+    body, after_body = body_from(after_prologue)
+    for _ in range(8):
+        nxt, end = body_from(merge_snapshots(after_prologue, after_body))
+        stable = nxt == body
+        body, after_body = nxt, end
+        if stable:
+            break
+    else:
+        raise AssertionError("the loop body does not settle")
+    s.out += body
+    s.label("2:")
+
+    def tail_and_epilogue(entry):
+        dual_restore(s, pipe, entry)
+        m0 = s.mark()
+        s.raw("s_cmp_lg_u32 %8, 0")
+        s.raw("s_cbranch_scc1 3f")
+        at_branch = dual_snapshot(s, pipe)
+        pipe.drain()
+        a_end = dual_snapshot(s, pipe)
+        s.raw("s_branch 4f")
+        s.label("3:")
+        dual_restore(s, pipe, at_branch)
+        dual_row_tile(pipe, nct, 1, 2048, ASET[0], 128)
+        pipe.drain()
+        b_end = dual_snapshot(s, pipe)
+        s.label("4:")
+        dual_restore(s, pipe, merge_snapshots(a_end, b_end))
+        column_final(s, nct, emit)
+        s.wait()                                       # (the unused A request of the last row tile)
+        text = s.out[m0:]
+        del s.out[m0:]
+        return text
+
+    t_a = tail_and_epilogue(merge_snapshots(after_prologue, after_body))
+    t_b = tail_and_epilogue(merge_snapshots(after_body, after_prologue))
+    assert t_a == t_b, "the code behind the loop must not depend on whether the loop ran"
+    s.out += t_a
+    return s.out, sorted(s.used)
+
+
 def generate_bound(nb):
     """The bound kernel's pass (k_bound_mx, mm_kernels.hip): `nb` column tiles of queries held in registers (operands
     %4 .., the B fragments: query tiles of one candidate and / or of several candidates) against the row tiles of a set in
@@ -715,6 +913,16 @@ def main():
                 f.write(f'    "{line}\\n" \\\n')
             f.write('    ""\n')
             f.write(f"#define MM_SCREEN_MX_CLOBBERS_{nct}E " + ", ".join(regname(r) for r in regs) + ', "scc", "memory"\n')
+        for carry, emit, suffix, what in ((False, False, "", "plain"), (True, False, "C", "carry"), (True, True, "E", "carry + column store")):
+            for nct in range(NCT_MIN, NCT_MAX + 1):
+                out, regs = generate_dual(nct, carry, emit)
+                total += len(out)
+                f.write(f"// ---- DUAL form, nct = {nct}, {what}: {len(out)} instructions\n")
+                f.write(f"#define MM_SCREEN_MX_ASM_D{nct}{suffix} \\\n")
+                for line in out:
+                    f.write(f'    "{line}\\n" \\\n')
+                f.write('    ""\n')
+                f.write(f"#define MM_SCREEN_MX_CLOBBERS_D{nct}{suffix} " + ", ".join(regname(r) for r in regs) + ', "scc", "memory"\n')
         for nb in BOUND_NB:
             out, regs = generate_bound(nb)
             total += len(out)
@@ -749,8 +957,29 @@ def main():
                     "                     : \"v\"(vB), \"v\"(vA), \"v\"(vRW), \"v\"(vRR), \"s\"(0), \"s\"(nloop), \"s\"(tail), \"v\"(vRS), \"v\"(vCS)\n"
                     f"                     : MM_SCREEN_MX_CLOBBERS_{nct}E);\n"
                     "        return m;\n    }\n};\n")
+        f.write("template <int NCT, bool CARRY> struct MxMainD;\ntemplate <int NCT> struct MxEmitD;\n")
+        for carry in (False, True):
+            for nct in range(NCT_MIN, NCT_MAX + 1):
+                name = f"D{nct}{'C' if carry else ''}"
+                f.write(f"template <> struct MxMainD<{nct}, {'true' if carry else 'false'}> {{\n"
+                        "    static __device__ __forceinline__ int run(unsigned vB, unsigned vA, int nloop, int tail, unsigned vRS)\n    {\n"
+                        "        int m, counter;\n"
+                        f"        asm volatile(MM_SCREEN_MX_ASM_{name}\n"
+                        "                     : \"=&v\"(m), \"=&s\"(counter)\n"
+                        "                     : \"v\"(vB), \"v\"(vA), \"s\"(0), \"s\"(0), \"s\"(0), \"s\"(nloop), \"s\"(tail), \"v\"(vRS)\n"
+                        f"                     : MM_SCREEN_MX_CLOBBERS_{name});\n"
+                        "        return m;\n    }\n};\n")
+        for nct in range(NCT_MIN, NCT_MAX + 1):
+            f.write(f"template <> struct MxEmitD<{nct}> {{\n"
+                    "    static __device__ __forceinline__ int run(unsigned vB, unsigned vA, int nloop, int tail, unsigned vRS, unsigned vCS)\n    {\n"
+                    "        int m, counter;\n"
+                    f"        asm volatile(MM_SCREEN_MX_ASM_D{nct}E\n"
+                    "                     : \"=&v\"(m), \"=&s\"(counter)\n"
+                    "                     : \"v\"(vB), \"v\"(vA), \"s\"(0), \"s\"(0), \"s\"(0), \"s\"(nloop), \"s\"(tail), \"v\"(vRS), \"v\"(vCS)\n"
+                    f"                     : MM_SCREEN_MX_CLOBBERS_D{nct}E);\n"
+                    "        return m;\n    }\n};\n")
         f.write("#endif\n")
-    print(total, "instructions in", 3 * (NCT_MAX - NCT_MIN + 1), "blocks ->", os.path.normpath(dst))
+    print(total, "instructions in", 6 * (NCT_MAX - NCT_MIN + 1), "blocks ->", os.path.normpath(dst))
 
 
 if __name__ == "__main__":
