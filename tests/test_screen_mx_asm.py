@@ -1,18 +1,24 @@
 """The generated main phases of k_screen_mx (csrc/mm_screen_mx_asm.inc, tools/gen_screen_mx.py), executed symbolically.
 
-One asm block per column-tile count (2 .. 17) in two forms (plain; carry = the row minima go through a row store, for
-target sets cut into column blocks), the row-tile count a run-time operand: hundreds to ~1600 hand-scheduled instructions
-each on fixed registers, a loop, a tail and two epilogues; nothing in them is checked by the compiler.  This test interprets
-the committed text with SETS in the registers, one per half of the wave (lanes 0-31 and 32-63 hold different rows of an MFMA
-result) -- an MFMA writes the atoms (row tile, column tile, element, half), a minimum is a union, a maximum collects
-finished minima -- for row-tile counts 1 .. 7, 17 and 33, and requires that at the end
+One asm block per column-tile count (2 .. 17) in three forms (plain; carry = the row minima go through a row store, for
+target sets cut into column blocks; emit = carry + a column store, for the first pick of a bounded search) and two schemes
+(SINGLE: one MFMA per tile, the row minima cross the lanes through an LDS transpose; DUAL: two MFMAs per tile on swapped
+operands, both minima in-lane), the row-tile count a run-time operand: hundreds to ~1400 hand-scheduled instructions each on
+fixed registers, a loop, a tail and two epilogues; nothing in them is checked by the compiler.  This test interprets the
+committed text with SETS in the registers, one per half of the wave (lanes 0-31 and 32-63 hold different rows of an MFMA
+result) -- an MFMA writes the atoms (row tile, column tile, element, half), or their transposed twins for the dual form's
+second MFMA, a minimum is a union, a maximum collects finished minima -- for row-tile counts 1 .. 7, 17 and 33, and requires
+that at the end
   * the value that leaves the block is the maximum over exactly: the COMPLETE column minimum of each column tile (all row
     tiles, 16 elements, both halves -- nothing missing, nothing folded twice into a different minimum) and, in the plain
-    form, every row tile's reduction,
-  * every row tile's minima went through the reduction scratch exactly once, complete (all column tiles, element by
-    element), and were read back in full,
-  * carry form: every row tile's reduction met the stored minimum of ITS slot of the row store and was written back there,
-    once,
+    form, every row tile's minimum,
+  * single scheme: every row tile's minima went through the reduction scratch exactly once, complete (all column tiles,
+    element by element), and were read back in full; dual scheme: a row tile's minimum holds every transposed atom of its
+    column tiles from both halves,
+  * carry form: every row tile's minimum met the stored minimum of ITS slot of the row store and was written back there,
+    once; emit form: the column store holds every column tile's complete minimum,
+  * a candidate's column fragments are read once, into the accumulation registers a[4t : 4t + 3] of their tile, and every MFMA
+    takes the fragment of its own tile,
   * no register is read while an LDS load into it is outstanding, no MFMA destination is touched within 12 wait states
     of its MFMA (8 passes: 11 required; the assembler pads nothing inside an asm string), no v_permlane32_swap reads a
     register a vector instruction wrote fewer than 2 wait states before -- on every path through the branches.
