@@ -443,17 +443,18 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
     TraceTimer tt_work("stage_level: work list");
     // ---- work decomposition: one workgroup = `apb` consecutive candidates of one pair ----
     const int64_t target_wgs = 256 * 24;
-    // at most 8 candidates per workgroup: measured on config3 (apb 2/4/8/16/64/128: 140.6/145.0/146.3/
+    // the packed-FMA and exact kernels: at most 8 candidates per workgroup, measured on config3 (apb 2/4/8/16/64/128: 140.6/145.0/146.3/
     // 144.6/138.2/122.3 TFLOP/s) -- many short workgroups keep the co-resident ones out of phase
     // (rotation / epilogue of one overlaps the micro-tile loop of the others) and balance the tail
     int apb = (int)std::min<int64_t>(8, std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs));
     // matrix-pipe screen: one WAVE per candidate, four waves per workgroup -- a workgroup of fewer than four candidates
     // leaves waves idle for the whole item (small batches: a single search of 361 candidates)
     if (use_mx) apb = std::max(apb, 4);
-    // ... and of SMALL sets more of them: a work item stages the pair's rows once (global loads, two barriers: ~3 us with
-    // two workgroups per CU to hide it), and 8 candidates of 7 x 7 tiles are over in 3.6 us.  A wave should see ~600 tiles
-    // per item (17 x 17 tiles: 2 candidates, as measured above; 7 x 7: 12), as far as the batch has candidates for
-    // 24 workgroups per CU.
+    // ... and with the matrix-pipe screen more of them: a work item stages the pair's rows once (global loads, two barriers:
+    // ~3 us, with one other workgroup on the CU to hide it) and a 17 x 17-tile candidate takes a wave 10 us, a 7 x 7 one 1.8.
+    // A wave should see ~2300 tiles per item (17 x 17 tiles: 8 candidates, 32 per workgroup; small sets up to 16 per wave) as
+    // far as the batch has candidates for 24 workgroups per CU: config3's launch 16.19 ms at 578 tiles, 16.00 at 1156,
+    // 15.83 at 2312, 15.77 at 4624 (tools/exp_apb.sh).
     const int64_t apb_fill = std::max<int64_t>(1, (A + target_wgs - 1) / target_wgs);
     auto apb_of = [&](int p) {
         if (!use_mx || pair_key[(size_t)p] < 2) return apb;
@@ -461,7 +462,7 @@ int Plan::stage_level(const std::vector<PairSpec>& pairs, int precision_, int32_
         int nct = 0, multi = 0;
         mx_variant(d.n_tgt, &nct, &multi);
         const int64_t tiles = (int64_t)((d.n_ref + 31) / 32) * ((d.n_tgt + 31) / 32);
-        const int64_t per_wave = std::min<int64_t>(16, std::max<int64_t>(2, (578 + tiles - 1) / tiles));
+        const int64_t per_wave = std::min<int64_t>(16, std::max<int64_t>(2, (2312 + tiles - 1) / tiles));
         return (int)std::max<int64_t>(apb, std::min<int64_t>(4 * per_wave, apb_fill));
     };
     groups.clear();
