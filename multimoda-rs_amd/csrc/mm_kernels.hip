@@ -544,9 +544,10 @@ k_screen_fast(const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ w
 // runs entirely beside the 16 minima (34 ns per tile per SIMD against 82 for the packed-FMA form); the compiler's
 // own schedule does not (46 ns), so the main phase is one generated asm block (tools/gen_screen_mx.py).
 // The workgroup shares the pair's row fragments; below that every WAVE takes candidates of its own (a0 + wave, + 4, ...)
-// and computes all 17 x 17 tiles of each: column fragments in a wave-private LDS copy, column minima in registers for the
-// whole candidate, row minima across the 32 column lanes through a wave-private LDS transpose -- no barrier and no shared
-// accumulator in the candidate loop.  Error of the screened value: PairDesc::e2 = mx_e2(rho_a, rho_b) (mm_engine.cpp).
+// and computes all 17 x 17 tiles of each: column fragments written to a wave-private LDS copy and read from there ONCE, into
+// accumulation registers (every MFMA of a column tile takes its B operand from a[4t : 4t + 3]), column minima in registers
+// for the whole candidate, row minima across the 32 column lanes through a wave-private LDS transpose (or, for small sets,
+// in-lane from a second, transposed MFMA per tile: the DUAL form) -- no barrier and no shared accumulator in the candidate loop.  Error of the screened value: PairDesc::e2 = mx_e2(rho_a, rho_b) (mm_engine.cpp).
 // Set sizes: the column-tile count NCT (target set, <= 17 per block) is a template parameter -- the column minima live in
 // one register per column tile -- and the row-tile count (reference set) is a run-time operand of the asm block; a target
 // set of more than 544 points is cut into equal blocks of NCT tiles (MULTI: the row minima are carried from block to block

@@ -24,20 +24,24 @@ folds into it with 16 three-operand minima.  Per row tile at nct = 17: 8 (column
 vector instructions for 17 tiles; the floor of two values per instruction, each value used twice, would be 272 -- the init
 tile's row half costs nothing.
 
-The cross-lane reduction of a row tile's minima (LDS transpose: write, read back a row per lane, fold, meet the other
-half through ds_bpermute) is spread over the steps of the NEXT row tile, each LDS round trip behind a wait the pipeline
-has anyway where the row tile has steps enough (nct >= 14: seven stages, four values read back at a time; below that all
-16 values of a row are read back at once into a landing zone of their own, three round trips, the surplus ones behind
-waits of their own).  The column minima stay in registers for the whole candidate (this wave has seen every row); lanes l
+The cross-lane reduction of a row tile's minima (LDS transpose: two rows per ds_write2_b32, a row read back per lane 16
+bytes at a time, fold, meet the other half through v_permlane32_swap) is spread over the steps of the NEXT row tile, one
+stage at the head of a step, where the row tile has steps enough (nct >= 12: seven stages, four values read back at a time;
+below that all 16 values of a row are read back at once into a landing zone of their own, three round trips, the surplus
+ones behind waits of their own).
+
+A candidate's column (B) fragments are read from LDS ONCE, into accumulation registers a[4t : 4t + 3], and every MFMA of column
+tile t takes its B operand from there (the init tile's come with the prologue, the others behind the first MFMA): the
+only LDS traffic of the main loop is a row tile's A fragment and its reduction.  The column minima stay in registers for the whole candidate (this wave has seen every row); lanes l
 and l + 32 hold different rows of the same column, so at the end v_permlane32_swap brings the halves of two column tiles
 together, one minimum per pair, and the maximum over everything leaves in one register.
 
 Wait states: nothing in an asm string is padded by the assembler.  The generator tracks every MFMA's destination and
 pads (s_nop) where fewer than MFMA_STATES instructions separate it from the first instruction that touches the buffer,
 pads a vector write ahead of a v_permlane32_swap, and refuses to read a register an LDS load is still filling.  Where two
-paths meet (zero loop iterations, the tail) the code after the join is generated from either predecessor state and
-required to be the same text.  tests/test_screen_mx_asm.py executes every block symbolically for row-tile counts 1 .. 9
-and 17.
+paths meet (the loop's entry, its exit) the code after the join is generated from the MERGED state of the predecessors --
+every hazard at the distance of the closer path -- until the text settles.  tests/test_screen_mx_asm.py executes every block
+symbolically for row-tile counts 1 .. 7, 17 and 33.
 
 Register map (VGPR):
   v36        rowmax     max over rows of the row minima (signed-int order on f32 bits, floored at 0)
@@ -46,9 +50,12 @@ Register map (VGPR):
   v[68:71], v72         reduction: four values read back, accumulator
   v73                   LDS address of the A fragments, advanced by two row tiles per loop iteration
   v74, v75              carry: address of the row store (advanced like v73), the stored minimum read back
-  v[80:87], v[88:95]    B operand fragments, two groups (double buffer)
-  v[100:195]            six result buffers P, Q, R, S, X0, X1
-  v[196:211]            nct < 14: landing zone of the reduction (16 values of a row)
+  v76                   LDS address of row 8 of this lane's column in the reduction scratch
+  v[84:179]             six result buffers P, Q, R, S, X0, X1
+  v[180:195]            nct < 12: landing zone of the reduction (16 values of a row)
+  a[0 : 4 nct)          the candidate's column (B) fragments
+(180 or 196 vector registers + up to 68 accumulation registers: two waves per SIMD, to the last register at nct = 17 --
+tests/test_kernel_resources.py.)
 Operands: %0 out: this lane's maximum; %1 =s loop counter; %2 vB (LDS byte address of this lane's B fragment in column
 tile 0, the wave's own copy); %3 vA (A fragment of row tile 0; the next ones 1024 bytes apart); %4 vRW / %5 vRR
 (row-reduction scratch: write / read address); %6 unused (a scalar zero: the halves meet through v_permlane32_swap); %7 s: loop iterations = (row tiles - 1) / 2;
