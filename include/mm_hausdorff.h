@@ -143,15 +143,16 @@ int  mm_engine_screen_stats(mm_engine* e, int64_t out[5]);
 /* MM_PRECISION_F32_BOUNDED runs its bound rounds only on batches of at least n candidates (default
  * 16384): a dozen dependent launches cost more than screening a small batch outright. 0 = always. */
 int  mm_engine_set_bound_min_candidates(mm_engine* e, int64_t n);
-/* MM_PRECISION_F32_BOUNDED computes its lower bounds and screens its survivors on the f16 matrix pipe when every pair of
- * the batch has sets of 64 .. 1024 points (default, on != 0); on == 0 keeps the packed-FMA kernels of rounds 1-3 (the A/B
- * switch of bench.py's bounded_search leg).  Same winners and costs either way. */
+/* MM_PRECISION_F32_BOUNDED computes its lower bounds, its picks and its survivors on the f16 matrix pipe when every pair of
+ * the batch has sets of 64 .. 544 points and the target sets share one column-tile count (default, on != 0; a batch of other
+ * shapes is screened outright on the matrix pipe, without bound rounds); on == 0 keeps the packed-FMA kernels of rounds 1-3
+ * (the A/B switch of bench.py's bounded_search leg).  Same winners and costs either way. */
 int  mm_engine_set_bound_matrix(mm_engine* e, int on);
 
 /* TEST HOOK (nothing in the product calls it): the lower bound MM_PRECISION_F32_BOUNDED's bound kernels give every
  * candidate of one search -- out_lb2[i] <= (exact cost of candidate i)^2 up to *e2 (error bound of the kernel's squared
  * values) and *delta (of the distance); *stride = every stride-th point of either set was a query.  matrix != 0: the
- * matrix-pipe kernel (sets of 64 .. 1024 points), 0: the packed-FMA kernel. */
+ * matrix-pipe kernel (sets of 64 .. 544 points), 0: the packed-FMA kernel. */
 int  mm_lower_bounds(mm_engine* e, const double* rx, const double* ry, int nr, const double* tx, const double* ty, int nt,
                      double cx, double cy, const double* angles, int n_angles, int flags, int matrix, float* out_lb2,
                      double* e2, double* delta, int* stride);
